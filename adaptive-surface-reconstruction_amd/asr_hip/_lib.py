@@ -1,0 +1,186 @@
+"""ctypes binding of libasr_hip.so (C ABI: include/asr_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU is present the
+calls below raise.  Device memory comes from torch (plumbing only): every pointer handed to
+the library is tensor.data_ptr() of a contiguous CUDA(HIP) tensor.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libasr_hip.so")
+
+ASR_MAX_LEVEL = 21
+ASR_NUM_GRIDS = 5
+
+
+class AsrHipError(RuntimeError):
+    pass
+
+
+class OctreeFrame(ctypes.Structure):
+    _fields_ = [
+        ("voxel_size", ctypes.c_float * (ASR_MAX_LEVEL + 1)),
+        ("inv_voxel_size", ctypes.c_float * (ASR_MAX_LEVEL + 1)),
+        ("offset", ctypes.c_int32 * 3),
+        ("bb_min", ctypes.c_float * 3),
+        ("bb_max", ctypes.c_float * 3),
+    ]
+
+
+class SparseConvArgs(ctypes.Structure):
+    _fields_ = [
+        ("filters", ctypes.c_void_p),
+        ("inp_features", ctypes.c_void_p),
+        ("inp_ld", ctypes.c_int64),
+        ("inp_importance", ctypes.c_void_p),
+        ("neighbors_importance", ctypes.c_void_p),
+        ("neighbors_index", ctypes.c_void_p),
+        ("neighbors_kernel_index", ctypes.c_void_p),
+        ("neighbors_row_splits", ctypes.c_void_p),
+        ("num_out", ctypes.c_int64),
+        ("num_inp", ctypes.c_int64),
+        ("kernel_size", ctypes.c_int),
+        ("cin", ctypes.c_int),
+        ("cout", ctypes.c_int),
+        ("normalize", ctypes.c_int),
+        ("bias", ctypes.c_void_p),
+        ("relu", ctypes.c_int),
+        ("residual", ctypes.c_void_p),
+        ("residual_ld", ctypes.c_int64),
+        ("out", ctypes.c_void_p),
+        ("out_ld", ctypes.c_int64),
+        ("out_importance", ctypes.c_void_p),
+        ("algo", ctypes.c_int),
+    ]
+
+
+class Weight(ctypes.Structure):
+    _fields_ = [
+        ("name", ctypes.c_char_p),
+        ("data", ctypes.c_void_p),
+        ("ndim", ctypes.c_int32),
+        ("shape", ctypes.c_int64 * 5),
+    ]
+
+
+class ImplicitParams(ctypes.Structure):
+    _fields_ = [
+        ("point_radius_scale", ctypes.c_float),
+        ("octree_max_depth", ctypes.c_int),
+        ("bb_min", ctypes.c_float * 3),
+        ("bb_max", ctypes.c_float * 3),
+        ("scale_sdf", ctypes.c_int),
+    ]
+
+
+class ImplicitSizes(ctypes.Structure):
+    _fields_ = [
+        ("num_points", ctypes.c_int64),
+        ("num_nodes", ctypes.c_int64),
+        ("num_voxels", ctypes.c_int64 * ASR_NUM_GRIDS),
+        ("num_pairs", ctypes.c_int64 * ASR_NUM_GRIDS),
+        ("num_agg_pairs", ctypes.c_int64),
+    ]
+
+
+# every symbol declared in include/asr_hip.h (tests/test_abi.py checks the list against the header)
+EXPORTS = [
+    "asr_hip_context_create", "asr_hip_context_destroy", "asr_hip_context_set_stream",
+    "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes",
+    "asr_hip_struct_size",
+    "asr_octree_frame_init", "asr_hip_point_keys", "asr_hip_octree_build", "asr_hip_octree_get",
+    "asr_hip_grid_neighbors_count", "asr_hip_grid_neighbors_fill", "asr_hip_grid_coarsen_count",
+    "asr_hip_grid_coarsen_fill", "asr_hip_voxel_info", "asr_hip_multi_radius_search_count",
+    "asr_hip_multi_radius_search_fill", "asr_hip_continuous_conv_f32",
+    "asr_hip_aggregation_importance", "asr_hip_sparse_conv_f32", "asr_hip_invert_neighbors_list",
+    "asr_hip_reduce_subarrays_sum", "asr_hip_decode_mlp", "asr_hip_implicit_build",
+    "asr_hip_implicit_network", "asr_hip_implicit_forward", "asr_hip_implicit_get",
+    "asr_hip_implicit_stage_ms",
+]
+
+_lib = None
+
+
+def load():
+    """Loads libasr_hip.so; raises AsrHipError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AsrHipError(
+                "libasr_hip.so not found at %s -- build it with __graft_entry__.build() or "
+                "`make -C adaptive-surface-reconstruction_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.asr_hip_last_error.restype = ctypes.c_char_p
+        lib.asr_hip_version.restype = ctypes.c_char_p
+        lib.asr_hip_context_reserved_bytes.restype = ctypes.c_size_t
+        lib.asr_hip_struct_size.restype = ctypes.c_size_t
+        for name, cls in (("asr_octree_frame", OctreeFrame), ("asr_sparse_conv_args", SparseConvArgs),
+                          ("asr_weight", Weight), ("asr_implicit_params", ImplicitParams),
+                          ("asr_implicit_sizes", ImplicitSizes)):
+            if lib.asr_hip_struct_size(name.encode()) != ctypes.sizeof(cls):
+                raise AsrHipError("ABI mismatch: struct %s has a different size in libasr_hip.so"
+                                  % name)
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise AsrHipError("expected a GPU tensor: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise AsrHipError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Context:
+    """asr_hip_context bound to a torch stream."""
+
+    def __init__(self, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise AsrHipError("no GPU visible: the MI355X path cannot run (no CPU fallback)")
+        self.lib = load()
+        self._h = ctypes.c_void_p(0)
+        s = stream if stream is not None else torch.cuda.current_stream()
+        rc = self.lib.asr_hip_context_create(ctypes.byref(self._h), ctypes.c_void_p(s.cuda_stream))
+        if rc != 0:
+            raise AsrHipError("asr_hip_context_create failed with code %d" % rc)
+
+    def set_stream(self, stream):
+        self.lib.asr_hip_context_set_stream(self._h, ctypes.c_void_p(stream.cuda_stream))
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.asr_hip_last_error(self._h)
+            raise AsrHipError("asr_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+    def call(self, name, *args):
+        self.check(getattr(self.lib, name)(self._h, *args))
+
+    def reserved_bytes(self):
+        return int(self.lib.asr_hip_context_reserved_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            self.lib.asr_hip_context_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def frame_init(bb_min, bb_max):
+    f = OctreeFrame()
+    mn = (ctypes.c_float * 3)(*[float(x) for x in bb_min])
+    mx = (ctypes.c_float * 3)(*[float(x) for x in bb_max])
+    rc = load().asr_octree_frame_init(ctypes.byref(f), mn, mx)
+    if rc != 0:
+        raise AsrHipError("asr_octree_frame_init failed (degenerate bounding box?)")
+    return f

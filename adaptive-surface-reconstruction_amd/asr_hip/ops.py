@@ -1,0 +1,254 @@
+"""Per-stage operators on GPU torch tensors, thin wrappers over the C ABI (include/asr_hip.h).
+
+Names and argument meaning follow the reference interfaces they stand in for:
+  create_octree / create_grids_from_octree  -> cpp/pybind/module.cpp:144-228
+  multi_radius_search                        -> cpp/lib/nsearch.cpp:107-162
+  continuous_conv / sparse_conv / invert_neighbors_list / reduce_subarrays_sum
+                                             -> open3d.ml.torch.ops used by models/common_torch.py
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AsrHipError, Context, ptr
+
+_ctx = None
+
+
+def context():
+    """process-wide context on torch's current stream"""
+    global _ctx
+    if _ctx is None:
+        _ctx = Context()
+    _ctx.set_stream(torch.cuda.current_stream())
+    return _ctx
+
+
+def _dev(t, dtype):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    if not t.is_cuda:
+        raise AsrHipError("expected a GPU tensor: the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+i64 = ctypes.c_int64
+
+
+def point_keys(frame, points, radii, radius_scale=1.0, max_depth=21):
+    points = _dev(points, torch.float32)
+    radii = _dev(radii, torch.float32)
+    n = points.shape[0]
+    keys = torch.empty(n, dtype=torch.int64, device=points.device)
+    context().call("asr_hip_point_keys", ctypes.byref(frame), ptr(points), ptr(radii), i64(n),
+                   ctypes.c_float(radius_scale), int(max_depth), ptr(keys))
+    return keys  # uint64 bit pattern in an int64 tensor
+
+
+def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
+    """-> (nodes, leaves) sorted uint64 keys (as int64 tensors)"""
+    points = _dev(points, torch.float32)
+    radii = _dev(radii, torch.float32)
+    if points.ndim != 2 or points.shape[1] != 3:
+        raise ValueError("points must have shape [N,3]")
+    if radii.ndim != 1 or radii.shape[0] != points.shape[0]:
+        raise ValueError("radii must have shape [N]")
+    nn, nl = i64(0), i64(0)
+    ctx = context()
+    ctx.call("asr_hip_octree_build", ctypes.byref(frame), ptr(points), ptr(radii),
+             i64(points.shape[0]), ctypes.c_float(radius_scale), int(max_depth), ctypes.byref(nn),
+             ctypes.byref(nl))
+    nodes = torch.empty(nn.value, dtype=torch.int64, device=points.device)
+    leaves = torch.empty(nl.value, dtype=torch.int64, device=points.device)
+    ctx.call("asr_hip_octree_get", ptr(nodes), ptr(leaves))
+    return nodes, leaves
+
+
+def grid_neighbors(keys):
+    keys = _dev(keys, torch.int64)
+    v = keys.shape[0]
+    rs = torch.empty(v + 1, dtype=torch.int64, device=keys.device)
+    p = i64(0)
+    ctx = context()
+    ctx.call("asr_hip_grid_neighbors_count", ptr(keys), i64(v), ptr(rs), ctypes.byref(p))
+    idx = torch.empty(p.value, dtype=torch.int32, device=keys.device)
+    kidx = torch.empty(p.value, dtype=torch.uint8, device=keys.device)
+    ctx.call("asr_hip_grid_neighbors_fill", ptr(keys), i64(v), ptr(rs), ptr(idx), ptr(kidx))
+    return idx, kidx, rs
+
+
+def grid_coarsen(keys):
+    keys = _dev(keys, torch.int64)
+    v = keys.shape[0]
+    vo = i64(0)
+    ctx = context()
+    ctx.call("asr_hip_grid_coarsen_count", ptr(keys), i64(v), ctypes.byref(vo))
+    out_keys = torch.empty(vo.value, dtype=torch.int64, device=keys.device)
+    up_idx = torch.empty(v, dtype=torch.int32, device=keys.device)
+    up_kidx = torch.empty(v, dtype=torch.uint8, device=keys.device)
+    up_rs = torch.empty(v + 1, dtype=torch.int64, device=keys.device)
+    ctx.call("asr_hip_grid_coarsen_fill", ptr(keys), i64(v), ptr(out_keys), vo, ptr(up_idx),
+             ptr(up_kidx), ptr(up_rs))
+    return out_keys, up_idx, up_kidx, up_rs
+
+
+def voxel_info(frame, keys):
+    keys = _dev(keys, torch.int64)
+    v = keys.shape[0]
+    centers = torch.empty((v, 3), dtype=torch.float32, device=keys.device)
+    sizes = torch.empty(v, dtype=torch.float32, device=keys.device)
+    context().call("asr_hip_voxel_info", ctypes.byref(frame), ptr(keys), i64(v), ptr(centers),
+                   ptr(sizes))
+    return centers, sizes
+
+
+def multi_radius_search(frame, points, radii, centers, sizes):
+    """-> (index int32, squared dist f32, row_splits int64, scale_compat f32)"""
+    points = _dev(points, torch.float32)
+    radii = _dev(radii, torch.float32)
+    centers = _dev(centers, torch.float32)
+    sizes = _dev(sizes, torch.float32)
+    n, v = points.shape[0], sizes.shape[0]
+    rs = torch.empty(v + 1, dtype=torch.int64, device=points.device)
+    p = i64(0)
+    ctx = context()
+    ctx.call("asr_hip_multi_radius_search_count", ctypes.byref(frame), ptr(points), i64(n),
+             ptr(centers), ptr(sizes), i64(v), ptr(rs), ctypes.byref(p))
+    idx = torch.empty(p.value, dtype=torch.int32, device=points.device)
+    dist = torch.empty(p.value, dtype=torch.float32, device=points.device)
+    compat = torch.empty(p.value, dtype=torch.float32, device=points.device)
+    ctx.call("asr_hip_multi_radius_search_fill", ptr(points), ptr(radii), i64(n), ptr(centers),
+             ptr(sizes), i64(v), ptr(rs), ptr(idx), ptr(dist), ptr(compat))
+    return idx, dist, rs, compat
+
+
+def aggregation_importance(compat, dist):
+    compat = _dev(compat, torch.float32)
+    dist = _dev(dist, torch.float32)
+    out = torch.empty_like(compat)
+    context().call("asr_hip_aggregation_importance", ptr(compat), ptr(dist), i64(compat.shape[0]),
+                   ptr(out))
+    return out
+
+
+def continuous_conv(filters, out_positions, extents, inp_positions, inp_features, neighbors_index,
+                    neighbors_importance, neighbors_row_splits, normalize=True, bias=None,
+                    relu=False):
+    filters = _dev(filters, torch.float32)
+    if filters.ndim != 5 or tuple(filters.shape[:3]) != (4, 4, 4):
+        raise RuntimeError("continuous_conv: only kernel_size [4,4,4] is implemented")
+    cin, cout = filters.shape[3], filters.shape[4]
+    out_positions = _dev(out_positions, torch.float32)
+    v = out_positions.shape[0]
+    extents = _dev(extents, torch.float32).reshape(-1)
+    if extents.shape[0] == 1 and v != 1:
+        extents = extents.expand(v).contiguous()
+    if extents.shape[0] != v:
+        raise RuntimeError("continuous_conv: extents must be a scalar or have one entry per output")
+    inp_positions = _dev(inp_positions, torch.float32)
+    inp_features = _dev(inp_features, torch.float32)
+    if inp_features.shape[1] != cin:
+        raise RuntimeError("continuous_conv: feature width does not match the filter")
+    nidx = _dev(neighbors_index, torch.int32)
+    rs = _dev(neighbors_row_splits, torch.int64)
+    nimp = None
+    if neighbors_importance is not None and neighbors_importance.numel():
+        nimp = _dev(neighbors_importance, torch.float32)
+    b = _dev(bias, torch.float32) if bias is not None else None
+    out = torch.empty((v, cout), dtype=torch.float32, device=filters.device)
+    context().call("asr_hip_continuous_conv_f32", ptr(filters), ptr(out_positions), ptr(extents),
+                   ptr(inp_positions), ptr(inp_features), ptr(nidx), ptr(nimp), ptr(rs), i64(v),
+                   int(cin), int(cout), int(bool(normalize)), ptr(b), int(bool(relu)), ptr(out))
+    return out
+
+
+def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
+                neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False,
+                residual=None, out=None, return_importance=False, algo=0,
+                neighbors_importance=None):
+    """SpecialSparseConv.forward (models/common_torch.py:95-148) in one launch."""
+    filters = _dev(filters, torch.float32)
+    K, cin, cout = filters.shape
+    inp_features = _dev(inp_features, torch.float32)
+    nidx = _dev(neighbors_index, torch.int32)
+    nk = _dev(neighbors_kernel_index, torch.uint8)
+    rs = _dev(neighbors_row_splits, torch.int64)
+    v = rs.shape[0] - 1
+    if inp_features.shape[1] != cin:
+        raise RuntimeError("sparse_conv: feature width does not match the filter")
+    imp = _dev(inp_importance, torch.float32) if inp_importance is not None else None
+    nimp = _dev(neighbors_importance, torch.float32) if neighbors_importance is not None else None
+    b = _dev(bias, torch.float32) if bias is not None else None
+    res = _dev(residual, torch.float32) if residual is not None else None
+    if out is None:
+        out = torch.empty((v, cout), dtype=torch.float32, device=filters.device)
+    oimp = torch.empty(v, dtype=torch.float32, device=filters.device) if return_importance else None
+    a = _lib.SparseConvArgs()
+    a.filters = filters.data_ptr()
+    a.inp_features = inp_features.data_ptr()
+    a.inp_ld = inp_features.stride(0)
+    a.inp_importance = imp.data_ptr() if imp is not None else None
+    a.neighbors_importance = nimp.data_ptr() if nimp is not None else None
+    a.neighbors_index = nidx.data_ptr()
+    a.neighbors_kernel_index = nk.data_ptr()
+    a.neighbors_row_splits = rs.data_ptr()
+    a.num_out = v
+    a.num_inp = inp_features.shape[0]
+    a.kernel_size = K
+    a.cin = cin
+    a.cout = cout
+    a.normalize = int(bool(normalize))
+    a.bias = b.data_ptr() if b is not None else None
+    a.relu = int(bool(relu))
+    a.residual = res.data_ptr() if res is not None else None
+    a.residual_ld = res.stride(0) if res is not None else 0
+    a.out = out.data_ptr()
+    a.out_ld = out.stride(0)
+    a.out_importance = oimp.data_ptr() if oimp is not None else None
+    a.algo = int(algo)
+    context().call("asr_hip_sparse_conv_f32", ctypes.byref(a))
+    if return_importance:
+        return out, oimp
+    return out
+
+
+def invert_neighbors_list(num_points, inp_neighbors_index, inp_neighbors_row_splits,
+                          inp_neighbors_attributes=None):
+    idx = _dev(inp_neighbors_index, torch.int32)
+    rs = _dev(inp_neighbors_row_splits, torch.int64)
+    attr = None
+    if inp_neighbors_attributes is not None and inp_neighbors_attributes.numel():
+        attr = _dev(inp_neighbors_attributes, torch.uint8)
+    p = idx.shape[0]
+    out_idx = torch.empty(p, dtype=torch.int32, device=idx.device)
+    out_rs = torch.empty(num_points + 1, dtype=torch.int64, device=idx.device)
+    out_attr = torch.empty(p if attr is not None else 0, dtype=torch.uint8, device=idx.device)
+    context().call("asr_hip_invert_neighbors_list", i64(num_points), ptr(idx), ptr(rs),
+                   i64(rs.shape[0] - 1), ptr(attr), ptr(out_idx), ptr(out_rs),
+                   ptr(out_attr) if attr is not None else ctypes.c_void_p(0))
+    return out_idx, out_rs, out_attr
+
+
+def reduce_subarrays_sum(values, row_splits, gather_index=None):
+    values = _dev(values, torch.float32)
+    rs = _dev(row_splits, torch.int64)
+    g = _dev(gather_index, torch.int32) if gather_index is not None else None
+    out = torch.empty(rs.shape[0] - 1, dtype=torch.float32, device=values.device)
+    context().call("asr_hip_reduce_subarrays_sum", ptr(values), ptr(g), ptr(rs),
+                   i64(rs.shape[0] - 1), ptr(out))
+    return out
+
+
+def decode_mlp(code, w1, b1, w2, b2, w3, voxel_sizes=None):
+    code = _dev(code, torch.float32)
+    w1, b1, w2, b2, w3 = (_dev(t, torch.float32) for t in (w1, b1, w2, b2, w3))
+    sizes = _dev(voxel_sizes, torch.float32) if voxel_sizes is not None else None
+    v, c = code.shape
+    out = torch.empty((v, 2), dtype=torch.float32, device=code.device)
+    context().call("asr_hip_decode_mlp", ptr(code), i64(v), int(c), ptr(w1), ptr(b1),
+                   int(w1.shape[0]), ptr(w2), ptr(b2), int(w2.shape[0]), ptr(w3), ptr(sizes),
+                   ptr(out))
+    return out

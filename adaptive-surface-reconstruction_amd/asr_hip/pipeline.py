@@ -1,0 +1,151 @@
+"""Whole hot path: device-resident points / normals / radii -> values[V0, 2].
+
+Host-side mirror of the middle of asr::ReconstructSurface (cpp/lib/asr.cpp:143-336) with the
+network methods aggregate / unet / decode of models/v0/net_definitions_torch.py:535-666.  All
+work happens inside libasr_hip.so (asr_hip_implicit_forward); this class only marshals pointers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AsrHipError, Context, ImplicitParams, ImplicitSizes, Weight, ptr
+
+# dtype / trailing shape of the arrays asr_hip_implicit_get can return (input_dict keys of
+# cpp/lib/asr.cpp:159-312)
+_ARRAY_TYPES = {
+    "values": (torch.float32, 2),
+    "feats1": (torch.float32, None),
+    "importance": (torch.float32, 0),
+    "code": (torch.float32, None),
+    "nodes": (torch.int64, 0),
+    "voxel_keys": (torch.int64, 0),
+    "voxel_centers": (torch.float32, 3),
+    "voxel_sizes": (torch.float32, 0),
+    "neighbors_index": (torch.int32, 0),
+    "neighbors_kernel_index": (torch.uint8, 0),
+    "neighbors_row_splits": (torch.int64, 0),
+    "up_neighbors_index": (torch.int32, 0),
+    "up_neighbors_kernel_index": (torch.uint8, 0),
+    "up_neighbors_row_splits": (torch.int64, 0),
+    "down_neighbors_index": (torch.int32, 0),
+    "down_neighbors_kernel_index": (torch.uint8, 0),
+    "down_neighbors_row_splits": (torch.int64, 0),
+    "aggregation_neighbors_index": (torch.int32, 0),
+    "aggregation_neighbors_dist": (torch.float32, 0),
+    "aggregation_row_splits": (torch.int64, 0),
+    "aggregation_scale_compat": (torch.float32, 0),
+}
+
+
+class ImplicitPipeline:
+    """weights: dict state_dict-name -> tensor (names of SURVEY A.6 / UNet5.state_dict())."""
+
+    STAGES = ("octree", "grids", "aggregation_search", "continuous_conv", "unet", "decode")
+
+    def __init__(self, weights, device="cuda:0", point_radius_scale=1.0, octree_max_depth=21,
+                 scale_sdf=True):
+        if not torch.cuda.is_available():
+            raise AsrHipError("no GPU visible: the MI355X path cannot run (no CPU fallback)")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.ctx = Context()
+        self.point_radius_scale = float(point_radius_scale)
+        self.octree_max_depth = int(octree_max_depth)
+        self.scale_sdf = bool(scale_sdf)
+        self._weights = {}
+        self._names = []
+        for name, t in weights.items():
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(np.ascontiguousarray(t))
+            self._weights[name] = t.detach().to(self.device, torch.float32).contiguous()
+        self._table = (Weight * len(self._weights))()
+        for i, (name, t) in enumerate(self._weights.items()):
+            self._names.append(name.encode())
+            self._table[i].name = self._names[-1]
+            self._table[i].data = t.data_ptr()
+            self._table[i].ndim = t.ndim
+            for d in range(t.ndim):
+                self._table[i].shape[d] = t.shape[d]
+        self.sizes = None
+
+    def _params(self, bb_min, bb_max):
+        p = ImplicitParams()
+        p.point_radius_scale = self.point_radius_scale
+        p.octree_max_depth = self.octree_max_depth
+        for d in range(3):
+            p.bb_min[d] = float(bb_min[d])
+            p.bb_max[d] = float(bb_max[d])
+        p.scale_sdf = int(self.scale_sdf)
+        return p
+
+    @staticmethod
+    def _check(points, normals, radii):
+        for t in (points, normals, radii):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and
+                    t.is_contiguous()):
+                raise AsrHipError("inputs must be contiguous float32 GPU tensors")
+        if points.ndim != 2 or points.shape[1] != 3:
+            raise ValueError("points must have shape [num_points,3]")
+        if normals.shape != points.shape:
+            raise ValueError("normals must have shape [num_points,3]")
+        if radii.ndim != 1 or radii.shape[0] != points.shape[0]:
+            raise ValueError("radii must have shape [num_point3]")
+        if points.shape[0] == 0:
+            raise RuntimeError("points is null!\n")
+
+    def forward(self, points, normals, radii, bb_min, bb_max):
+        """Enqueues the whole path on torch's current stream; returns values[V0,2] (a view into
+        the context arena, valid until the next forward)."""
+        self._check(points, normals, radii)
+        self.ctx.set_stream(torch.cuda.current_stream())
+        p = self._params(bb_min, bb_max)
+        sizes = ImplicitSizes()
+        self.ctx.call("asr_hip_implicit_forward", ptr(points), ptr(normals), ptr(radii),
+                      ctypes.c_int64(points.shape[0]), self._table, len(self._weights),
+                      ctypes.byref(p), ctypes.byref(sizes))
+        self.sizes = sizes
+        return self.get("values")
+
+    def build(self, points, radii, bb_min, bb_max):
+        """geometry half only (octree, grids, aggregation neighbours)"""
+        self.ctx.set_stream(torch.cuda.current_stream())
+        p = self._params(bb_min, bb_max)
+        sizes = ImplicitSizes()
+        self.ctx.call("asr_hip_implicit_build", ptr(points), ptr(radii),
+                      ctypes.c_int64(points.shape[0]), ctypes.byref(p), ctypes.byref(sizes))
+        self.sizes = sizes
+        return sizes
+
+    def network(self, points, normals, bb_min, bb_max):
+        """network half on the structures of the last build()"""
+        self.ctx.set_stream(torch.cuda.current_stream())
+        p = self._params(bb_min, bb_max)
+        self.ctx.call("asr_hip_implicit_network", ptr(points), ptr(normals),
+                      ctypes.c_int64(points.shape[0]), self._table, len(self._weights),
+                      ctypes.byref(p), ctypes.c_void_p(0))
+        return self.get("values")
+
+    def get(self, name):
+        """copy of one named array of the last forward (see include/asr_hip.h)"""
+        base = name.rstrip("0123456789")
+        if base not in _ARRAY_TYPES:
+            raise KeyError(name)
+        dtype, cols = _ARRAY_TYPES[base]
+        nbytes = ctypes.c_size_t(0)
+        self.ctx.call("asr_hip_implicit_get", name.encode(), ctypes.c_void_p(0), ctypes.byref(nbytes))
+        item = torch.empty((), dtype=dtype).element_size()
+        out = torch.empty(nbytes.value // item, dtype=dtype, device=self.device)
+        self.ctx.call("asr_hip_implicit_get", name.encode(), ptr(out), ctypes.byref(nbytes))
+        if cols is None:
+            v0 = int(self.sizes.num_voxels[0])
+            out = out.reshape(v0, -1)
+        elif cols:
+            out = out.reshape(-1, cols)
+        return out
+
+    def stage_ms(self):
+        ms = (ctypes.c_float * 6)()
+        self.ctx.call("asr_hip_implicit_stage_ms", ms)
+        return dict(zip(self.STAGES, [float(x) for x in ms]))

@@ -1,0 +1,695 @@
+// asr_api.hip -- the C ABI (include/asr_hip.h) and the whole-path driver that replaces the
+// section of asr::ReconstructSurface between pre-filter and contouring
+// (cpp/lib/asr.cpp:143-336) plus UNet5.aggregate/unet/decode
+// (models/v0/net_definitions_torch.py:535-666).
+#include <cmath>
+#include <cstring>
+
+#include "asr_common.h"
+
+#define CTX_GUARD(ctx)                      \
+    if (!(ctx)) return ASR_HIP_EINVAL;      \
+    (ctx)->err.clear();
+
+extern "C" {
+
+const char* asr_hip_version(void) { return "0.2.0+mi355x.r1"; }
+
+size_t asr_hip_struct_size(const char* name) {
+    if (!name) return 0;
+    if (!strcmp(name, "asr_octree_frame")) return sizeof(asr_octree_frame);
+    if (!strcmp(name, "asr_sparse_conv_args")) return sizeof(asr_sparse_conv_args);
+    if (!strcmp(name, "asr_weight")) return sizeof(asr_weight);
+    if (!strcmp(name, "asr_implicit_params")) return sizeof(asr_implicit_params);
+    if (!strcmp(name, "asr_implicit_sizes")) return sizeof(asr_implicit_sizes);
+    return 0;
+}
+
+int asr_hip_context_create(asr_hip_context** out, void* stream) {
+    if (!out) return ASR_HIP_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ASR_HIP_ENODEV;
+    asr_hip_context* ctx = new asr_hip_context();
+    ctx->stream = (hipStream_t)stream;
+    memset(&ctx->sizes, 0, sizeof(ctx->sizes));
+    *out = ctx;
+    return ASR_HIP_OK;
+}
+void asr_hip_context_destroy(asr_hip_context* ctx) {
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    asr_geom_release(ctx);
+    ctx->persist.release();
+    ctx->scratch.release();
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->ev_ok)
+        for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    delete ctx;
+}
+void asr_hip_context_set_stream(asr_hip_context* ctx, void* stream) {
+    if (ctx) ctx->stream = (hipStream_t)stream;
+}
+const char* asr_hip_last_error(const asr_hip_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+size_t asr_hip_context_reserved_bytes(const asr_hip_context* ctx) {
+    return ctx ? ctx->persist.reserved() + ctx->scratch.reserved() : 0;
+}
+
+// cpp/lib/octree.cpp:20-42 (float / double operation order is part of the contract, A.7)
+int asr_octree_frame_init(asr_octree_frame* f, const float bb_min[3], const float bb_max[3]) {
+    if (!f || !bb_min || !bb_max) return ASR_HIP_EINVAL;
+    float center[3];
+    for (int d = 0; d < 3; ++d) {
+        f->bb_min[d] = bb_min[d];
+        f->bb_max[d] = bb_max[d];
+        center[d] = 0.5f * (bb_max[d] + bb_min[d]);
+    }
+    float edge = bb_max[0] - bb_min[0];
+    edge = std::fmax(edge, bb_max[1] - bb_min[1]);
+    edge = std::fmax(edge, bb_max[2] - bb_min[2]);
+    if (!(edge > 0.f)) return ASR_HIP_EINVAL;
+    f->voxel_size[0] = edge;
+    f->inv_voxel_size[0] = 1 / edge;
+    for (int i = 1; i <= ASR_MAX_LEVEL; ++i) {
+        double tmp = edge * (1.0 / std::pow(2, i));
+        f->voxel_size[i] = (float)tmp;
+        f->inv_voxel_size[i] = (float)(1.0 / tmp);
+    }
+    for (int d = 0; d < 3; ++d) {
+        volatile float new_min = center[d] - 0.5f * edge;
+        volatile float t = new_min * f->inv_voxel_size[ASR_MAX_LEVEL];
+        f->offset[d] = (int)(-std::floor(t));
+    }
+    return ASR_HIP_OK;
+}
+
+int asr_hip_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, const float* points,
+                       const float* radii, int64_t n, float radius_scale, int max_depth,
+                       uint64_t* keys_out) {
+    CTX_GUARD(ctx);
+    if (!frame || n < 0 || (n > 0 && (!points || !radii || !keys_out)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "point_keys: null argument");
+    return asr_geom_point_keys(ctx, frame, points, radii, n, radius_scale, max_depth, keys_out);
+}
+
+int asr_hip_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* points,
+                         const float* radii, int64_t n, float radius_scale, int max_depth,
+                         int64_t* num_nodes, int64_t* num_leaves) {
+    CTX_GUARD(ctx);
+    if (!frame || n < 0 || (n > 0 && (!points || !radii)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree_build: null argument");
+    ctx->persist.reset();
+    ctx->named.clear();
+    ASR_TRY(asr_geom_octree_build(ctx, frame, points, radii, n, radius_scale, max_depth));
+    if (num_nodes) *num_nodes = ctx->num_nodes;
+    if (num_leaves) *num_leaves = ctx->num_leaves;
+    return ASR_HIP_OK;
+}
+int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out, uint64_t* leaves_out) {
+    CTX_GUARD(ctx);
+    if (nodes_out && ctx->num_nodes)
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(nodes_out, ctx->nodes, 8 * ctx->num_nodes,
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+    if (leaves_out && ctx->num_leaves)
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(leaves_out, ctx->leaves, 8 * ctx->num_leaves,
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+    return ASR_HIP_OK;
+}
+
+int asr_hip_grid_neighbors_count(asr_hip_context* ctx, const uint64_t* keys, int64_t v,
+                                 int64_t* row_splits_out, int64_t* num_pairs) {
+    CTX_GUARD(ctx);
+    if (v < 0 || !row_splits_out || !num_pairs || (v > 0 && !keys))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "grid_neighbors_count: null argument");
+    ctx->scratch.reset();
+    return asr_geom_neighbors_count(ctx, keys, v, row_splits_out, num_pairs);
+}
+int asr_hip_grid_neighbors_fill(asr_hip_context* ctx, const uint64_t* keys, int64_t v,
+                                const int64_t* row_splits, int32_t* index_out,
+                                uint8_t* kernel_index_out) {
+    CTX_GUARD(ctx);
+    if (v < 0 || (v > 0 && (!keys || !row_splits || !index_out || !kernel_index_out)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "grid_neighbors_fill: null argument");
+    ctx->scratch.reset();
+    return asr_geom_neighbors_fill(ctx, keys, v, row_splits, index_out, kernel_index_out);
+}
+int asr_hip_grid_coarsen_count(asr_hip_context* ctx, const uint64_t* keys, int64_t v,
+                               int64_t* v_out) {
+    CTX_GUARD(ctx);
+    if (v < 0 || !v_out || (v > 0 && !keys))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "grid_coarsen_count: null argument");
+    return asr_geom_coarsen_count(ctx, keys, v, v_out);
+}
+int asr_hip_grid_coarsen_fill(asr_hip_context* ctx, const uint64_t* keys, int64_t v,
+                              uint64_t* out_keys, int64_t v_out, int32_t* up_index_out,
+                              uint8_t* up_kernel_index_out, int64_t* up_row_splits_out) {
+    CTX_GUARD(ctx);
+    if (v < 0 || (v > 0 && (!keys || !out_keys || !up_index_out || !up_kernel_index_out ||
+                            !up_row_splits_out)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "grid_coarsen_fill: null argument");
+    ctx->scratch.reset();
+    return asr_geom_coarsen_fill(ctx, keys, v, out_keys, v_out, up_index_out, up_kernel_index_out,
+                                 up_row_splits_out);
+}
+int asr_hip_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame, const uint64_t* keys,
+                       int64_t v, float* centers_out, float* sizes_out) {
+    CTX_GUARD(ctx);
+    if (!frame || v < 0 || (v > 0 && !keys)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "voxel_info: null argument");
+    return asr_geom_voxel_info(ctx, frame, keys, v, centers_out, sizes_out);
+}
+int asr_hip_multi_radius_search_count(asr_hip_context* ctx, const asr_octree_frame* frame,
+                                      const float* points, int64_t n, const float* centers,
+                                      const float* sizes, int64_t v, int64_t* row_splits_out,
+                                      int64_t* num_pairs) {
+    CTX_GUARD(ctx);
+    if (!frame || n < 0 || v < 0 || !row_splits_out || !num_pairs || (n > 0 && !points) ||
+        (v > 0 && (!centers || !sizes)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "multi_radius_search_count: null argument");
+    ctx->scratch.reset();
+    return asr_geom_radius_count(ctx, frame, points, n, centers, sizes, v, row_splits_out, num_pairs);
+}
+int asr_hip_multi_radius_search_fill(asr_hip_context* ctx, const float* points, const float* radii,
+                                     int64_t n, const float* centers, const float* sizes,
+                                     int64_t v, const int64_t* row_splits, int32_t* index_out,
+                                     float* dist_out, float* compat_out) {
+    CTX_GUARD(ctx);
+    if (v > 0 && (!row_splits || !index_out || !dist_out || (compat_out && !radii)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "multi_radius_search_fill: null argument");
+    return asr_geom_radius_fill(ctx, points, radii, n, centers, sizes, v, row_splits, index_out,
+                                dist_out, compat_out);
+}
+
+int asr_hip_continuous_conv_f32(asr_hip_context* ctx, const float* filters, const float* out_pos,
+                                const float* extents, const float* inp_pos, const float* inp_feat,
+                                const int32_t* nidx, const float* nimp, const int64_t* rs,
+                                int64_t num_out, int cin, int cout, int normalize,
+                                const float* bias, int relu, float* out) {
+    CTX_GUARD(ctx);
+    if (num_out > 0 && (!filters || !out_pos || !extents || !inp_pos || !inp_feat || !rs || !out))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: null argument");
+    return asr_conv_cconv(ctx, filters, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs, num_out,
+                          cin, cout, normalize, bias, relu, out);
+}
+int asr_hip_aggregation_importance(asr_hip_context* ctx, const float* compat, const float* dist,
+                                   int64_t n, float* out) {
+    CTX_GUARD(ctx);
+    if (n > 0 && (!compat || !dist || !out))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "aggregation_importance: null argument");
+    return asr_conv_agg_importance(ctx, compat, dist, n, out);
+}
+int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* a) {
+    CTX_GUARD(ctx);
+    if (!a) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: null args");
+    if (a->num_out > 0 && (!a->filters || !a->inp_features || !a->neighbors_index ||
+                           !a->neighbors_kernel_index || !a->neighbors_row_splits || !a->out))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: null argument");
+    return asr_conv_sparse(ctx, a);
+}
+int asr_hip_invert_neighbors_list(asr_hip_context* ctx, int64_t num_points, const int32_t* idx,
+                                  const int64_t* rs, int64_t num_rows, const uint8_t* attr,
+                                  int32_t* out_idx, int64_t* out_rs, uint8_t* out_attr) {
+    CTX_GUARD(ctx);
+    if (num_points < 0 || num_rows < 0 || !out_rs || (num_rows > 0 && !rs))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "invert_neighbors_list: null argument");
+    ctx->scratch.reset();
+    return asr_geom_invert(ctx, num_points, idx, rs, num_rows, attr, out_idx, out_rs, out_attr);
+}
+int asr_hip_reduce_subarrays_sum(asr_hip_context* ctx, const float* values, const int32_t* gidx,
+                                 const int64_t* rs, int64_t rows, float* out) {
+    CTX_GUARD(ctx);
+    if (rows > 0 && (!values || !rs || !out))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "reduce_subarrays_sum: null argument");
+    return asr_conv_reduce(ctx, values, gidx, rs, rows, out);
+}
+int asr_hip_decode_mlp(asr_hip_context* ctx, const float* code, int64_t v, int c, const float* w1,
+                       const float* b1, int h1, const float* w2, const float* b2, int h2,
+                       const float* w3, const float* sizes, float* out) {
+    CTX_GUARD(ctx);
+    if (v > 0 && (!code || !w1 || !b1 || !w2 || !b2 || !w3 || !out))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "decode_mlp: null argument");
+    return asr_conv_decode(ctx, code, v, c, w1, b1, h1, w2, b2, h2, w3, sizes, out);
+}
+
+}  // extern "C"
+
+// ==========================================================================================
+// whole path
+// ==========================================================================================
+namespace {
+
+__global__ void k_make_feats(const float* normals, i64 n, float* feats) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // cpp/lib/asr.cpp:168-176: feats = [nx, ny, nz, 1]
+    reinterpret_cast<float4*>(feats)[i] =
+            make_float4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 1.f);
+}
+
+int ensure_events(asr_hip_context* ctx) {
+    if (!ctx->ev_ok) {
+        for (auto& e : ctx->ev) ASR_HIP_CHECK(ctx, hipEventCreate(&e));
+        ctx->ev_ok = true;
+    }
+    return ASR_HIP_OK;
+}
+
+void name_it(asr_hip_context* ctx, const std::string& name, const void* p, size_t bytes) {
+    ctx->named[name] = {p, bytes};
+}
+
+struct WeightTable {
+    const asr_weight* w;
+    int n;
+    const asr_weight* find(const std::string& name) const {
+        for (int i = 0; i < n; ++i)
+            if (w[i].name && name == w[i].name) return &w[i];
+        return nullptr;
+    }
+};
+
+struct Feat {
+    float* p;
+    i64 ld;
+    int c;
+};
+
+struct Net {
+    asr_hip_context* ctx;
+    WeightTable wt;
+
+    int get(const std::string& name, int ndim, const asr_weight** out) {
+        const asr_weight* w = wt.find(name);
+        if (!w || !w->data) ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "missing weight '%s'", name.c_str());
+        if (w->ndim != ndim)
+            ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "weight '%s' has rank %d, expected %d", name.c_str(),
+                     w->ndim, ndim);
+        *out = w;
+        return ASR_HIP_OK;
+    }
+
+    // one SpecialSparseConv (+bias, ReLU): models/common_torch.py:95-148
+    int conv(const std::string& prefix, int K, Feat in, const int32_t* nidx, const uint8_t* nk,
+             const i64* rs, i64 num_out, i64 num_inp, const float* imp, int normalize, float* out,
+             i64 out_ld, int expect_cout, float* out_imp, const float* residual, i64 residual_ld) {
+        const asr_weight *k, *b;
+        ASR_TRY(get(prefix + ".kernel", 3, &k));
+        ASR_TRY(get(prefix + ".bias", 1, &b));
+        if (k->shape[0] != K || k->shape[1] != in.c || (expect_cout > 0 && k->shape[2] != expect_cout) ||
+            b->shape[0] != k->shape[2])
+            ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "weight '%s.kernel' has shape [%lld,%lld,%lld], expected [%d,%d,%d]",
+                     prefix.c_str(), (long long)k->shape[0], (long long)k->shape[1],
+                     (long long)k->shape[2], K, in.c, expect_cout);
+        asr_sparse_conv_args a;
+        memset(&a, 0, sizeof(a));
+        a.filters = k->data;
+        a.inp_features = in.p;
+        a.inp_ld = in.ld;
+        a.inp_importance = imp;
+        a.neighbors_index = nidx;
+        a.neighbors_kernel_index = nk;
+        a.neighbors_row_splits = rs;
+        a.num_out = num_out;
+        a.num_inp = num_inp;
+        a.kernel_size = K;
+        a.cin = in.c;
+        a.cout = (int)k->shape[2];
+        a.normalize = normalize;
+        a.bias = b->data;
+        a.relu = 1;
+        a.residual = residual;
+        a.residual_ld = residual_ld;
+        a.out = out;
+        a.out_ld = out_ld;
+        a.out_importance = out_imp;
+        return asr_conv_sparse(ctx, &a);
+    }
+    int cout_of(const std::string& prefix, int* c) {
+        const asr_weight* k;
+        ASR_TRY(get(prefix + ".kernel", 3, &k));
+        *c = (int)k->shape[2];
+        return ASR_HIP_OK;
+    }
+
+    // SparseConvBlock with conv1a/conv1b (normalized_channels < output_channels) or plain
+    // conv1 (decoder blocks): net_definitions_torch.py:253-302.  `out` receives conv4.
+    int block(const std::string& name, Feat in, const GridDev& g, const float* imp, bool with_imp,
+              Feat out, float** out_imp) {
+        asr_hip_context* c = ctx;
+        int C = out.c;
+        float* t1 = arena_alloc<float>(c->scratch, (size_t)g.v * C);
+        float* t2 = arena_alloc<float>(c->scratch, (size_t)g.v * C);
+        if (!t1 || !t2) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
+        if (with_imp) {
+            int ca, cb;
+            ASR_TRY(cout_of(name + ".conv1a", &ca));
+            ASR_TRY(cout_of(name + ".conv1b", &cb));
+            if (ca + cb != C) ASR_FAIL(c, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != block width", name.c_str());
+            float* oi = arena_alloc<float>(c->scratch, g.v);
+            if (!oi) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_TRY(conv(name + ".conv1a", 55, in, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t1, C,
+                         ca, nullptr, nullptr, 0));
+            ASR_TRY(conv(name + ".conv1b", 55, in, g.nidx, g.nkidx, g.nrs, g.v, g.v, imp, 1, t1 + ca,
+                         C, cb, oi, nullptr, 0));
+            *out_imp = oi;
+        } else {
+            ASR_TRY(conv(name + ".conv1", 55, in, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t1, C,
+                         C, nullptr, nullptr, 0));
+        }
+        Feat f1{t1, C, C}, f2{t2, C, C};
+        ASR_TRY(conv(name + ".conv2", 55, f1, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t2, C, C,
+                     nullptr, nullptr, 0));
+        ASR_TRY(conv(name + ".conv3", 55, f2, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t1, C, C,
+                     nullptr, nullptr, 0));
+        ASR_TRY(conv(name + ".conv4", 55, f1, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, out.p,
+                     out.ld, C, nullptr, nullptr, 0));
+        return ASR_HIP_OK;
+    }
+    // SparseConvTransitionBlock down (conv1a/conv1b): net_definitions_torch.py:357-387
+    int down(const std::string& name, Feat in, const GridDev& fine, const GridDev& coarse,
+             const float* imp, Feat out, float** out_imp) {
+        int ca, cb;
+        ASR_TRY(cout_of(name + ".conv1a", &ca));
+        ASR_TRY(cout_of(name + ".conv1b", &cb));
+        if (ca + cb != out.c) ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != width", name.c_str());
+        float* oi = arena_alloc<float>(ctx->scratch, coarse.v);
+        if (!oi) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(conv(name + ".conv1a", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, coarse.v,
+                     fine.v, nullptr, 0, out.p, out.ld, ca, nullptr, nullptr, 0));
+        ASR_TRY(conv(name + ".conv1b", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, coarse.v,
+                     fine.v, imp, 1, out.p + ca, out.ld, cb, oi, nullptr, 0));
+        *out_imp = oi;
+        return ASR_HIP_OK;
+    }
+    // up transition (conv1): rows = fine voxels, inputs from the coarse grid
+    int up(const std::string& name, Feat in, const GridDev& fine, const GridDev& coarse, Feat out,
+           const float* residual, i64 residual_ld) {
+        return conv(name + ".conv1", 9, in, fine.up_idx, fine.up_kidx, fine.up_rs, fine.v, coarse.v,
+                    nullptr, 0, out.p, out.ld, out.c, nullptr, residual, residual_ld);
+    }
+};
+
+int implicit_build(asr_hip_context* ctx, const float* points, const float* radii, i64 n,
+                   const asr_implicit_params* prm) {
+    ASR_TRY(ensure_events(ctx));
+    ctx->persist.reset();
+    ctx->scratch.reset();
+    ctx->named.clear();
+    ctx->values = ctx->feats1 = ctx->importance = ctx->code = nullptr;
+    memset(&ctx->sizes, 0, sizeof(ctx->sizes));
+    ctx->sizes.num_points = n;
+    if (asr_octree_frame_init(&ctx->frame, prm->bb_min, prm->bb_max) != ASR_HIP_OK)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "degenerate bounding box");
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale,
+                                  prm->octree_max_depth));
+    ctx->sizes.num_nodes = ctx->num_nodes;
+    name_it(ctx, "nodes", ctx->nodes, 8 * ctx->num_nodes);
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->num_leaves == 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "no point inside the bounding box");
+
+    // grids (cpp/lib/grid.cpp:245-314)
+    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+        GridDev& g = ctx->grids[i];
+        g = GridDev();
+        ctx->scratch.reset();
+        if (i == 0) {
+            g.v = ctx->num_leaves;
+            g.keys = ctx->leaves;
+        } else {
+            GridDev& prev = ctx->grids[i - 1];
+            ASR_TRY(asr_geom_coarsen_count(ctx, prev.keys, prev.v, &g.v));
+            g.keys = arena_alloc<u64>(ctx->persist, g.v);
+            prev.up_idx = arena_alloc<int32_t>(ctx->persist, prev.v);
+            prev.up_kidx = arena_alloc<uint8_t>(ctx->persist, prev.v);
+            prev.up_rs = arena_alloc<i64>(ctx->persist, prev.v + 1);
+            if (!g.keys || !prev.up_idx || !prev.up_kidx || !prev.up_rs)
+                ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_TRY(asr_geom_coarsen_fill(ctx, prev.keys, prev.v, g.keys, g.v, prev.up_idx,
+                                          prev.up_kidx, prev.up_rs));
+            // neighbors_down = invert(up lists)  (net_definitions_torch.py:548-559)
+            prev.down_idx = arena_alloc<int32_t>(ctx->persist, prev.v);
+            prev.down_kidx = arena_alloc<uint8_t>(ctx->persist, prev.v);
+            prev.down_rs = arena_alloc<i64>(ctx->persist, g.v + 1);
+            if (!prev.down_idx || !prev.down_kidx || !prev.down_rs)
+                ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_TRY(asr_geom_invert(ctx, g.v, prev.up_idx, prev.up_rs, prev.v, prev.up_kidx,
+                                    prev.down_idx, prev.down_rs, prev.down_kidx));
+            std::string s = std::to_string(i - 1);
+            name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
+            name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
+            name_it(ctx, "up_neighbors_row_splits" + s, prev.up_rs, 8 * (prev.v + 1));
+            name_it(ctx, "down_neighbors_index" + s, prev.down_idx, 4 * prev.v);
+            name_it(ctx, "down_neighbors_kernel_index" + s, prev.down_kidx, prev.v);
+            name_it(ctx, "down_neighbors_row_splits" + s, prev.down_rs, 8 * (g.v + 1));
+        }
+        g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
+        g.sizes = arena_alloc<float>(ctx->persist, g.v);
+        if (!g.centers || !g.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
+        ASR_TRY(asr_geom_neighbors_build(ctx, ctx->persist, g.keys, g.v, &g.nrs, &g.nidx, &g.nkidx,
+                                         &g.p));
+        ctx->sizes.num_voxels[i] = g.v;
+        ctx->sizes.num_pairs[i] = g.p;
+        std::string s = std::to_string(i);
+        name_it(ctx, "voxel_keys" + s, g.keys, 8 * g.v);
+        name_it(ctx, "voxel_centers" + s, g.centers, 12 * g.v);
+        name_it(ctx, "voxel_sizes" + s, g.sizes, 4 * g.v);
+        name_it(ctx, "neighbors_index" + s, g.nidx, 4 * g.p);
+        name_it(ctx, "neighbors_kernel_index" + s, g.nkidx, g.p);
+        name_it(ctx, "neighbors_row_splits" + s, g.nrs, 8 * (g.v + 1));
+    }
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+
+    // aggregation neighbours (cpp/lib/asr.cpp:266-273)
+    {
+        ctx->scratch.reset();
+        GridDev& g0 = ctx->grids[0];
+        ctx->agg_rs = arena_alloc<i64>(ctx->persist, g0.v + 1);
+        if (!ctx->agg_rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        i64 P = 0;
+        ASR_TRY(asr_geom_radius_count(ctx, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v,
+                                      ctx->agg_rs, &P));
+        ctx->agg_idx = arena_alloc<int32_t>(ctx->persist, P);
+        ctx->agg_dist = arena_alloc<float>(ctx->persist, P);
+        ctx->agg_compat = arena_alloc<float>(ctx->persist, P);
+        if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat)
+            ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_radius_fill(ctx, points, radii, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
+                                     ctx->agg_idx, ctx->agg_dist, ctx->agg_compat));
+        ctx->sizes.num_agg_pairs = P;
+        name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * P);
+        name_it(ctx, "aggregation_neighbors_dist", ctx->agg_dist, 4 * P);
+        name_it(ctx, "aggregation_scale_compat", ctx->agg_compat, 4 * P);
+        name_it(ctx, "aggregation_row_splits", ctx->agg_rs, 8 * (g0.v + 1));
+    }
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    return ASR_HIP_OK;
+}
+
+int implicit_network(asr_hip_context* ctx, const float* points, const float* normals, i64 n,
+                     const asr_weight* weights, int num_weights, const asr_implicit_params* prm,
+                     float* values_out) {
+    ASR_TRY(ensure_events(ctx));
+    if (n != ctx->sizes.num_points || ctx->sizes.num_voxels[0] == 0)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: no matching implicit_build");
+    ctx->scratch.reset();
+    Net net{ctx, {weights, num_weights}};
+    GridDev* g = ctx->grids;
+    const i64 V0 = g[0].v;
+    const i64 P = ctx->sizes.num_agg_pairs;
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+
+    // ---- aggregate (net_definitions_torch.py:640-653, 72-120) ----
+    const asr_weight *ck, *cb;
+    ASR_TRY(net.get("cconv_block_in.conv1.kernel", 5, &ck));
+    ASR_TRY(net.get("cconv_block_in.conv1.bias", 1, &cb));
+    if (ck->shape[0] != 4 || ck->shape[1] != 4 || ck->shape[2] != 4 || ck->shape[3] != 4)
+        ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "cconv_block_in.conv1.kernel must be [4,4,4,4,C]");
+    const int C0 = (int)ck->shape[4];
+    float* feats = arena_alloc<float>(ctx->scratch, 4 * (size_t)n);
+    float* imp_pairs = arena_alloc<float>(ctx->persist, P > V0 ? P : V0);
+    float* feats1 = arena_alloc<float>(ctx->persist, (size_t)V0 * C0);
+    if (!feats || !imp_pairs || !feats1) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_make_feats<<<grid_for(n, 256), 256, 0, ctx->stream>>>(normals, n, feats);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(asr_conv_agg_importance(ctx, ctx->agg_compat, ctx->agg_dist, P, imp_pairs));
+    ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, points, feats, ctx->agg_idx,
+                           imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1));
+    ctx->feats1 = feats1;
+    ctx->importance = imp_pairs;
+    name_it(ctx, "feats1", feats1, 4 * (size_t)V0 * C0);
+    name_it(ctx, "importance", imp_pairs, 4 * (size_t)P);
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+
+    // the per-PAIR importance array is indexed with grid-0 VOXEL indices
+    // (net_definitions_torch.py:572-578 -> common_torch.py:125).  torch would raise on P < V0.
+    if (P < V0)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL,
+                 "aggregation pairs (%lld) < voxels (%lld): reference indexing is out of range",
+                 (long long)P, (long long)V0);
+
+    // ---- unet (net_definitions_torch.py:535-638) ----
+    int c_enc[5], c_down[5], c_up[4], c_dec[4];
+    {
+        int a, b;
+        for (int i = 0; i < 5; ++i) {
+            std::string nm = "sparseconv_encblock" + std::to_string(i);
+            ASR_TRY(net.cout_of(nm + ".conv1a", &a));
+            ASR_TRY(net.cout_of(nm + ".conv1b", &b));
+            c_enc[i] = a + b;
+        }
+        for (int i = 1; i <= 3; ++i) {
+            std::string nm = "sparseconv_down" + std::to_string(i);
+            ASR_TRY(net.cout_of(nm + ".conv1a", &a));
+            ASR_TRY(net.cout_of(nm + ".conv1b", &b));
+            c_down[i] = a + b;
+        }
+        c_down[4] = c_down[3];  // sparseconv_down3 is reused for 3->4 (B.3)
+        for (int i = 0; i < 4; ++i) {
+            ASR_TRY(net.cout_of("sparseconv_up" + std::to_string(i) + ".conv1", &c_up[i]));
+            ASR_TRY(net.cout_of("sparseconv_decblock" + std::to_string(i) + ".conv4", &c_dec[i]));
+        }
+    }
+    Arena& S = ctx->scratch;
+    auto buf = [&](i64 rows, int c) { return arena_alloc<float>(S, (size_t)rows * c); };
+    // concat buffers [up_i | enc_i] for levels 1..3; level 0 uses a residual add
+    float* cat[4] = {nullptr, nullptr, nullptr, nullptr};
+    int cat_ld[4] = {0, 0, 0, 0};
+    for (int i = 1; i <= 3; ++i) {
+        cat_ld[i] = c_up[i] + c_enc[i];
+        cat[i] = buf(g[i].v, cat_ld[i]);
+        if (!cat[i]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    }
+    float* f2 = buf(V0, c_enc[0]);
+    float* f10 = buf(g[4].v, c_enc[4]);
+    if (!f2 || !f10) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+
+    Feat enc_out[5];
+    enc_out[0] = Feat{f2, c_enc[0], c_enc[0]};
+    for (int i = 1; i <= 3; ++i) enc_out[i] = Feat{cat[i] + c_up[i], cat_ld[i], c_enc[i]};
+    enc_out[4] = Feat{f10, c_enc[4], c_enc[4]};
+
+    float* imp = nullptr;
+    ASR_TRY(net.block("sparseconv_encblock0", Feat{feats1, C0, C0}, g[0], imp_pairs, true, enc_out[0],
+                      &imp));
+    for (int i = 1; i <= 4; ++i) {
+        std::string dn = "sparseconv_down" + std::to_string(i < 4 ? i : 3);
+        float* t = buf(g[i].v, c_down[i]);
+        if (!t) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        float* imp_d = nullptr;
+        ASR_TRY(net.down(dn, enc_out[i - 1], g[i - 1], g[i], imp, Feat{t, c_down[i], c_down[i]}, &imp_d));
+        float* imp_e = nullptr;
+        ASR_TRY(net.block("sparseconv_encblock" + std::to_string(i), Feat{t, c_down[i], c_down[i]},
+                          g[i], imp_d, true, enc_out[i], &imp_e));
+        imp = imp_e;
+    }
+    // decoder
+    Feat cur = enc_out[4];
+    for (int i = 3; i >= 1; --i) {
+        ASR_TRY(net.up("sparseconv_up" + std::to_string(i), cur, g[i], g[i + 1],
+                       Feat{cat[i], cat_ld[i], c_up[i]}, nullptr, 0));
+        float* d = buf(g[i].v, c_dec[i]);
+        if (!d) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        float* dummy = nullptr;
+        ASR_TRY(net.block("sparseconv_decblock" + std::to_string(i), Feat{cat[i], cat_ld[i], cat_ld[i]},
+                          g[i], nullptr, false, Feat{d, c_dec[i], c_dec[i]}, &dummy));
+        cur = Feat{d, c_dec[i], c_dec[i]};
+    }
+    if (c_up[0] != c_enc[0])
+        ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "residual skip needs up0 width == encblock0 width");
+    float* f21 = buf(V0, c_up[0]);
+    float* code = arena_alloc<float>(ctx->persist, (size_t)V0 * c_dec[0]);
+    if (!f21 || !code) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    // feats21 = relu(up0(feats19)) + feats2   (net_definitions_torch.py:631-633)
+    ASR_TRY(net.up("sparseconv_up0", cur, g[0], g[1], Feat{f21, c_up[0], c_up[0]}, f2, c_enc[0]));
+    {
+        float* dummy = nullptr;
+        ASR_TRY(net.block("sparseconv_decblock0", Feat{f21, c_up[0], c_up[0]}, g[0], nullptr, false,
+                          Feat{code, c_dec[0], c_dec[0]}, &dummy));
+    }
+    ctx->code = code;
+    name_it(ctx, "code", code, 4 * (size_t)V0 * c_dec[0]);
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+
+    // ---- decode + sdf scale (net_definitions_torch.py:655-666, asr.cpp:324-336) ----
+    const asr_weight *w1, *b1, *w2, *b2, *w3;
+    ASR_TRY(net.get("dense_decoder1.weight", 2, &w1));
+    ASR_TRY(net.get("dense_decoder1.bias", 1, &b1));
+    ASR_TRY(net.get("dense_decoder2.weight", 2, &w2));
+    ASR_TRY(net.get("dense_decoder2.bias", 1, &b2));
+    ASR_TRY(net.get("dense_decoder3.weight", 2, &w3));
+    if (w1->shape[1] != 3 + c_dec[0] || w2->shape[1] != w1->shape[0] || w3->shape[1] != w2->shape[0] ||
+        w3->shape[0] != 2)
+        ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "dense_decoder shapes do not chain");
+    float* values = values_out;
+    if (!values) {
+        values = arena_alloc<float>(ctx->persist, 2 * (size_t)V0);
+        if (!values) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    }
+    ASR_TRY(asr_conv_decode(ctx, code, V0, c_dec[0], w1->data, b1->data, (int)w1->shape[0], w2->data,
+                            b2->data, (int)w2->shape[0], w3->data,
+                            prm->scale_sdf ? g[0].sizes : nullptr, values));
+    ctx->values = values;
+    name_it(ctx, "values", values, 8 * (size_t)V0);
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    return ASR_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int asr_hip_implicit_build(asr_hip_context* ctx, const float* points, const float* radii, int64_t n,
+                           const asr_implicit_params* prm, asr_implicit_sizes* sizes) {
+    CTX_GUARD(ctx);
+    if (!points || !radii || n <= 0 || !prm)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_build: points is null!");  // cpp/lib/asr.cpp:101-103
+    ASR_TRY(implicit_build(ctx, points, radii, n, prm));
+    if (sizes) *sizes = ctx->sizes;
+    return ASR_HIP_OK;
+}
+int asr_hip_implicit_network(asr_hip_context* ctx, const float* points, const float* normals,
+                             int64_t n, const asr_weight* weights, int num_weights,
+                             const asr_implicit_params* prm, float* values_out) {
+    CTX_GUARD(ctx);
+    if (!points || !normals || n <= 0 || !weights || !prm)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: null argument");
+    return implicit_network(ctx, points, normals, n, weights, num_weights, prm, values_out);
+}
+int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points, const float* normals,
+                             const float* radii, int64_t n, const asr_weight* weights,
+                             int num_weights, const asr_implicit_params* prm,
+                             asr_implicit_sizes* sizes) {
+    CTX_GUARD(ctx);
+    if (!points || !normals || !radii || n <= 0 || !weights || !prm)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward: points is null!");
+    ASR_TRY(implicit_build(ctx, points, radii, n, prm));
+    ASR_TRY(implicit_network(ctx, points, normals, n, weights, num_weights, prm, nullptr));
+    if (sizes) *sizes = ctx->sizes;
+    return ASR_HIP_OK;
+}
+int asr_hip_implicit_get(asr_hip_context* ctx, const char* name, void* dst, size_t* nbytes) {
+    CTX_GUARD(ctx);
+    if (!name) ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_get: null name");
+    auto it = ctx->named.find(name);
+    if (it == ctx->named.end()) ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_get: unknown array '%s'", name);
+    if (nbytes) *nbytes = it->second.second;
+    if (dst && it->second.second)
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(dst, it->second.first, it->second.second,
+                                          hipMemcpyDeviceToDevice, ctx->stream));
+    return ASR_HIP_OK;
+}
+int asr_hip_implicit_stage_ms(asr_hip_context* ctx, float out_ms[6]) {
+    CTX_GUARD(ctx);
+    if (!ctx->ev_ok || !out_ms) ASR_FAIL(ctx, ASR_HIP_EINVAL, "stage_ms: nothing recorded");
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const int pairs[6][2] = {{0, 1}, {1, 2}, {2, 3}, {4, 5}, {5, 6}, {6, 7}};
+    for (int i = 0; i < 6; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[pairs[i][0]], ctx->ev[pairs[i][1]]) != hipSuccess) ms = -1.f;
+        out_ms[i] = ms;
+    }
+    return ASR_HIP_OK;
+}
+
+}  // extern "C"

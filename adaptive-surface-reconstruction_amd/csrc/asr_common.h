@@ -1,0 +1,229 @@
+// asr_common.h -- context, device arena and shared device helpers (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/asr_hip.h"
+
+typedef uint64_t u64;
+typedef int64_t i64;
+
+// ---------------------------------------------------------------------------------------
+// Device arena: a list of hipMalloc'd slabs with bump allocation.  reset() rewinds the bump
+// pointers but keeps the slabs, so steady-state forwards do not call hipMalloc.
+// ---------------------------------------------------------------------------------------
+struct Arena {
+    struct Slab {
+        char* base;
+        size_t size, used;
+    };
+    std::vector<Slab> slabs;
+    size_t min_slab = size_t(256) << 20;
+
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (bytes == 0) bytes = 256;
+        for (auto& s : slabs)
+            if (s.size - s.used >= bytes) {
+                void* p = s.base + s.used;
+                s.used += bytes;
+                return p;
+            }
+        size_t sz = bytes > min_slab ? bytes : min_slab;
+        void* p = nullptr;
+        if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
+        slabs.push_back({(char*)p, sz, bytes});
+        return p;
+    }
+    void reset() {
+        for (auto& s : slabs) s.used = 0;
+    }
+    size_t reserved() const {
+        size_t t = 0;
+        for (auto& s : slabs) t += s.size;
+        return t;
+    }
+    void release() {
+        for (auto& s : slabs) (void)hipFree(s.base);
+        slabs.clear();
+    }
+};
+
+// mark/rewind for temporaries inside one API call
+struct ArenaMark {
+    std::vector<size_t> used;
+};
+
+struct GridDev {
+    i64 v = 0, p = 0;
+    u64* keys = nullptr;
+    float* centers = nullptr;
+    float* sizes = nullptr;
+    int32_t* nidx = nullptr;
+    uint8_t* nkidx = nullptr;
+    i64* nrs = nullptr;
+    int32_t* up_idx = nullptr;
+    uint8_t* up_kidx = nullptr;
+    i64* up_rs = nullptr;
+    // inverted up lists (rows = next coarser grid)
+    int32_t* down_idx = nullptr;
+    uint8_t* down_kidx = nullptr;
+    i64* down_rs = nullptr;
+};
+
+struct asr_hip_context {
+    hipStream_t stream = nullptr;
+    std::string err;
+    Arena persist;  // results that outlive a call (octree, grids, values)
+    Arena scratch;  // temporaries
+    // last octree
+    u64* nodes = nullptr;
+    u64* leaves = nullptr;
+    i64 num_nodes = 0, num_leaves = 0;
+    // last implicit build
+    asr_octree_frame frame;
+    asr_implicit_sizes sizes;
+    GridDev grids[ASR_NUM_GRIDS];
+    int32_t* agg_idx = nullptr;
+    float* agg_dist = nullptr;
+    float* agg_compat = nullptr;
+    i64* agg_rs = nullptr;
+    float* values = nullptr;
+    float* feats1 = nullptr;
+    float* importance = nullptr;
+    float* code = nullptr;
+    float stage_ms[6] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[8] = {};
+    bool ev_ok = false;
+    int* d_flags = nullptr;  // small device scratch for counters (persistent)
+    void* radius_state = nullptr;  // RadiusState of asr_geom.hip (between _count and _fill)
+    std::map<std::string, std::pair<const void*, size_t>> named;  // asr_hip_implicit_get
+};
+
+#define ASR_FAIL(ctx, code, ...)                         \
+    do {                                                 \
+        char _b[512];                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);           \
+        (ctx)->err = _b;                                 \
+        return (code);                                   \
+    } while (0)
+
+#define ASR_HIP_CHECK(ctx, expr)                                                            \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            ASR_FAIL(ctx, ASR_HIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                     __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define ASR_CHECK_LAUNCH(ctx) ASR_HIP_CHECK(ctx, hipGetLastError())
+
+#define ASR_TRY(expr)               \
+    do {                            \
+        int _r = (expr);            \
+        if (_r != ASR_HIP_OK) return _r; \
+    } while (0)
+
+template <class T>
+static inline T* arena_alloc(Arena& a, size_t count) {
+    return (T*)a.alloc(count * sizeof(T));
+}
+
+static inline unsigned grid_for(i64 n, int block) {
+    i64 g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------------------
+// device helpers: Morton / location codes (cpp/lib/zindex.h, octreebase.h)
+// ---------------------------------------------------------------------------------------
+__host__ __device__ static inline u64 asr_dilate21(u64 x) {
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x00FF0000FF0000FFull;
+    x = (x | (x << 8)) & 0xF00F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x30C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x9249249249249249ull;
+    return x;
+}
+__host__ __device__ static inline u64 asr_compact21(u64 x) {
+    x &= 0x1249249249249249ull;
+    x = ((x >> 2) | x) & 0x30C30C30C30C30C3ull;
+    x = ((x >> 4) | x) & 0xF00F00F00F00F00Full;
+    x = ((x >> 8) | x) & 0x00FF0000FF0000FFull;
+    x = ((x >> 16) | x) & 0x001F00000000FFFFull;
+    x = ((x >> 32) | x) & 0x00000000001FFFFFull;
+    return x;
+}
+__host__ __device__ static inline u64 asr_morton3d(u64 x, u64 y, u64 z) {
+    return asr_dilate21(x) | (asr_dilate21(y) << 1) | (asr_dilate21(z) << 2);
+}
+__device__ static inline int asr_key_level(u64 key) { return (63 - __clzll((long long)key)) / 3; }
+// key of (x,y,z,lev) or 0 if outside the level's cube (octreebase.h:59-65,120-128)
+__device__ static inline u64 asr_coord_key(int x, int y, int z, int lev) {
+    int lim = 1 << lev;
+    if (lev > ASR_MAX_LEVEL || x < 0 || x >= lim || y < 0 || y >= lim || z < 0 || z >= lim)
+        return 0;
+    return asr_morton3d((u64)x, (u64)y, (u64)z) | (u64(1) << (3 * lev));
+}
+__device__ static inline void asr_key_coord(u64 key, int& x, int& y, int& z, int& lev) {
+    lev = asr_key_level(key);
+    u64 k = key & ~(u64(1) << (3 * lev));
+    x = (int)asr_compact21(k);
+    y = (int)asr_compact21(k >> 1);
+    z = (int)asr_compact21(k >> 2);
+}
+
+// 64-bit finaliser (murmur3 fmix64) used by all device hash tables
+__device__ static inline u64 asr_hash64(u64 k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// internal entry points shared between translation units
+int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                        const float* radii, i64 n, float radius_scale, int max_depth, u64* keys);
+int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                          const float* radii, i64 n, float radius_scale, int max_depth);
+int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* rs, i64* num_pairs);
+int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const i64* rs,
+                            int32_t* idx, uint8_t* kidx);
+int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* keys, i64 v,
+                             i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs);
+int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_out);
+int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out_keys, i64 v_out,
+                          int32_t* up_idx, uint8_t* up_kidx, i64* up_rs);
+int asr_geom_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame, const u64* keys,
+                        i64 v, float* centers, float* sizes);
+int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                          i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
+                          i64* num_pairs);
+int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* radii, i64 n,
+                         const float* centers, const float* sizes, i64 v, const i64* rs,
+                         int32_t* idx, float* dist, float* compat);
+int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, const i64* rs,
+                    i64 num_rows, const uint8_t* attr, int32_t* out_idx, i64* out_rs,
+                    uint8_t* out_attr);
+void asr_geom_release(asr_hip_context* ctx);
+
+int asr_conv_agg_importance(asr_hip_context* ctx, const float* compat, const float* dist, i64 n,
+                            float* out);
+int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_pos,
+                   const float* extents, const float* inp_pos, const float* inp_feat,
+                   const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
+                   int cout, int normalize, const float* bias, int relu, float* out);
+int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* args);
+int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gidx, const i64* rs,
+                    i64 rows, float* out);
+int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const float* w1,
+                    const float* b1, int h1, const float* w2, const float* b2, int h2,
+                    const float* w3, const float* sizes, float* out);

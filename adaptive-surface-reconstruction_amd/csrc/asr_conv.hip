@@ -1,0 +1,445 @@
+// asr_conv.hip -- floating point half of the hot path on gfx950 (fp32 throughout):
+//   a10 continuous conv (wave per output voxel, lane = one of the 4x4x4 filter cells),
+//   a12 sparse conv (gather -> f32 MFMA 16x16x4, slot-skipping row tiles; scalar reference
+//       kernel for odd shapes and cross-checking),
+//   importance sums, a14 decoder MLP.
+#include "asr_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// neighbour importance of the aggregation block: compat * clamp((1-d)^3, 0, 1)
+// (models/common_torch.py:21-22, net_definitions_torch.py:107)
+// ------------------------------------------------------------------------------------------
+__global__ void k_agg_importance(const float* compat, const float* dist, i64 n, float* out) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float t = 1.f - dist[i];
+    float w = t * t * t;
+    w = fminf(fmaxf(w, 0.f), 1.f);
+    out[i] = compat[i] * w;
+}
+
+// ------------------------------------------------------------------------------------------
+// a10: continuous conv, kernel 4x4x4 (64 cells == one wavefront).
+// One wave per output voxel.  Lane l owns filter cell l = (z*4+y)*4+x and accumulates
+// B[cell][0..3] (four input channels per pass) over the voxel's neighbours with its own
+// trilinear weight; the 256-deep contraction with W[cell][cin][cout] is a per-lane partial
+// dot product followed by a wave reduce-scatter.  HBM traffic: neighbour index / importance /
+// point rows (gather) + one output row; the 32 KB filter stays in L1/L2.
+// ------------------------------------------------------------------------------------------
+__device__ inline float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int COUT_MAX>
+__global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters,
+                                               const float* __restrict__ out_pos,
+                                               const float* __restrict__ extents,
+                                               const float* __restrict__ inp_pos,
+                                               const float* __restrict__ inp_feat,
+                                               const int32_t* __restrict__ nidx,
+                                               const float* __restrict__ nimp,
+                                               const i64* __restrict__ rs, i64 num_out, int cin,
+                                               int cout, int normalize,
+                                               const float* __restrict__ bias, int relu,
+                                               float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const i64 q = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
+    if (q >= num_out) return;
+    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const i64 b = rs[q], e = rs[q + 1];
+    const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
+    const float inv_e = 1.f / extents[q];
+    const float sc2 = 2.f * inv_e;
+
+    float acc[COUT_MAX];
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+    float norm = 0.f;
+
+    for (int c0 = 0; c0 < cin; c0 += 4) {
+        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f;
+        for (i64 p = b; p < e; ++p) {
+            const int32_t i = nidx[p];
+            const float w = nimp ? nimp[p] : 1.f;
+            if (c0 == 0) norm += w;
+            float dx = (inp_pos[3 * (i64)i] - ox) * sc2;
+            float dy = (inp_pos[3 * (i64)i + 1] - oy) * sc2;
+            float dz = (inp_pos[3 * (i64)i + 2] - oz) * sc2;
+            float r = sqrtf(dx * dx + dy * dy + dz * dz);
+            float m = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
+            if (m < 1e-8f) {
+                dx = dy = dz = 0.f;
+            } else {
+                float s = 0.5f * r / m;
+                dx *= s;
+                dy *= s;
+                dz *= s;
+            }
+            float ux = fminf(fmaxf((dx + 0.5f) * 3.f, 0.f), 3.f);
+            float uy = fminf(fmaxf((dy + 0.5f) * 3.f, 0.f), 3.f);
+            float uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
+            float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+            int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+            int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
+            float ax = ux - fx, ay = uy - fy, az = uz - fz;
+            // this lane's trilinear weight (sums both corners when x0 == x1 at the border)
+            float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
+            float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
+            float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
+            // same association as the oracle: ((wx*wy)*wz) * (w*f)
+            float wt = wx * wy * wz;
+            if (wt != 0.f) {
+                const float* f = inp_feat + (i64)i * cin + c0;
+                B0 += wt * (w * f[0]);
+                if (c0 + 1 < cin) B1 += wt * (w * f[1]);
+                if (c0 + 2 < cin) B2 += wt * (w * f[2]);
+                if (c0 + 3 < cin) B3 += wt * (w * f[3]);
+            }
+        }
+        // partial contraction: acc[o] += sum_c W[lane][c0+c][o] * B_c
+        const float* wrow = filters + ((i64)lane * cin + c0) * cout;
+#pragma unroll
+        for (int o = 0; o < COUT_MAX; ++o) {
+            if (o < cout) {
+                float s = wrow[o] * B0;
+                if (c0 + 1 < cin) s += wrow[cout + o] * B1;
+                if (c0 + 2 < cin) s += wrow[2 * cout + o] * B2;
+                if (c0 + 3 < cin) s += wrow[3 * cout + o] * B3;
+                acc[o] += s;
+            }
+        }
+    }
+    const float inv_norm = (normalize && norm != 0.f) ? 1.f / norm : 0.f;
+    float mine = 0.f;
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+        if (o < cout) {
+            float s = wave_reduce_sum(acc[o]);
+            if (lane == o) mine = s;
+        }
+    }
+    if (lane < cout) {
+        float r = mine;
+        if (normalize && norm != 0.f) r = r / norm;
+        (void)inv_norm;
+        if (bias) r += bias[lane];
+        if (relu) r = fmaxf(r, 0.f);
+        out[q * cout + lane] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a12 scalar reference kernel: one thread per (row, out channel).  Any cin / cout / strides.
+// Used for shapes the MFMA kernel does not take and as an in-library cross-check (algo=1).
+// ------------------------------------------------------------------------------------------
+__global__ void k_sconv_scalar(asr_sparse_conv_args a) {
+    i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    i64 q = t / a.cout;
+    int oc = (int)(t % a.cout);
+    if (q >= a.num_out) return;
+    float acc = 0.f, norm = 0.f;
+    for (i64 p = a.neighbors_row_splits[q]; p < a.neighbors_row_splits[q + 1]; ++p) {
+        int32_t i = a.neighbors_index[p];
+        float w = a.neighbors_importance ? a.neighbors_importance[p]
+                                         : (a.inp_importance ? a.inp_importance[i] : 1.f);
+        norm += w;
+        const float* f = a.inp_features + (i64)i * a.inp_ld;
+        const float* W = a.filters + ((i64)a.neighbors_kernel_index[p] * a.cin) * a.cout + oc;
+        for (int ic = 0; ic < a.cin; ++ic) acc += W[(i64)ic * a.cout] * (w * f[ic]);
+    }
+    if (a.normalize && norm != 0.f) acc /= norm;
+    if (a.bias) acc += a.bias[oc];
+    if (a.relu) acc = fmaxf(acc, 0.f);
+    if (a.residual) acc += a.residual[q * a.residual_ld + oc];
+    a.out[q * a.out_ld + oc] = acc;
+    if (a.out_importance && oc == 0) a.out_importance[q] = norm;
+}
+
+// ------------------------------------------------------------------------------------------
+// a12 MFMA kernel.
+// Block = 256 threads = 4 waves; tile = 64 output rows (16 per wave) x (NT*16) output columns
+// (blockIdx.y selects the column chunk).  A dense slot table nbr[64][55] is built in LDS from
+// the CSR rows; every wave then loops over the kernel slots that occur in ITS 16 rows only
+// (wave-uniform skip of absent slots: ~8 of 55 slots are occupied per voxel).
+// For a slot k and a 16-wide cin chunk, lane (r = l&15, g = l>>4) gathers the float4
+// f[idx(r,k)][16j+4g .. +3]; MFMA step t (0..3) contracts cin index 16j+4g+t, i.e. the four
+// k-lanes of v_mfma_f32_16x16x4_f32 are mapped to a permuted cin order so the gather is 16 B
+// per lane.  B operand lanes read W[k][16j+4g+t][n0 + (l&15)] (64 B runs) from L1/L2.
+// Epilogue: normalise, bias, ReLU, residual, strided store (zero-copy concat).
+// ------------------------------------------------------------------------------------------
+constexpr int TM = 64;      // rows per block
+constexpr int NBR_LD = 57;  // odd stride: conflict-free column reads
+
+template <int NT, bool IMP>
+__global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a) {
+    __shared__ int s_nbr[TM * NBR_LD];
+    __shared__ float s_w[IMP ? TM * NBR_LD : 1];
+    __shared__ float s_norm[TM];
+    __shared__ unsigned long long s_mask[TM];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const i64 row0 = (i64)blockIdx.x * TM;
+    const int n0 = blockIdx.y * (NT * 16);
+    const int K = a.kernel_size;
+
+    for (int i = tid; i < TM * NBR_LD; i += 256) s_nbr[i] = -1;
+    __syncthreads();
+    if (tid < TM) {
+        i64 q = row0 + tid;
+        unsigned long long m = 0;
+        float norm = 0.f;
+        if (q < a.num_out) {
+            for (i64 p = a.neighbors_row_splits[q]; p < a.neighbors_row_splits[q + 1]; ++p) {
+                int k = a.neighbors_kernel_index[p];
+                int32_t i = a.neighbors_index[p];
+                if (k >= K) continue;  // malformed input: slot outside the filter
+                s_nbr[tid * NBR_LD + k] = i;
+                m |= 1ull << k;
+                float w = 1.f;
+                if (IMP) {
+                    w = a.neighbors_importance ? a.neighbors_importance[p] : a.inp_importance[i];
+                    s_w[tid * NBR_LD + k] = w;
+                }
+                norm += w;
+            }
+        }
+        s_mask[tid] = m;
+        s_norm[tid] = norm;
+    }
+    __syncthreads();
+
+    const int r = lane & 15, g = lane >> 4;
+    const int lrow = wave * 16 + r;
+    unsigned long long wmask = s_mask[wave * 16 + (lane & 15)];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) wmask |= __shfl_xor(wmask, o, 64);
+    wmask = __builtin_amdgcn_readfirstlane((unsigned)(wmask)) |
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(wmask >> 32)) << 32);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+
+    const int cin = a.cin, cout = a.cout;
+    const int ncol = lane & 15;
+    while (wmask) {
+        const int k = __builtin_ctzll(wmask);
+        wmask &= wmask - 1;
+        if (k >= K) break;
+        const int idx = s_nbr[lrow * NBR_LD + k];
+        const bool valid = idx >= 0;
+        const float* frow = a.inp_features + (i64)(valid ? idx : 0) * a.inp_ld;
+        const float imp = (IMP && valid) ? s_w[lrow * NBR_LD + k] : 1.f;
+        const float* Wk = a.filters + (i64)k * cin * cout;
+        for (int c0 = 0; c0 < cin; c0 += 16) {
+            const int c = c0 + 4 * g;
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid && c < cin) av = *reinterpret_cast<const float4*>(frow + c);
+            if (IMP) {
+                av.x *= imp;
+                av.y *= imp;
+                av.z *= imp;
+                av.w *= imp;
+            }
+            const float avs[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ci = c + t;
+                const float* wrow = Wk + (i64)ci * cout + n0 + ncol;
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb) {
+                    float bv = 0.f;
+                    if (ci < cin && n0 + nb * 16 + ncol < cout) bv = wrow[nb * 16];
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[t], bv, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: acc[nb][i] is C[row = 4*g + i][col = ncol] of the wave's 16 x 16 block
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lr = wave * 16 + 4 * g + i;
+        const i64 q = row0 + lr;
+        if (q >= a.num_out) continue;
+        const float norm = s_norm[lr];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
+            if (col >= cout) continue;
+            float v = acc[nb][i];
+            if (a.normalize && norm != 0.f) v /= norm;
+            if (a.bias) v += a.bias[col];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.residual) v += a.residual[q * a.residual_ld + col];
+            a.out[q * a.out_ld + col] = v;
+        }
+    }
+    if (a.out_importance && blockIdx.y == 0 && tid < TM && row0 + tid < a.num_out)
+        a.out_importance[row0 + tid] = s_norm[tid];
+}
+
+// ------------------------------------------------------------------------------------------
+// reduce_subarrays_sum (with optional gather)
+// ------------------------------------------------------------------------------------------
+__global__ void k_reduce_rows(const float* values, const int32_t* gidx, const i64* rs, i64 rows,
+                              float* out) {
+    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (q >= rows) return;
+    float s = 0.f;
+    for (i64 p = rs[q]; p < rs[q + 1]; ++p) s += gidx ? values[gidx[p]] : values[p];
+    out[q] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// a14 decoder MLP (3+c -> h1 -> h2 -> 2, zero shifts) + sdf scale; thread per voxel,
+// weights staged in LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int DEC_MAX = 64;
+__global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, i64 v, int c,
+                                                const float* __restrict__ w1,
+                                                const float* __restrict__ b1, int h1,
+                                                const float* __restrict__ w2,
+                                                const float* __restrict__ b2, int h2,
+                                                const float* __restrict__ w3,
+                                                const float* __restrict__ sizes,
+                                                float* __restrict__ out) {
+    extern __shared__ float s_w[];
+    float* sw1 = s_w;                 // [h1][c]   (shift columns dropped: shifts are zero)
+    float* sb1 = sw1 + h1 * c;        // [h1]
+    float* sw2 = sb1 + h1;            // [h2][h1]
+    float* sb2 = sw2 + h2 * h1;       // [h2]
+    float* sw3 = sb2 + h2;            // [2][h2]
+    for (int i = threadIdx.x; i < h1 * c; i += blockDim.x) sw1[i] = w1[(i / c) * (3 + c) + 3 + i % c];
+    for (int i = threadIdx.x; i < h1; i += blockDim.x) sb1[i] = b1[i];
+    for (int i = threadIdx.x; i < h2 * h1; i += blockDim.x) sw2[i] = w2[i];
+    for (int i = threadIdx.x; i < h2; i += blockDim.x) sb2[i] = b2[i];
+    for (int i = threadIdx.x; i < 2 * h2; i += blockDim.x) sw3[i] = w3[i];
+    __syncthreads();
+    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (q >= v) return;
+    float x[DEC_MAX], f1[DEC_MAX];
+    for (int k = 0; k < c; ++k) x[k] = code[q * c + k];
+    for (int j = 0; j < h1; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < c; ++k) s += x[k] * sw1[j * c + k];
+        s += sb1[j];
+        f1[j] = fmaxf(s, 0.f);
+    }
+    float o0 = 0.f, o1 = 0.f;
+    for (int j = 0; j < h2; ++j) {
+        float s = 0.f;
+        for (int k = 0; k < h1; ++k) s += f1[k] * sw2[j * h1 + k];
+        s += sb2[j];
+        s = fmaxf(s, 0.f);
+        o0 += s * sw3[j];
+        o1 += s * sw3[h2 + j];
+    }
+    if (sizes) o0 *= sizes[q];
+    out[2 * q] = o0;
+    out[2 * q + 1] = o1;
+}
+
+}  // namespace
+
+// ==========================================================================================
+int asr_conv_agg_importance(asr_hip_context* ctx, const float* compat, const float* dist, i64 n,
+                            float* out) {
+    if (n <= 0) return ASR_HIP_OK;
+    k_agg_importance<<<grid_for(n, 256), 256, 0, ctx->stream>>>(compat, dist, n, out);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_pos,
+                   const float* extents, const float* inp_pos, const float* inp_feat,
+                   const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
+                   int cout, int normalize, const float* bias, int relu, float* out) {
+    if (num_out <= 0) return ASR_HIP_OK;
+    if (cout < 1 || cout > 64) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cout must be 1..64");
+    if (cin < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cin must be >= 1");
+    unsigned blocks = grid_for(num_out * 64, 256);
+    if (cout <= 8)
+        k_cconv<8><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat,
+                                                    nidx, nimp, rs, num_out, cin, cout, normalize,
+                                                    bias, relu, out);
+    else if (cout <= 32)
+        k_cconv<32><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat,
+                                                     nidx, nimp, rs, num_out, cin, cout, normalize,
+                                                     bias, relu, out);
+    else
+        k_cconv<64><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat,
+                                                     nidx, nimp, rs, num_out, cin, cout, normalize,
+                                                     bias, relu, out);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
+    asr_sparse_conv_args a = *pa;
+    if (a.num_out <= 0) return ASR_HIP_OK;
+    if (a.kernel_size < 1 || a.kernel_size > 56)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: kernel_size must be 1..56");
+    if (a.cin < 1 || a.cout < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: bad channel count");
+    if (a.inp_ld < a.cin || a.out_ld < a.cout)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: row stride smaller than channel count");
+    bool mfma_ok = (a.cin % 4 == 0) && (a.inp_ld % 4 == 0) &&
+                   ((uintptr_t)a.inp_features % 16 == 0);
+    int algo = a.algo;
+    if (algo == 0) algo = mfma_ok ? 2 : 1;
+    if (algo == 2 && !mfma_ok)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: MFMA path needs cin %% 4 == 0 and 16 B rows");
+    if (algo == 1) {
+        i64 total = a.num_out * a.cout;
+        k_sconv_scalar<<<grid_for(total, 256), 256, 0, ctx->stream>>>(a);
+        ASR_CHECK_LAUNCH(ctx);
+        return ASR_HIP_OK;
+    }
+    dim3 block(256);
+    unsigned tiles = (unsigned)((a.num_out + TM - 1) / TM);
+    int nt = a.cout > 64 ? 8 : a.cout > 32 ? 4 : a.cout > 16 ? 2 : 1;
+    dim3 grid(tiles, (a.cout + nt * 16 - 1) / (nt * 16));
+    const bool imp = a.inp_importance || a.neighbors_importance;
+#define ASR_LAUNCH_SCONV(NT_)                                              \
+    if (imp)                                                               \
+        k_sconv_mfma<NT_, true><<<grid, block, 0, ctx->stream>>>(a);       \
+    else                                                                   \
+        k_sconv_mfma<NT_, false><<<grid, block, 0, ctx->stream>>>(a);
+    switch (nt) {
+        case 1: ASR_LAUNCH_SCONV(1) break;
+        case 2: ASR_LAUNCH_SCONV(2) break;
+        case 4: ASR_LAUNCH_SCONV(4) break;
+        default: ASR_LAUNCH_SCONV(8) break;
+    }
+#undef ASR_LAUNCH_SCONV
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gidx, const i64* rs,
+                    i64 rows, float* out) {
+    if (rows <= 0) return ASR_HIP_OK;
+    k_reduce_rows<<<grid_for(rows, 256), 256, 0, ctx->stream>>>(values, gidx, rs, rows, out);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const float* w1,
+                    const float* b1, int h1, const float* w2, const float* b2, int h2,
+                    const float* w3, const float* sizes, float* out) {
+    if (v <= 0) return ASR_HIP_OK;
+    if (c > DEC_MAX || h1 > DEC_MAX || h2 > DEC_MAX || c < 1 || h1 < 1 || h2 < 1)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "decode_mlp: layer widths must be 1..64");
+    size_t lds = sizeof(float) * (size_t)(h1 * c + h1 + h2 * h1 + h2 + 2 * h2);
+    k_decode<<<grid_for(v, 256), 256, lds, ctx->stream>>>(code, v, c, w1, b1, h1, w2, b2, h2, w3,
+                                                          sizes, out);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}

@@ -1,0 +1,979 @@
+// asr_geom.hip -- integer / geometry half of the hot path on gfx950:
+//   a3 point location codes, a4 octree closure + 2:1 face balance, a5 55-slot neighbour CSR,
+//   a6 sibling coarsening, a7 voxel info, a8 multi-radius search + scale compatibility,
+//   a11 CSR inversion.
+// All kernels are HBM / latency bound integer work: open-addressing hash tables in HBM
+// (64-bit CAS), rocPRIM radix sort / scan for ordering, one thread per voxel / point / pair.
+// Compiled with -ffp-contract=off: the float expressions below must round exactly like the
+// reference's.
+#include <cstring>
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+#include "asr_common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+// ------------------------------------------------------------------------------------------
+// hash set / map on u64 keys (0 = empty)
+// ------------------------------------------------------------------------------------------
+struct HashTab {
+    u64* keys;
+    int32_t* vals;  // may be null (set)
+    u64 mask;
+};
+
+__device__ inline u64 ld_agent(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// returns 1 = inserted, 0 = existed, -1 = table full; slot_out = slot of the key
+__device__ inline int tab_insert(const HashTab& t, u64 key, u64* slot_out = nullptr) {
+    u64 slot = asr_hash64(key) & t.mask;
+    for (u64 probe = 0; probe <= t.mask; ++probe) {
+        u64 cur = ld_agent(&t.keys[slot]);
+        if (cur == 0) {
+            cur = atomicCAS((unsigned long long*)&t.keys[slot], 0ull, (unsigned long long)key);
+            if (cur == 0) {
+                if (slot_out) *slot_out = slot;
+                return 1;
+            }
+        }
+        if (cur == key) {
+            if (slot_out) *slot_out = slot;
+            return 0;
+        }
+        slot = (slot + 1) & t.mask;
+    }
+    return -1;
+}
+// lookup after the building kernel finished (plain loads)
+__device__ inline bool tab_contains(const HashTab& t, u64 key) {
+    u64 slot = asr_hash64(key) & t.mask;
+    for (u64 probe = 0; probe <= t.mask; ++probe) {
+        u64 cur = t.keys[slot];
+        if (cur == key) return true;
+        if (cur == 0) return false;
+        slot = (slot + 1) & t.mask;
+    }
+    return false;
+}
+__device__ inline int tab_find(const HashTab& t, u64 key) {
+    u64 slot = asr_hash64(key) & t.mask;
+    for (u64 probe = 0; probe <= t.mask; ++probe) {
+        u64 cur = t.keys[slot];
+        if (cur == key) return t.vals[slot];
+        if (cur == 0) return -1;
+        slot = (slot + 1) & t.mask;
+    }
+    return -1;
+}
+__device__ inline i64 tab_find_slot(const HashTab& t, u64 key) {
+    u64 slot = asr_hash64(key) & t.mask;
+    for (u64 probe = 0; probe <= t.mask; ++probe) {
+        u64 cur = t.keys[slot];
+        if (cur == key) return (i64)slot;
+        if (cur == 0) return -1;
+        slot = (slot + 1) & t.mask;
+    }
+    return -1;
+}
+
+u64 next_pow2(u64 x) {
+    u64 p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// a3: point -> (level, key)   octree.h:42-68
+// ------------------------------------------------------------------------------------------
+__device__ inline int level_from_scale(const asr_octree_frame& f, float scale) {
+    for (int level = 0; level <= ASR_MAX_LEVEL; ++level)
+        if (f.voxel_size[level] < scale) return level - 1 > 0 ? level - 1 : 0;
+    return ASR_MAX_LEVEL;
+}
+__device__ inline void frame_coord(const asr_octree_frame& f, float px, float py, float pz,
+                                   int level, int& x, int& y, int& z) {
+    float inv = f.inv_voxel_size[ASR_MAX_LEVEL];
+    float tx = px * inv, ty = py * inv, tz = pz * inv;
+    x = (int)floorf(tx) + f.offset[0];
+    y = (int)floorf(ty) + f.offset[1];
+    z = (int)floorf(tz) + f.offset[2];
+    int s = ASR_MAX_LEVEL - level;
+    x >>= s;
+    y >>= s;
+    z >>= s;
+}
+__device__ inline u64 point_key(const asr_octree_frame& f, const float* pts, const float* radii,
+                                i64 i, float radius_scale, int max_depth) {
+    float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    if (px < f.bb_min[0] || py < f.bb_min[1] || pz < f.bb_min[2] || px > f.bb_max[0] ||
+        py > f.bb_max[1] || pz > f.bb_max[2])
+        return 0;
+    int level = level_from_scale(f, radius_scale * radii[i]);
+    level = level < max_depth ? level : max_depth;
+    int x, y, z;
+    frame_coord(f, px, py, pz, level, x, y, z);
+    return asr_coord_key(x, y, z, level);
+}
+
+__global__ void k_point_keys(asr_octree_frame f, const float* pts, const float* radii, i64 n,
+                             float radius_scale, int max_depth, u64* keys) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = point_key(f, pts, radii, i, radius_scale, max_depth);
+}
+
+// ------------------------------------------------------------------------------------------
+// a4: octree node set.  cnt[0] = nodes inserted, cnt[1] = overflow flag, cnt[2] = next frontier
+// ------------------------------------------------------------------------------------------
+// insert the sibling group of `a` and all missing ancestor groups (+ root).
+// The thread that wins the CAS on a group's first sibling creates the other seven and
+// continues upwards; losers stop (CreateAncestorsAndSiblings, octree.cpp:110-150).
+__device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, u64* frontier,
+                                             int frontier_cap) {
+    while (true) {
+        if (a == 1) {
+            int r = tab_insert(t, 1);
+            if (r == 1) atomicAdd(&cnt[0], 1);
+            if (r < 0) cnt[1] = 1;
+            return;
+        }
+        u64 first = a & ~u64(7);
+        int r = tab_insert(t, first);
+        if (r < 0) {
+            cnt[1] = 1;
+            return;
+        }
+        if (r == 0) return;
+        for (int j = 1; j < 8; ++j)
+            if (tab_insert(t, first + j) < 0) cnt[1] = 1;
+        atomicAdd(&cnt[0], 8);
+        if (frontier) {
+            int pos = atomicAdd(&cnt[2], 1);
+            if (pos < frontier_cap)
+                frontier[pos] = first;
+            else
+                cnt[1] = 1;
+        }
+        a >>= 3;
+    }
+}
+
+__global__ void k_octree_insert_points(asr_octree_frame f, const float* pts, const float* radii,
+                                       i64 n, float radius_scale, int max_depth, HashTab t,
+                                       int* cnt) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 key = point_key(f, pts, radii, i, radius_scale, max_depth);
+    if (key == 0) return;  // the reference inserts key 0 here and then hits UB
+    insert_with_ancestors(t, key, cnt, nullptr, 0);
+}
+
+// frontier of BalanceFaces: all first siblings (octree.cpp:159-166)
+__global__ void k_collect_first_siblings(HashTab t, u64* frontier, int* cnt, int frontier_cap) {
+    u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (s > t.mask) return;
+    u64 k = t.keys[s];
+    if (k != 0 && (k & 7) == 0) {
+        int pos = atomicAdd(&cnt[2], 1);
+        if (pos < frontier_cap)
+            frontier[pos] = k;
+        else
+            cnt[1] = 1;
+    }
+}
+// leaf test against the node set at round start (octree.cpp:175)
+__global__ void k_balance_classify(HashTab t, u64* frontier, int m) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    u64 k = frontier[i];
+    bool has_child = (__clzll((long long)k) > 1) && tab_contains(t, k << 3);
+    if (has_child || k == 1) frontier[i] = 0;  // drop
+}
+// octree.cpp:177-203 for all surviving frontier entries
+__global__ void k_balance_insert(HashTab t, const u64* frontier, int m, u64* next, int* cnt,
+                                 int frontier_cap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * 6) return;
+    u64 k = frontier[i / 6];
+    if (k == 0) return;
+    int j = i % 6;
+    const int ox = (j == 0) ? -1 : (j == 3) ? 1 : 0;
+    const int oy = (j == 1) ? -1 : (j == 4) ? 1 : 0;
+    const int oz = (j == 2) ? -1 : (j == 5) ? 1 : 0;
+    int x, y, z, lev;
+    asr_key_coord(k >> 3, x, y, z, lev);
+    u64 key = asr_coord_key(x + ox, y + oy, z + oz, lev);
+    if (key == 0) return;
+    insert_with_ancestors(t, key, cnt, next, frontier_cap);
+}
+__global__ void k_collect_nodes(HashTab t, u64* nodes, u64* leaves, int* cnt) {
+    u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (s > t.mask) return;
+    u64 k = t.keys[s];
+    if (k == 0) return;
+    nodes[atomicAdd(&cnt[3], 1)] = k;
+    bool has_child = (__clzll((long long)k) > 1) && tab_contains(t, k << 3);
+    if (!has_child) leaves[atomicAdd(&cnt[4], 1)] = k;
+}
+
+// ------------------------------------------------------------------------------------------
+// a5: neighbour CSR.  grid.cpp:43-175
+// ------------------------------------------------------------------------------------------
+__global__ void k_map_build(const u64* keys, i64 v, HashTab t, int* cnt) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    u64 slot;
+    int r = tab_insert(t, keys[i], &slot);
+    if (r < 0)
+        cnt[1] = 1;
+    else
+        t.vals[slot] = (int32_t)i;
+}
+
+__constant__ int8_t c_child_off[24][3] = {
+        {-1, 0, 0}, {-1, 1, 0}, {-1, 0, 1}, {-1, 1, 1}, {2, 0, 0},  {2, 1, 0},  {2, 0, 1},  {2, 1, 1},
+        {0, -1, 0}, {1, -1, 0}, {0, -1, 1}, {1, -1, 1}, {0, 2, 0},  {1, 2, 0},  {0, 2, 1},  {1, 2, 1},
+        {0, 0, -1}, {1, 0, -1}, {0, 1, -1}, {1, 1, -1}, {0, 0, 2},  {1, 0, 2},  {0, 1, 2},  {1, 1, 2}};
+__constant__ int8_t c_nb_off[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0},
+                                      {0, 1, 0},  {0, 0, -1}, {0, 0, 1}};
+__constant__ int8_t c_parent_koff[6][8] = {
+        {-1, 0, -1, 1, -1, 2, -1, 3}, {0, -1, 1, -1, 2, -1, 3, -1}, {-1, -1, 0, 1, -1, -1, 2, 3},
+        {0, 1, -1, -1, 2, 3, -1, -1}, {-1, -1, -1, -1, 0, 1, 2, 3}, {0, 1, 2, 3, -1, -1, -1, -1}};
+
+// candidate c in [0,36): 0..5 same level, 6..29 child level, 30..35 parent level.
+// returns neighbour index or -1; slot = kernel index of the hit.
+__device__ inline int neighbor_candidate(const HashTab& t, u64 key, int x, int y, int z, int lev,
+                                         int c, int& slot) {
+    if (c < 6) {
+        u64 nk = asr_coord_key(x + c_nb_off[c][0], y + c_nb_off[c][1], z + c_nb_off[c][2], lev);
+        slot = 1 + c;
+        return nk ? tab_find(t, nk) : -1;
+    } else if (c < 30) {
+        if (lev >= ASR_MAX_LEVEL) return -1;
+        int j = c - 6;
+        u64 nk = asr_coord_key(2 * x + c_child_off[j][0], 2 * y + c_child_off[j][1],
+                               2 * z + c_child_off[j][2], lev + 1);
+        slot = 7 + j;
+        return nk ? tab_find(t, nk) : -1;
+    } else {
+        if (lev <= 0) return -1;
+        int j = c - 30;
+        u64 nk = asr_coord_key(x + c_nb_off[j][0], y + c_nb_off[j][1], z + c_nb_off[j][2], lev);
+        if (!nk) return -1;
+        int koff = c_parent_koff[j][nk & 7];
+        if (koff < 0) return -1;  // sibling: its parent is this voxel's parent, never in the grid
+        slot = 31 + 4 * j + koff;
+        return tab_find(t, nk >> 3);
+    }
+}
+
+__global__ void k_neighbors_count(const u64* keys, i64 v, HashTab t, i64* counts, u64* masks) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i > v) return;
+    if (i == v) {
+        counts[v] = 0;
+        return;
+    }
+    u64 key = keys[i];
+    int x, y, z, lev;
+    asr_key_coord(key, x, y, z, lev);
+    u64 m = 0;
+    int n = 1;
+#pragma unroll 6
+    for (int c = 0; c < 36; ++c) {
+        int slot;
+        int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
+        if (idx >= 0) {
+            m |= u64(1) << c;
+            ++n;
+        }
+    }
+    counts[i] = n;
+    if (masks) masks[i] = m;
+}
+__global__ void k_neighbors_fill(const u64* keys, i64 v, HashTab t, const i64* rs, const u64* masks,
+                                 int32_t* nidx, uint8_t* nkidx) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    u64 key = keys[i];
+    int x, y, z, lev;
+    asr_key_coord(key, x, y, z, lev);
+    i64 o = rs[i];
+    nidx[o] = (int32_t)i;
+    nkidx[o] = 0;
+    ++o;
+    u64 m = masks ? masks[i] : ~u64(0);
+    for (int c = 0; c < 36; ++c) {
+        if (!((m >> c) & 1)) continue;
+        int slot;
+        int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
+        if (idx >= 0) {
+            nidx[o] = idx;
+            nkidx[o] = (uint8_t)slot;
+            ++o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a6: CombineSiblings.  grid.cpp:177-243
+// ------------------------------------------------------------------------------------------
+__device__ inline bool merged_head(const u64* keys, i64 v, i64 i) {
+    u64 k = keys[i];
+    return (k & 7) == 0 && i + 7 < v && keys[i + 7] == (k | 7);
+}
+// state: 0 = carried, 1 = merged head, 2 = merged member (dropped)
+__device__ inline int coarsen_state(const u64* keys, i64 v, i64 i) {
+    u64 k = keys[i];
+    if ((k & 7) == 0) return merged_head(keys, v, i) ? 1 : 0;
+    i64 h = i - (i64)(k & 7);
+    if (h >= 0 && keys[h] == (k & ~u64(7)) && merged_head(keys, v, h)) return 2;
+    return 0;
+}
+__global__ void k_coarsen_count(const u64* keys, i64 v, int* cnt) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    if (coarsen_state(keys, v, i) != 2) atomicAdd(&cnt[5], 1);
+}
+__global__ void k_coarsen_emit(const u64* keys, i64 v, u64* out_keys, int32_t* out_src, int* cnt) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    int st = coarsen_state(keys, v, i);
+    if (st == 2) return;
+    int pos = atomicAdd(&cnt[5], 1);
+    out_keys[pos] = st == 1 ? keys[i] >> 3 : keys[i];
+    out_src[pos] = (int32_t)i;
+}
+__global__ void k_coarsen_up(const u64* keys, i64 v, const int32_t* sorted_src, i64 v_out,
+                             int32_t* up_idx, uint8_t* up_kidx) {
+    i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (p >= v_out) return;
+    i64 i = sorted_src[p];
+    if (merged_head(keys, v, i)) {
+        for (int j = 0; j < 8; ++j) {
+            up_idx[i + j] = (int32_t)p;
+            up_kidx[i + j] = (uint8_t)j;
+        }
+    } else {
+        up_idx[i] = (int32_t)p;
+        up_kidx[i] = 8;
+    }
+}
+__global__ void k_iota64(i64* out, i64 n) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// ------------------------------------------------------------------------------------------
+// a7: voxel centres / sizes.  grid.cpp:251-268, octree.h:78-93 (double arithmetic)
+// ------------------------------------------------------------------------------------------
+__global__ void k_voxel_info(asr_octree_frame f, const u64* keys, i64 v, float* centers,
+                             float* sizes) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    int x, y, z, lev;
+    asr_key_coord(keys[i], x, y, z, lev);
+    int s = ASR_MAX_LEVEL - lev;
+    double half = 0.5 * (double)(u64(1) << s);
+    double vs = (double)f.voxel_size[ASR_MAX_LEVEL];
+    if (centers) {
+        centers[3 * i + 0] = (float)((((x << s) - f.offset[0]) + half) * vs);
+        centers[3 * i + 1] = (float)((((y << s) - f.offset[1]) + half) * vs);
+        centers[3 * i + 2] = (float)((((z << s) - f.offset[2]) + half) * vs);
+    }
+    if (sizes) sizes[i] = f.voxel_size[lev];
+}
+
+// ------------------------------------------------------------------------------------------
+// a8: multi radius search.  Points are sorted by their level-21 Morton code inside the octree
+// frame; for every level used by a query a hash table maps cell -> [start,end) in that order;
+// a query of radius r looks at the 3^3 cells of the deepest level whose cell size is >= r.
+// ------------------------------------------------------------------------------------------
+__global__ void k_point_codes(asr_octree_frame f, const float* pts, i64 n, u64* codes,
+                              int32_t* ids) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x, y, z;
+    frame_coord(f, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], ASR_MAX_LEVEL, x, y, z);
+    const int lim = (1 << ASR_MAX_LEVEL) - 1;
+    x = min(max(x, 0), lim);
+    y = min(max(y, 0), lim);
+    z = min(max(z, 0), lim);
+    codes[i] = asr_morton3d((u64)x, (u64)y, (u64)z);
+    ids[i] = (int32_t)i;
+}
+__global__ void k_gather_points(const float* pts, const int32_t* ids, i64 n, float4* sorted) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t id = ids[i];
+    sorted[i] = make_float4(pts[3 * (i64)id], pts[3 * (i64)id + 1], pts[3 * (i64)id + 2],
+                            __int_as_float(id));
+}
+__device__ inline int query_level(const asr_octree_frame& f, float r) {
+    int lev = 0;
+    while (lev < ASR_MAX_LEVEL && f.voxel_size[lev + 1] >= r) ++lev;
+    return lev;
+}
+__global__ void k_query_levels(asr_octree_frame f, const float* sizes, i64 v, int* cnt) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    int lev = query_level(f, sizes[i]);
+    atomicMin(&cnt[6], lev);
+    atomicMax(&cnt[7], lev);
+}
+// boundaries of the sorted code array: cell (prefix,level) starts / ends at i
+template <bool COUNT_ONLY>
+__global__ void k_cell_bounds(const u64* codes, i64 n, int lmin, int lmax, HashTab t,
+                              int32_t* start, int32_t* end, int* cnt) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i > n) return;
+    u64 a = i > 0 ? codes[i - 1] : 0, b = i < n ? codes[i] : 0;
+    int local = 0;
+    for (int l = lmin; l <= lmax; ++l) {
+        int s = 3 * (ASR_MAX_LEVEL - l);
+        u64 pa = (s >= 63) ? 0 : (a >> s), pb = (s >= 63) ? 0 : (b >> s);
+        bool has_a = i > 0, has_b = i < n;
+        if (has_a && has_b && pa == pb) continue;
+        u64 marker = u64(1) << (3 * l);
+        if (COUNT_ONLY) {
+            if (has_b) ++local;
+        } else {
+            u64 slot;
+            if (has_a) {
+                if (tab_insert(t, pa | marker, &slot) < 0)
+                    cnt[1] = 1;
+                else
+                    end[slot] = (int32_t)i;
+            }
+            if (has_b) {
+                if (tab_insert(t, pb | marker, &slot) < 0)
+                    cnt[1] = 1;
+                else
+                    start[slot] = (int32_t)i;
+            }
+        }
+    }
+    if (COUNT_ONLY && local) atomicAdd(&cnt[8], local);
+}
+
+__device__ inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+
+// MODE 0: count, MODE 1: write unsorted candidates
+template <int MODE>
+__global__ void k_radius_query(asr_octree_frame f, const float4* sorted, const float* centers,
+                               const float* sizes, i64 v, HashTab t, const int32_t* start,
+                               const int32_t* end, i64* counts, const i64* rs, int32_t* tmp_idx,
+                               float* tmp_dist, int32_t* tmp_row) {
+    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (MODE == 0 && q == v) counts[v] = 0;
+    if (q >= v) return;
+    float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
+    float r = sizes[q];
+    float r2 = r * r;
+    int lev = query_level(f, r);
+    int x, y, z;
+    frame_coord(f, cx, cy, cz, lev, x, y, z);
+    int lim = (1 << lev) - 1;
+    u64 marker = u64(1) << (3 * lev);
+    i64 n = 0;
+    i64 o = MODE == 1 ? rs[q] : 0;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                int xx = x + dx, yy = y + dy, zz = z + dz;
+                if (xx < 0 || yy < 0 || zz < 0 || xx > lim || yy > lim || zz > lim) continue;
+                i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | marker);
+                if (slot < 0) continue;
+                int32_t b = start[slot], e = end[slot];
+                for (int32_t p = b; p < e; ++p) {
+                    float4 pt = sorted[p];
+                    float d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+                    if (d < r2) {
+                        if (MODE == 1) {
+                            tmp_idx[o + n] = __float_as_int(pt.w);
+                            tmp_dist[o + n] = d;
+                            tmp_row[o + n] = (int32_t)q;
+                        }
+                        ++n;
+                    }
+                }
+            }
+    if (MODE == 0) counts[q] = n;
+}
+// order every row by (distance, index): rank by counting, one thread per pair
+__global__ void k_radius_rank(const int32_t* tmp_idx, const float* tmp_dist, const int32_t* tmp_row,
+                              i64 num_pairs, const i64* rs, const float* sizes, const float* radii,
+                              int32_t* idx, float* dist, float* compat) {
+    i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (p >= num_pairs) return;
+    int32_t q = tmp_row[p];
+    i64 b = rs[q], e = rs[q + 1];
+    float d = tmp_dist[p];
+    int32_t id = tmp_idx[p];
+    i64 rank = 0;
+    for (i64 t = b; t < e; ++t) {
+        float dt = tmp_dist[t];
+        int32_t it = tmp_idx[t];
+        rank += (dt < d || (dt == d && it < id)) ? 1 : 0;
+    }
+    i64 o = b + rank;
+    idx[o] = id;
+    dist[o] = d;
+    if (compat) {
+        float a = sizes[q];
+        float bb = 2 * radii[id];
+        float ratio = fminf(a, bb) / fmaxf(a, bb);
+        compat[o] = ratio * ratio;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a11: CSR inversion
+// ------------------------------------------------------------------------------------------
+__global__ void k_invert_hist(const int32_t* idx, i64 p, i64* counts, i64 num_points) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < p) atomicAdd((unsigned long long*)&counts[idx[i]], 1ull);
+    (void)num_points;
+}
+__global__ void k_iota32(int32_t* out, i64 n) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+}
+__global__ void k_invert_fill(const int32_t* sorted_src, i64 p, const i64* rs, i64 num_rows,
+                              const uint8_t* attr, int32_t* out_idx, uint8_t* out_attr) {
+    i64 d = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (d >= p) return;
+    i64 src = sorted_src[d];
+    // row of pair src: largest q with rs[q] <= src
+    i64 lo = 0, hi = num_rows;
+    while (hi - lo > 1) {
+        i64 mid = (lo + hi) >> 1;
+        if (rs[mid] <= src)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    out_idx[d] = (int32_t)lo;
+    if (attr) out_attr[d] = attr[src];
+}
+
+// ------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------
+int ensure_flags(asr_hip_context* ctx) {
+    if (!ctx->d_flags) {
+        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_flags, 64 * sizeof(int)));
+    }
+    return ASR_HIP_OK;
+}
+int read_flags(asr_hip_context* ctx, int* host) {
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(host, ctx->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_HIP_OK;
+}
+int set_flag(asr_hip_context* ctx, int which, int value) {
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_flags + which, &value, sizeof(int),
+                                      hipMemcpyHostToDevice, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_HIP_OK;
+}
+
+int make_table(asr_hip_context* ctx, Arena& arena, u64 cap, bool with_vals, HashTab& t) {
+    t.keys = arena_alloc<u64>(arena, cap);
+    t.vals = with_vals ? arena_alloc<int32_t>(arena, cap) : nullptr;
+    t.mask = cap - 1;
+    if (!t.keys || (with_vals && !t.vals)) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(t.keys, 0, cap * sizeof(u64), ctx->stream));
+    return ASR_HIP_OK;
+}
+
+int sort_keys(asr_hip_context* ctx, Arena& arena, const u64* in, u64* out, i64 n, int end_bit = 64) {
+    if (n <= 0) return ASR_HIP_OK;
+    size_t tb = 0;
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_keys(nullptr, tb, in, out, (size_t)n, 0, end_bit,
+                                                ctx->stream));
+    void* tmp = arena.alloc(tb ? tb : 256);
+    if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_keys(tmp, tb, in, out, (size_t)n, 0, end_bit,
+                                                ctx->stream));
+    return ASR_HIP_OK;
+}
+template <class K, class V>
+int sort_pairs(asr_hip_context* ctx, Arena& arena, const K* kin, K* kout, const V* vin, V* vout,
+               i64 n, int end_bit) {
+    if (n <= 0) return ASR_HIP_OK;
+    size_t tb = 0;
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, (size_t)n, 0,
+                                                 end_bit, ctx->stream));
+    void* tmp = arena.alloc(tb ? tb : 256);
+    if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (size_t)n, 0,
+                                                 end_bit, ctx->stream));
+    return ASR_HIP_OK;
+}
+// out[0..n] = exclusive scan of in[0..n] (in has n+1 entries, in[n] ignored by callers that set it 0)
+int scan_counts(asr_hip_context* ctx, Arena& arena, const i64* in, i64* out, i64 n_plus_1) {
+    size_t tb = 0;
+    ASR_HIP_CHECK(ctx, rocprim::exclusive_scan(nullptr, tb, in, out, i64(0), (size_t)n_plus_1,
+                                               rocprim::plus<i64>(), ctx->stream));
+    void* tmp = arena.alloc(tb ? tb : 256);
+    if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, rocprim::exclusive_scan(tmp, tb, in, out, i64(0), (size_t)n_plus_1,
+                                               rocprim::plus<i64>(), ctx->stream));
+    return ASR_HIP_OK;
+}
+int read_i64(asr_hip_context* ctx, const i64* dev, i64* host) {
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(host, dev, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return ASR_HIP_OK;
+}
+
+int bits_for(i64 n) {
+    int b = 1;
+    while ((i64(1) << b) < n) ++b;
+    return b;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// entry points used by asr_api.hip
+// ==========================================================================================
+int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                        const float* radii, i64 n, float radius_scale, int max_depth, u64* keys) {
+    if (n <= 0) return ASR_HIP_OK;
+    k_point_keys<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, radii, n, radius_scale,
+                                                            max_depth, keys);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+// Result: ctx->nodes / ctx->leaves (sorted) in the persist arena.
+int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                          const float* radii, i64 n, float radius_scale, int max_depth) {
+    ASR_TRY(ensure_flags(ctx));
+    if (max_depth > ASR_MAX_LEVEL) max_depth = ASR_MAX_LEVEL;
+    if (max_depth < 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "max_depth must be >= 0");
+    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 4 * n));
+    int host[16];
+    for (int attempt = 0; attempt < 6; ++attempt, cap <<= 2) {
+        ctx->scratch.reset();
+        HashTab t;
+        ASR_TRY(make_table(ctx, ctx->scratch, cap, false, t));
+        int fcap = (int)std::min<u64>(cap / 8, u64(1) << 30);
+        u64* fr_a = arena_alloc<u64>(ctx->scratch, fcap);
+        u64* fr_b = arena_alloc<u64>(ctx->scratch, fcap);
+        if (!fr_a || !fr_b) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        if (n > 0) {
+            k_octree_insert_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
+                    *frame, pts, radii, n, radius_scale, max_depth, t, ctx->d_flags);
+            ASR_CHECK_LAUNCH(ctx);
+        }
+        k_collect_first_siblings<<<grid_for((i64)cap, BLK), BLK, 0, ctx->stream>>>(
+                t, fr_a, ctx->d_flags, fcap);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(read_flags(ctx, host));
+        bool overflow = host[1] != 0 || (u64)host[0] * 2 > cap;
+        int m = host[2];
+        while (!overflow && m > 0) {
+            ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 2, 0, sizeof(int), ctx->stream));
+            k_balance_classify<<<grid_for(m, BLK), BLK, 0, ctx->stream>>>(t, fr_a, m);
+            ASR_CHECK_LAUNCH(ctx);
+            k_balance_insert<<<grid_for((i64)m * 6, BLK), BLK, 0, ctx->stream>>>(
+                    t, fr_a, m, fr_b, ctx->d_flags, fcap);
+            ASR_CHECK_LAUNCH(ctx);
+            ASR_TRY(read_flags(ctx, host));
+            overflow = host[1] != 0 || (u64)host[0] * 2 > cap;
+            m = host[2];
+            std::swap(fr_a, fr_b);
+        }
+        if (overflow) continue;
+        i64 num_nodes = host[0];
+        if (num_nodes == 0) {
+            ctx->num_nodes = ctx->num_leaves = 0;
+            ctx->nodes = ctx->leaves = nullptr;
+            return ASR_HIP_OK;
+        }
+        u64* nodes_u = arena_alloc<u64>(ctx->scratch, num_nodes);
+        u64* leaves_u = arena_alloc<u64>(ctx->scratch, num_nodes);
+        if (!nodes_u || !leaves_u) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_collect_nodes<<<grid_for((i64)cap, BLK), BLK, 0, ctx->stream>>>(t, nodes_u, leaves_u,
+                                                                         ctx->d_flags);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(read_flags(ctx, host));
+        if (host[3] != num_nodes)
+            ASR_FAIL(ctx, ASR_HIP_ELOGIC, "octree node count mismatch %d vs %lld", host[3],
+                     (long long)num_nodes);
+        i64 num_leaves = host[4];
+        ctx->nodes = arena_alloc<u64>(ctx->persist, num_nodes);
+        ctx->leaves = arena_alloc<u64>(ctx->persist, num_leaves);
+        if (!ctx->nodes || !ctx->leaves) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(sort_keys(ctx, ctx->scratch, nodes_u, ctx->nodes, num_nodes));
+        ASR_TRY(sort_keys(ctx, ctx->scratch, leaves_u, ctx->leaves, num_leaves));
+        ctx->num_nodes = num_nodes;
+        ctx->num_leaves = num_leaves;
+        return ASR_HIP_OK;
+    }
+    ASR_FAIL(ctx, ASR_HIP_ELOGIC, "octree hash table overflow after 6 growth attempts");
+}
+
+static int build_key_map(asr_hip_context* ctx, const u64* keys, i64 v, HashTab& t) {
+    ASR_TRY(ensure_flags(ctx));
+    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * v));
+    ASR_TRY(make_table(ctx, ctx->scratch, cap, true, t));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    k_map_build<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* rs, i64* num_pairs) {
+    if (v <= 0) {
+        *num_pairs = 0;
+        if (rs) ASR_HIP_CHECK(ctx, hipMemsetAsync(rs, 0, sizeof(i64), ctx->stream));
+        return ASR_HIP_OK;
+    }
+    HashTab t;
+    ASR_TRY(build_key_map(ctx, keys, v, t));
+    i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
+    if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, nullptr);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
+    ASR_TRY(read_i64(ctx, rs + v, num_pairs));
+    return ASR_HIP_OK;
+}
+int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const i64* rs,
+                            int32_t* idx, uint8_t* kidx) {
+    if (v <= 0) return ASR_HIP_OK;
+    HashTab t;
+    ASR_TRY(build_key_map(ctx, keys, v, t));
+    k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, nullptr, idx, kidx);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+// fused variant for the whole-path driver: one map build, masks carried from count to fill.
+int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* keys, i64 v,
+                             i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs) {
+    HashTab t;
+    ASR_TRY(build_key_map(ctx, keys, v, t));
+    i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
+    u64* masks = arena_alloc<u64>(ctx->scratch, v);
+    i64* rs = arena_alloc<i64>(out_arena, v + 1);
+    if (!counts || !masks || !rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, masks);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
+    ASR_TRY(read_i64(ctx, rs + v, num_pairs));
+    int32_t* idx = arena_alloc<int32_t>(out_arena, *num_pairs);
+    uint8_t* kidx = arena_alloc<uint8_t>(out_arena, *num_pairs);
+    if (!idx || !kidx) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, masks, idx, kidx);
+    ASR_CHECK_LAUNCH(ctx);
+    *rs_out = rs;
+    *idx_out = idx;
+    *kidx_out = kidx;
+    return ASR_HIP_OK;
+}
+
+int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_out) {
+    ASR_TRY(ensure_flags(ctx));
+    if (v <= 0) {
+        *v_out = 0;
+        return ASR_HIP_OK;
+    }
+    int host[16];
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    k_coarsen_count<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(read_flags(ctx, host));
+    *v_out = host[5];
+    return ASR_HIP_OK;
+}
+int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out_keys, i64 v_out,
+                          int32_t* up_idx, uint8_t* up_kidx, i64* up_rs) {
+    ASR_TRY(ensure_flags(ctx));
+    if (v <= 0) return ASR_HIP_OK;
+    u64* k_u = arena_alloc<u64>(ctx->scratch, v_out);
+    int32_t* s_u = arena_alloc<int32_t>(ctx->scratch, v_out);
+    int32_t* s_s = arena_alloc<int32_t>(ctx->scratch, v_out);
+    if (!k_u || !s_u || !s_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    k_coarsen_emit<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, k_u, s_u, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, out_keys, s_u, s_s, v_out, 64)));
+    k_coarsen_up<<<grid_for(v_out, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, v_out, up_idx, up_kidx);
+    ASR_CHECK_LAUNCH(ctx);
+    k_iota64<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(up_rs, v + 1);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_geom_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame, const u64* keys,
+                        i64 v, float* centers, float* sizes) {
+    if (v <= 0) return ASR_HIP_OK;
+    k_voxel_info<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(*frame, keys, v, centers, sizes);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+// state kept in the scratch arena between _count and _fill
+struct RadiusState {
+    bool valid = false;
+    asr_octree_frame frame;
+    float4* sorted = nullptr;
+    HashTab tab;
+    int32_t* start = nullptr;
+    int32_t* end = nullptr;
+    i64 n = 0, v = 0;
+};
+static RadiusState& rstate(asr_hip_context* ctx) {
+    if (!ctx->radius_state) ctx->radius_state = new RadiusState();
+    return *(RadiusState*)ctx->radius_state;
+}
+void asr_geom_release(asr_hip_context* ctx) {
+    delete (RadiusState*)ctx->radius_state;
+    ctx->radius_state = nullptr;
+}
+
+int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                          i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
+                          i64* num_pairs) {
+    ASR_TRY(ensure_flags(ctx));
+    RadiusState& st = rstate(ctx);
+    st.valid = false;
+    if (v <= 0) {
+        *num_pairs = 0;
+        if (rs) ASR_HIP_CHECK(ctx, hipMemsetAsync(rs, 0, sizeof(i64), ctx->stream));
+        return ASR_HIP_OK;
+    }
+    if (n >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many points for int32 indices");
+    int host[16];
+    st.frame = *frame;
+    st.n = n;
+    st.v = v;
+    // sort points by code
+    u64* codes_u = arena_alloc<u64>(ctx->scratch, n + 1);
+    u64* codes = arena_alloc<u64>(ctx->scratch, n + 1);
+    int32_t* ids_u = arena_alloc<int32_t>(ctx->scratch, n + 1);
+    int32_t* ids = arena_alloc<int32_t>(ctx->scratch, n + 1);
+    st.sorted = arena_alloc<float4>(ctx->scratch, n + 1);
+    if (!codes_u || !codes || !ids_u || !ids || !st.sorted)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    if (n > 0) {
+        k_point_codes<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, n, codes_u, ids_u);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes_u, codes, ids_u, ids, n, 63)));
+        k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    // level range of the queries
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    int init[2] = {ASR_MAX_LEVEL, 0};
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_flags + 6, init, 2 * sizeof(int),
+                                      hipMemcpyHostToDevice, ctx->stream));
+    k_query_levels<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(*frame, sizes, v, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(read_flags(ctx, host));
+    int lmin = host[6], lmax = host[7];
+    // cell table
+    HashTab dummy{nullptr, nullptr, 0};
+    if (n > 0) {
+        k_cell_bounds<true><<<grid_for(n + 1, BLK), BLK, 0, ctx->stream>>>(
+                codes, n, lmin, lmax, dummy, nullptr, nullptr, ctx->d_flags);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    ASR_TRY(read_flags(ctx, host));
+    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * (i64)host[8]));
+    ASR_TRY(make_table(ctx, ctx->scratch, cap, false, st.tab));
+    st.start = arena_alloc<int32_t>(ctx->scratch, cap);
+    st.end = arena_alloc<int32_t>(ctx->scratch, cap);
+    if (!st.start || !st.end) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    if (n > 0) {
+        k_cell_bounds<false><<<grid_for(n + 1, BLK), BLK, 0, ctx->stream>>>(
+                codes, n, lmin, lmax, st.tab, st.start, st.end, ctx->d_flags);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
+    if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_radius_query<0><<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(
+            *frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, counts, nullptr, nullptr,
+            nullptr, nullptr);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
+    ASR_TRY(read_i64(ctx, rs + v, num_pairs));
+    ASR_TRY(read_flags(ctx, host));
+    if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search cell table overflow");
+    st.valid = true;
+    return ASR_HIP_OK;
+}
+
+int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* radii, i64 n,
+                         const float* centers, const float* sizes, i64 v, const i64* rs,
+                         int32_t* idx, float* dist, float* compat) {
+    RadiusState& st = rstate(ctx);
+    (void)pts;
+    if (v <= 0) return ASR_HIP_OK;
+    if (!st.valid || st.n != n || st.v != v)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL,
+                 "asr_hip_multi_radius_search_fill must follow the matching _count call");
+    i64 num_pairs = 0;
+    ASR_TRY(read_i64(ctx, rs + v, &num_pairs));
+    if (num_pairs > 0) {
+        int32_t* t_idx = arena_alloc<int32_t>(ctx->scratch, num_pairs);
+        float* t_dist = arena_alloc<float>(ctx->scratch, num_pairs);
+        int32_t* t_row = arena_alloc<int32_t>(ctx->scratch, num_pairs);
+        if (!t_idx || !t_dist || !t_row) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_radius_query<1><<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(
+                st.frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, nullptr, rs, t_idx,
+                t_dist, t_row);
+        ASR_CHECK_LAUNCH(ctx);
+        k_radius_rank<<<grid_for(num_pairs, BLK), BLK, 0, ctx->stream>>>(
+                t_idx, t_dist, t_row, num_pairs, rs, sizes, radii, idx, dist, compat);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    st.valid = false;
+    return ASR_HIP_OK;
+}
+
+int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, const i64* rs,
+                    i64 num_rows, const uint8_t* attr, int32_t* out_idx, i64* out_rs,
+                    uint8_t* out_attr) {
+    i64 p = 0;
+    if (num_rows > 0) ASR_TRY(read_i64(ctx, rs + num_rows, &p));
+    i64* counts = arena_alloc<i64>(ctx->scratch, num_points + 1);
+    if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, (num_points + 1) * sizeof(i64), ctx->stream));
+    if (p > 0) {
+        k_invert_hist<<<grid_for(p, BLK), BLK, 0, ctx->stream>>>(idx, p, counts, num_points);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, out_rs, num_points + 1));
+    if (p > 0) {
+        int32_t* src = arena_alloc<int32_t>(ctx->scratch, p);
+        int32_t* src_s = arena_alloc<int32_t>(ctx->scratch, p);
+        int32_t* key_s = arena_alloc<int32_t>(ctx->scratch, p);
+        if (!src || !src_s || !key_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_iota32<<<grid_for(p, BLK), BLK, 0, ctx->stream>>>(src, p);
+        ASR_CHECK_LAUNCH(ctx);
+        // stable LSD radix sort by target row == "fill in query order" 
+        ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, idx, key_s, src, src_s, p,
+                                              bits_for(num_points + 1))));
+        k_invert_fill<<<grid_for(p, BLK), BLK, 0, ctx->stream>>>(src_s, p, rs, num_rows, attr,
+                                                                out_idx, out_attr);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    return ASR_HIP_OK;
+}

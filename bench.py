@@ -1,0 +1,183 @@
+"""Benchmark of the hot path: input points/sec from device-resident points / normals / radii to
+signed implicit values (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the whole path (octree -> 5 grids -> aggregation search -> continuous conv
+-> 53 sparse convs -> decoder) over one synthetic 10 M-point scan-like cloud (config C3 of
+BASELINE.json / SURVEY 8(d)) that is already resident in HBM.  The path shards by scan: every
+rank owns one scan, there is no data-path collective ("scaling": "weak"); value = points all
+ranks processed / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "adaptive-surface-reconstruction_amd"), REPO, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
+
+
+def conv_flops(sizes, shapes):
+    """algorithmic FLOP of the 53 sparse convs: 2 * P * Cin * Cout per launch with P the actual
+    pair count of the launch; a transition has one pair per voxel of the finer grid"""
+    V = list(sizes.num_voxels)
+    P = list(sizes.num_pairs)
+    total, launches = 0.0, 0
+    for name, shp in shapes.items():
+        if not name.endswith(".kernel") or name.startswith("cconv"):
+            continue
+        k, cin, cout = shp
+        blk = name.split(".")[0]
+        lvl = int(blk[-1])
+        if k == 55:
+            pair_counts = [P[lvl]]
+        elif blk.startswith("sparseconv_down"):
+            pair_counts = [V[lvl - 1]] + ([V[3]] if lvl == 3 else [])  # down3 also runs 3->4
+        else:
+            pair_counts = [V[lvl]]
+        for pairs in pair_counts:
+            total += 2.0 * pairs * cin * cout
+            launches += 1
+    return total, launches
+
+
+def cpu_baseline(n_sample, seed):
+    """the oracle ("port" of the reference path incl. the Open3D op semantics) timed on the host
+    cores on a bounded sample of the same workload generator"""
+    import parity
+    from asr_hip import synth
+    from oracle import oracle as O
+    O.lib()
+    pts, nrm = synth.scan_cloud(n_sample, seed=seed, device="cpu")
+    points, normals = pts.numpy(), nrm.numpy()
+    radii = synth.knn_radii(points, 24)
+    bb_min, bb_max = synth.bounding_box(points, 0.1)
+    weights = synth.make_weights(1, seed=0, init="reference")
+    timings = {}
+    t0 = time.time()
+    parity.oracle_forward(points, normals, radii, bb_min, bb_max, weights, timings=timings)
+    dt = time.time() - t0
+    return {"value": n_sample / dt, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d-point slice of the C3 scan generator, whole path, %.1f s; stage s: %s" %
+                      (n_sample, dt, {k: round(v, 2) for k, v in timings.items()})}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=int(os.environ.get("ASR_BENCH_POINTS", 10_000_000)))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("ASR_BENCH_CPU_SAMPLE", 400_000)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                device_id=dev if args.backend == "nccl" else None)
+
+    from asr_hip import synth
+    from asr_hip.pipeline import ImplicitPipeline
+
+    # ---- inputs (untimed): one scan per rank, radii = exact 24-NN distance -------------------
+    n = args.points
+    pts, nrm = synth.scan_cloud(n, seed=1000 + rank, device=dev)
+    radii = torch.from_numpy(synth.knn_radii(pts.cpu().numpy(), 24)).to(dev)
+    bb_min, bb_max = synth.bounding_box(pts, 0.1)
+    weights = synth.make_weights(1, seed=0, init="reference")  # released weights are not in the repo
+    pipe = ImplicitPipeline(weights, device=dev)
+    shapes = synth.unet5_param_shapes(1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return pipe.forward(pts, nrm, radii, bb_min, bb_max)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stage_sum = dict.fromkeys(ImplicitPipeline.STAGES, 0.0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        values = step()
+        # stage times come from hip events recorded on the stream inside the library
+        for k, v in pipe.stage_ms().items():
+            stage_sum[k] += v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert values.shape[0] == pipe.sizes.num_voxels[0] and bool(torch.isfinite(values).all())
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        ms = dt / steps * 1e3
+        stage_ms = {k: v / steps for k, v in stage_sum.items()}
+        flops, launches = conv_flops(pipe.sizes, shapes)
+        unet_s = stage_ms["unet"] * 1e-3
+        achieved = flops / unet_s / 1e12 if unet_s > 0 else 0.0
+        out = {
+            "metric": "input points/sec to signed implicit values",
+            "value": world * n / (dt / steps),
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "C3: %d-point scan-like synthetic cloud per GPU, radii = 24-NN, "
+                                   "5 grid levels, UNet5 default.yaml widths, seeded random weights" % n,
+                       "points_per_gpu": n,
+                       "voxels": [int(v) for v in pipe.sizes.num_voxels],
+                       "pairs": [int(v) for v in pipe.sizes.num_pairs],
+                       "agg_pairs": int(pipe.sizes.num_agg_pairs),
+                       "parallelism": "one scan per GPU, no collective on the data path",
+                       "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()}},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "k_sconv_mfma (53 launches/step, %.3f ms avg, %.1f algorithmic "
+                                   "GFLOP/step)" % (stage_ms["unet"] / launches, flops / 1e9)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,253 @@
+/*
+ * asr_hip.h -- C ABI of the MI355X (gfx950) implementation of the adaptive-surface-
+ * reconstruction hot path: oriented points -> signed/unsigned implicit values on the
+ * adaptive octree grid.
+ *
+ * Conventions
+ *   - every pointer documented as "dev" is a device (HBM) pointer, everything else is host
+ *   - all kernels are enqueued on the context's hipStream_t; functions that return a
+ *     data-dependent size synchronise that stream before returning
+ *   - int return value: 0 = ok, otherwise an ASR_HIP_E* code; asr_hip_last_error() gives text
+ *   - no ownership transfer: the caller allocates every output after the *_count call
+ *   - dtypes follow the reference tensors (cpp/lib/asr.cpp:179-312): indices int32, kernel
+ *     indices uint8, row splits int64, keys uint64, features float32
+ *
+ * The reference has no C ABI (the ASR_API_EXTERN_C macros of cpp/lib/asr_config.h:18-28 are
+ * unused); each entry point cites the reference interface it stands in for.
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_HIP_OK 0
+#define ASR_HIP_EINVAL 1   /* bad argument (shape / null / unsupported size)            */
+#define ASR_HIP_EHIP 2     /* a HIP runtime call failed                                 */
+#define ASR_HIP_ENODEV 3   /* no gfx950 device / extension not usable                   */
+#define ASR_HIP_ELOGIC 4   /* internal invariant violated (e.g. hash table overflow)    */
+#define ASR_HIP_EWEIGHT 5  /* weight table incomplete / wrong shape                     */
+
+#define ASR_MAX_LEVEL 21      /* cpp/lib/octreebase.h:42                                  */
+#define ASR_NUM_GRIDS 5       /* cpp/lib/asr.cpp:156, models/v0/net_definitions_torch.py:403 */
+
+typedef struct asr_hip_context asr_hip_context;
+
+/* Octree frame: per-level voxel sizes and the integer offset of the root cube.
+ * Replaces asr::Octree::Octree (cpp/lib/octree.cpp:20-42); plain host POD, passed by value
+ * into kernels. */
+typedef struct asr_octree_frame {
+    float voxel_size[ASR_MAX_LEVEL + 1];
+    float inv_voxel_size[ASR_MAX_LEVEL + 1];
+    int32_t offset[3];
+    float bb_min[3];
+    float bb_max[3];
+} asr_octree_frame;
+
+/* ---- context ---------------------------------------------------------------------- */
+/* stream: a hipStream_t (NULL = the null stream). The context owns a device arena that is
+ * reused across calls. */
+int asr_hip_context_create(asr_hip_context** ctx, void* stream);
+void asr_hip_context_destroy(asr_hip_context* ctx);
+void asr_hip_context_set_stream(asr_hip_context* ctx, void* stream);
+const char* asr_hip_last_error(const asr_hip_context* ctx);
+const char* asr_hip_version(void); /* asr::GetVersionStr, cpp/lib/asr.hpp:29 */
+/* sizeof() of an ABI struct by name ("asr_octree_frame", "asr_sparse_conv_args", "asr_weight",
+ * "asr_implicit_params", "asr_implicit_sizes"); 0 for unknown names. Lets FFI bindings verify
+ * their struct layouts. */
+size_t asr_hip_struct_size(const char* name);
+/* bytes currently reserved by the arena */
+size_t asr_hip_context_reserved_bytes(const asr_hip_context* ctx);
+
+/* ---- a3: octree frame (cpp/lib/octree.cpp:20-42), host only --------------------------- */
+int asr_octree_frame_init(asr_octree_frame* frame, const float bb_min[3], const float bb_max[3]);
+
+/* ---- a1/a2/a3: per-point location codes (cpp/lib/octree.h:42-68, octreebase.h:59-65) --- */
+/* keys_out[i] = key of point i at the level chosen from radius_scale*radii[i] (clamped to
+ * max_depth); 0 for points outside [bb_min,bb_max] or with an invalid coordinate. */
+int asr_hip_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame,
+                       const float* points_dev, const float* radii_dev, int64_t n,
+                       float radius_scale, int max_depth, uint64_t* keys_out_dev);
+
+/* ---- a4: octree construction (asr::CreateOctreeFromPoints, cpp/lib/octree.cpp:230-280;
+ *      pybind create_octree, cpp/pybind/module.cpp:144-161) ----------------------------- */
+/* Builds the balanced node set inside the context and reports its sizes. grow_steps of the
+ * reference is always 0 on the path (cpp/lib/asr.cpp:151-153) and is not supported. */
+int asr_hip_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame,
+                         const float* points_dev, const float* radii_dev, int64_t n,
+                         float radius_scale, int max_depth, int64_t* num_nodes,
+                         int64_t* num_leaves);
+/* copies the sorted node keys / sorted leaf keys (tree.leaves) of the last build */
+int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out_dev, uint64_t* leaves_out_dev);
+
+/* ---- a5: CreateLeafNeighborInformation (cpp/lib/grid.cpp:43-175) ---------------------- */
+/* keys: sorted unique voxel keys. count: fills row_splits[V+1] and returns the pair count;
+ * fill: writes the CSR entries in ascending kernel-slot order. */
+int asr_hip_grid_neighbors_count(asr_hip_context* ctx, const uint64_t* keys_dev, int64_t v,
+                                 int64_t* row_splits_out_dev, int64_t* num_pairs);
+int asr_hip_grid_neighbors_fill(asr_hip_context* ctx, const uint64_t* keys_dev, int64_t v,
+                                const int64_t* row_splits_dev, int32_t* index_out_dev,
+                                uint8_t* kernel_index_out_dev);
+
+/* ---- a6: CombineSiblings (cpp/lib/grid.cpp:177-243) ----------------------------------- */
+int asr_hip_grid_coarsen_count(asr_hip_context* ctx, const uint64_t* keys_dev, int64_t v,
+                               int64_t* v_out);
+int asr_hip_grid_coarsen_fill(asr_hip_context* ctx, const uint64_t* keys_dev, int64_t v,
+                              uint64_t* out_keys_dev, int64_t v_out, int32_t* up_index_out_dev,
+                              uint8_t* up_kernel_index_out_dev, int64_t* up_row_splits_out_dev);
+
+/* ---- a7: InitGridVoxelInfo (cpp/lib/grid.cpp:251-268) --------------------------------- */
+int asr_hip_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame,
+                       const uint64_t* keys_dev, int64_t v, float* centers_out_dev,
+                       float* sizes_out_dev);
+
+/* ---- a8: ComputeAggregationNeighborsAndScaleCompatibility (cpp/lib/nsearch.cpp:107-162) - */
+/* Members of row q: points with ((dx*dx+dy*dy)+dz*dz) < size[q]^2, ordered by (distance,
+ * index); dist = squared distance; compat = (min(size, 2 r)/max(size, 2 r))^2. */
+int asr_hip_multi_radius_search_count(asr_hip_context* ctx, const asr_octree_frame* frame,
+                                      const float* points_dev, int64_t n,
+                                      const float* centers_dev, const float* sizes_dev,
+                                      int64_t v, int64_t* row_splits_out_dev,
+                                      int64_t* num_pairs);
+int asr_hip_multi_radius_search_fill(asr_hip_context* ctx, const float* points_dev,
+                                     const float* radii_dev, int64_t n,
+                                     const float* centers_dev, const float* sizes_dev,
+                                     int64_t v, const int64_t* row_splits_dev,
+                                     int32_t* index_out_dev, float* dist_out_dev,
+                                     float* compat_out_dev);
+
+/* ---- a10: open3d::continuous_conv as used by CConvAggregationBlock
+ *      (models/v0/net_definitions_torch.py:53-70,107-116): kernel 4x4x4, align_corners,
+ *      linear, ball_to_cube_radial, per-output extent, per-neighbour importance ------------ */
+/* filters [4,4,4,cin,cout]; out = conv (+bias if bias_dev) (relu if relu). */
+int asr_hip_continuous_conv_f32(asr_hip_context* ctx, const float* filters_dev,
+                                const float* out_positions_dev, const float* extents_dev,
+                                const float* inp_positions_dev, const float* inp_features_dev,
+                                const int32_t* neighbors_index_dev,
+                                const float* neighbors_importance_dev,
+                                const int64_t* neighbors_row_splits_dev, int64_t num_out,
+                                int cin, int cout, int normalize, const float* bias_dev,
+                                int relu, float* out_dev);
+/* neighbors_importance = compat * clamp((1-d)^3,0,1) (models/common_torch.py:21-22,
+ * net_definitions_torch.py:107) */
+int asr_hip_aggregation_importance(asr_hip_context* ctx, const float* compat_dev,
+                                   const float* dist_dev, int64_t num_pairs, float* out_dev);
+
+/* ---- a12: SpecialSparseConv.forward / open3d::sparse_conv
+ *      (models/common_torch.py:95-148) ------------------------------------------------- */
+typedef struct asr_sparse_conv_args {
+    const float* filters;              /* dev [K, cin, cout] row-major                       */
+    const float* inp_features;         /* dev, row i at inp_features + i*inp_ld              */
+    int64_t inp_ld;                    /* row stride in floats (>= cin)                      */
+    const float* inp_importance;       /* dev [num_inp] or NULL: neighbour importance =
+                                          inp_importance[neighbors_index] (:124-126)         */
+    const float* neighbors_importance; /* dev [P] or NULL: per-pair importance as taken by
+                                          open3d::sparse_conv; wins over inp_importance      */
+    const int32_t* neighbors_index;    /* dev [P]                                            */
+    const uint8_t* neighbors_kernel_index; /* dev [P]                                        */
+    const int64_t* neighbors_row_splits;   /* dev [num_out+1]                                */
+    int64_t num_out;
+    int64_t num_inp;
+    int kernel_size;                   /* 55 or 9                                            */
+    int cin, cout;
+    int normalize;                     /* divide by the importance sum (if != 0)             */
+    const float* bias;                 /* dev [cout] or NULL (:144-145)                      */
+    int relu;                          /* (:146)                                             */
+    const float* residual;             /* dev or NULL: added after the activation
+                                          (net_definitions_torch.py:633)                     */
+    int64_t residual_ld;
+    float* out;                        /* dev, row i at out + i*out_ld                       */
+    int64_t out_ld;
+    float* out_importance;             /* dev [num_out] or NULL: sum of neighbour importance
+                                          (reduce_subarrays_sum, :127-128)                   */
+    int algo;                          /* 0 = auto, 1 = scalar reference kernel, 2 = MFMA    */
+} asr_sparse_conv_args;
+int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* args);
+
+/* ---- a11: open3d::invert_neighbors_list (net_definitions_torch.py:22-36,548-559) -------- */
+int asr_hip_invert_neighbors_list(asr_hip_context* ctx, int64_t num_points,
+                                  const int32_t* inp_index_dev,
+                                  const int64_t* inp_row_splits_dev, int64_t num_rows,
+                                  const uint8_t* inp_attributes_dev, int32_t* out_index_dev,
+                                  int64_t* out_row_splits_dev, uint8_t* out_attributes_dev);
+
+/* ---- open3d::reduce_subarrays_sum (models/common_torch.py:127) -------------------------- */
+/* gather_index may be NULL; otherwise out[i] = sum values[gather_index[p]] */
+int asr_hip_reduce_subarrays_sum(asr_hip_context* ctx, const float* values_dev,
+                                 const int32_t* gather_index_dev,
+                                 const int64_t* row_splits_dev, int64_t num_rows,
+                                 float* out_dev);
+
+/* ---- a14: UNet5.decode with zero shifts + sdf scale
+ *      (net_definitions_torch.py:655-666, cpp/lib/asr.cpp:324-336) ------------------------ */
+/* w1 [h1, 3+c], b1 [h1], w2 [h2,h1], b2 [h2], w3 [2,h2] (torch Linear layout);
+ * sizes may be NULL (no sdf scale). out [v,2]. */
+int asr_hip_decode_mlp(asr_hip_context* ctx, const float* code_dev, int64_t v, int c,
+                       const float* w1_dev, const float* b1_dev, int h1, const float* w2_dev,
+                       const float* b2_dev, int h2, const float* w3_dev,
+                       const float* sizes_dev, float* out_dev);
+
+/* ---- whole path: the section of asr::ReconstructSurface between the pre-filter and the
+ *      contouring (cpp/lib/asr.cpp:143-336) ---------------------------------------------- */
+typedef struct asr_weight {
+    const char* name;   /* state_dict name of UNet5, e.g. "sparseconv_encblock0.conv1a.kernel" */
+    const float* data;  /* dev                                                                */
+    int32_t ndim;
+    int64_t shape[5];
+} asr_weight;
+
+typedef struct asr_implicit_params {
+    float point_radius_scale; /* asr.hpp:55, default 1                                      */
+    int octree_max_depth;     /* asr.hpp:63, default 21                                     */
+    float bb_min[3];          /* bounding box handed to CreateOctreeFromPoints              */
+    float bb_max[3];
+    int scale_sdf;            /* 1: values[:,0] *= voxel_size (asr.cpp:334-336)             */
+} asr_implicit_params;
+
+/* sizes of the structures built by the last asr_hip_implicit_* call */
+typedef struct asr_implicit_sizes {
+    int64_t num_points;
+    int64_t num_nodes;
+    int64_t num_voxels[ASR_NUM_GRIDS];
+    int64_t num_pairs[ASR_NUM_GRIDS];
+    int64_t num_agg_pairs;
+} asr_implicit_sizes;
+
+/* geometry half: octree, 5 grids, aggregation neighbours. Results stay in the context. */
+int asr_hip_implicit_build(asr_hip_context* ctx, const float* points_dev,
+                           const float* radii_dev, int64_t n,
+                           const asr_implicit_params* params, asr_implicit_sizes* sizes);
+/* network half: aggregate + unet + decode on the structures of the last build.
+ * values_out_dev [num_voxels[0], 2]. */
+int asr_hip_implicit_network(asr_hip_context* ctx, const float* points_dev,
+                             const float* normals_dev, int64_t n, const asr_weight* weights,
+                             int num_weights, const asr_implicit_params* params,
+                             float* values_out_dev);
+/* both halves; values live in the context afterwards (asr_hip_implicit_get "values") */
+int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points_dev,
+                             const float* normals_dev, const float* radii_dev, int64_t n,
+                             const asr_weight* weights, int num_weights,
+                             const asr_implicit_params* params, asr_implicit_sizes* sizes);
+/* copies one of the arrays of the last build/forward into dst_dev (device to device).
+ * name: "values", "feats1", "importance", "code",
+ *       "voxel_keys<i>", "voxel_centers<i>", "voxel_sizes<i>", "neighbors_index<i>",
+ *       "neighbors_kernel_index<i>", "neighbors_row_splits<i>", "up_neighbors_index<i>",
+ *       "up_neighbors_kernel_index<i>", "up_neighbors_row_splits<i>",
+ *       "aggregation_neighbors_index", "aggregation_neighbors_dist",
+ *       "aggregation_row_splits", "aggregation_scale_compat", "nodes"
+ * (the input_dict keys of cpp/lib/asr.cpp:159-312). nbytes returns the byte size; dst_dev may
+ * be NULL to query only. */
+int asr_hip_implicit_get(asr_hip_context* ctx, const char* name, void* dst_dev,
+                         size_t* nbytes);
+/* per-stage wall times (ms, hip events) of the last forward: octree, grids, aggregation
+ * search, continuous conv, unet, decode. */
+int asr_hip_implicit_stage_ms(asr_hip_context* ctx, float out_ms[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */

@@ -811,6 +811,16 @@ void orc_sparse_conv(const float* filters, const float* feat, i64 feat_ld, const
                      int cout, int normalize, float* out, i64 out_ld) {
     sparse_conv(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
 }
+// nsearch.cpp:148-161 on caller supplied pairs (pinned by tests/golden/scale_compat.npz)
+void orc_scale_compat(const float* sizes, const float* radii, const int32_t* idx, const i64* rs,
+                      i64 v, float* out) {
+    for (i64 q = 0; q < v; ++q)
+        for (i64 p = rs[q]; p < rs[q + 1]; ++p) {
+            float a = sizes[q], b = 2 * radii[idx[p]];
+            float ratio = std::min(a, b) / std::max(a, b);
+            out[p] = ratio * ratio;
+        }
+}
 // A.3
 void orc_reduce_subarrays_sum(const float* values, const i64* rs, i64 v, float* out) {
     for (i64 q = 0; q < v; ++q) {

@@ -227,6 +227,16 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     return out
 
 
+def scale_compat(voxel_sizes, radii, neighbors_index, row_splits):
+    sizes = _f32(voxel_sizes)
+    radii = _f32(radii)
+    idx = np.ascontiguousarray(neighbors_index, np.int32)
+    rs = np.ascontiguousarray(row_splits, np.int64)
+    out = np.zeros(idx.shape[0], np.float32)
+    lib().orc_scale_compat(_p(sizes), _p(radii), _p(idx), _p(rs), i64(rs.shape[0] - 1), _p(out))
+    return out
+
+
 def reduce_subarrays_sum(values, row_splits):
     values = _f32(values)
     rs = np.ascontiguousarray(row_splits, np.int64)

@@ -1,0 +1,119 @@
+"""Generates tests/golden/unet_*.npz in the BUILD CONTAINER (needs /root/reference).
+
+The reference's own model code (models/v0/net_definitions_torch.py, models/common_torch.py) is
+imported UNCHANGED from /root/reference on top of this repo's `open3d.ml.torch` facade; its ops
+run on the CPU through oracle/cpu_backend.py.  The fixture therefore pins the model glue
+(importance threading, down3 re-use, skip wiring, torch Linear decoder) against the reference
+implementation; the op arithmetic itself is the oracle's restatement of Open3D v0.14.1
+("parity unpinned", see oracle/asr_oracle.cpp).
+
+Stored: inputs (points, normals, radii, bbox), geometry produced by the oracle, outputs of
+aggregate / unet / decode and per-block statistics.  Weights are NOT stored: they are
+regenerated bit-identically by asr_hip.synth.make_weights(channel_div, seed).
+
+usage: python tests/golden/make_unet_fixture.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(REPO, "adaptive-surface-reconstruction_amd"))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import open3d.ml.torch  # noqa: E402,F401  (this repo's facade: schemas + GPU kernels)
+import oracle.cpu_backend  # noqa: E402,F401  (adds CPU kernels backed by the oracle)
+from oracle import oracle as O  # noqa: E402
+from asr_hip import synth  # noqa: E402
+from models.v0.net_definitions_torch import UNet5  # noqa: E402  (reference, unchanged)
+
+
+def build_item(points, normals, radii, bb_min, bb_max):
+    """input_dict of cpp/lib/asr.cpp:159-312, geometry from the oracle"""
+    o = O.Oracle()
+    o.build_octree(points, radii, bb_min, bb_max)
+    grids = o.create_grids(5)
+    item = {"points": points, "feats": np.concatenate([normals, np.ones((len(points), 1), np.float32)], 1)}
+    for i, g in enumerate(grids):
+        for k, v in g.items():
+            item[k + str(i)] = v
+    idx, dist, rs, compat = o.radius_search(points, radii, grids[0]["voxel_centers"],
+                                            grids[0]["voxel_sizes"])
+    item["aggregation_neighbors_index"] = idx
+    item["aggregation_neighbors_dist"] = dist
+    item["aggregation_row_splits"] = rs
+    item["aggregation_scale_compat"] = compat
+    return item, o
+
+
+def run(tag, n, channel_div, seed):
+    pts, nrm = synth.scan_cloud(n, seed=seed, device="cpu")
+    points, normals = pts.numpy(), nrm.numpy()
+    radii = synth.knn_radii(points, 24)
+    bb_min, bb_max = synth.bounding_box(points, 0.1)
+    item, _ = build_item(points, normals, radii, bb_min, bb_max)
+    weights = synth.make_weights(channel_div, seed=seed)
+
+    model = UNet5(channel_div=channel_div, with_importance="all", normalized_channels=8,
+                  residual_skip_connection=True).eval()
+    sd = model.state_dict()
+    for name, w in weights.items():
+        if name.startswith("dense_decoder") and channel_div != 1:
+            continue  # reference hard-codes in_features=35: decode only exists for channel_div=1
+        assert tuple(sd[name].shape) == w.shape, (name, sd[name].shape, w.shape)
+        sd[name].copy_(torch.from_numpy(w))
+    missing = [k for k in sd if k not in weights and not k.endswith("offset")]
+    assert not missing, missing
+
+    stats = {}
+
+    def hook(name):
+        def f(mod, inp, out):
+            t = out[0] if isinstance(out, tuple) else out
+            stats[name] = np.array([float(t.double().mean()), float(t.double().abs().mean()),
+                                    float(t.double().pow(2).mean().sqrt())])
+        return f
+
+    for name, mod in model.named_children():
+        if name.startswith("sparseconv") or name.startswith("cconv"):
+            mod.register_forward_hook(hook(name))
+
+    data = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in item.items()
+            if not k.startswith("voxel_keys")}
+    with torch.no_grad():
+        feats1, importance = model.aggregate(data)
+        code = model.unet((feats1, importance), data)
+        out = {"feats1": feats1.numpy(), "importance": importance.numpy(), "code": code.numpy()}
+        if channel_div == 1:
+            values = model.decode(torch.zeros(code.shape[0], 3), code).contiguous().numpy().copy()
+            values[:, 0] *= item["voxel_sizes0"]  # cpp/lib/asr.cpp:334-336
+            out["values"] = values
+    v0 = len(item["voxel_sizes0"])
+    print(tag, "points", n, "V", [len(item["voxel_sizes%d" % i]) for i in range(5)], "P_agg",
+          len(item["aggregation_neighbors_index"]))
+    for k, v in stats.items():
+        print("   %-24s mean %+.4f  |x| %.4f  rms %.4f" % (k, v[0], v[1], v[2]))
+    if "values" in out:
+        print("   values mean", out["values"].mean(0), "std", out["values"].std(0))
+    assert len(item["aggregation_neighbors_index"]) >= v0
+    save = {"points": points, "normals": normals, "radii": radii, "bb_min": bb_min,
+            "bb_max": bb_max, "channel_div": np.int32(channel_div), "seed": np.int32(seed)}
+    for k, v in item.items():
+        if k not in ("points", "feats"):
+            save["geom_" + k] = v
+    for k, v in out.items():
+        save["out_" + k] = v
+    for k, v in stats.items():
+        save["stat_" + k] = v
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "unet_%s.npz" % tag)
+    np.savez_compressed(path, **save)
+    print("   wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    run("d4_3k", 3000, 4, 1)
+    run("d1_2k", 2000, 1, 2)

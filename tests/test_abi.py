@@ -1,0 +1,86 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/asr_hip.h declares;
+host-only entry points work (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from asr_hip import _lib, synth
+from oracle import oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "asr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(asr_(?:hip_)?[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for s in declared:
+        assert hasattr(lib, s), "missing export %s" % s
+    assert sorted(_lib.EXPORTS) == declared
+    assert lib.asr_hip_version().decode().startswith("0.2.0")
+
+
+def test_struct_layouts_match_header_sizes():
+    # sizes implied by the header (LP64): a mismatch would corrupt every call
+    assert ctypes.sizeof(_lib.OctreeFrame) == 4 * (22 + 22 + 3 + 3 + 3)
+    assert ctypes.sizeof(_lib.Weight) == 8 + 8 + 8 + 5 * 8
+    assert ctypes.sizeof(_lib.ImplicitSizes) == 8 * (2 + 5 + 5 + 1)
+    assert ctypes.sizeof(_lib.ImplicitParams) == 4 * (1 + 1 + 3 + 3 + 1)
+    assert ctypes.sizeof(_lib.SparseConvArgs) == 160
+    lib = _lib.load()
+    assert lib.asr_hip_struct_size(b"asr_sparse_conv_args") == 160
+    assert lib.asr_hip_struct_size(b"nope") == 0
+
+
+def test_host_frame_init_matches_oracle():
+    """asr_octree_frame_init is host code (cpp/lib/octree.cpp:20-42); compare with the oracle"""
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        lo = rng.uniform(-3, 0, size=3).astype(np.float32)
+        hi = (lo + rng.uniform(0.1, 5, size=3)).astype(np.float32)
+        f = _lib.frame_init(lo, hi)
+        o = O.Oracle()
+        o.build_octree(np.zeros((0, 3), np.float32), np.zeros(0, np.float32), lo, hi)
+        vs, ivs, off = o.frame()
+        assert np.array_equal(np.array(f.voxel_size[:], np.float32), vs)
+        assert np.array_equal(np.array(f.inv_voxel_size[:], np.float32), ivs)
+        assert list(f.offset) == list(off)
+
+
+def test_degenerate_bbox_is_rejected():
+    import pytest
+    with pytest.raises(_lib.AsrHipError):
+        _lib.frame_init([0, 0, 0], [0, 0, 0])
+
+
+def test_param_table_matches_survey():
+    """92 200 000 parameters, names of SURVEY A.6"""
+    shapes = synth.unet5_param_shapes(1)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 92200000
+    assert shapes["sparseconv_encblock0.conv1a.kernel"] == (55, 32, 56)
+    assert shapes["sparseconv_decblock1.conv1.kernel"] == (55, 384, 128)
+    assert shapes["dense_decoder3.weight"] == (2, 32)
+    assert "sparseconv_down4.conv1a.kernel" not in shapes
+    w = synth.make_weights(4, seed=5)
+    w2 = synth.make_weights(4, seed=5)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+def test_no_cpu_fallback_in_product():
+    """the product ops refuse CPU tensors instead of computing something else"""
+    import pytest
+    import torch
+    from asr_hip import ops
+    with pytest.raises(_lib.AsrHipError):
+        ops._dev(torch.zeros(3), torch.float32)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.AsrHipError):
+            _lib.Context()

@@ -1,0 +1,188 @@
+"""GPU parity, integer / geometry rows (a1-a8, a11): HIP path through the C ABI vs the oracle,
+bit exact (indices, keys, centres, squared distances) -- compat within 1e-6."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from asr_hip import _lib, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _u64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _cloud(kind, n, seed):
+    if kind == "sphere":
+        pts, nrm = synth.sphere_cloud(n, seed)
+    else:
+        p, q = synth.scan_cloud(n, seed=seed, device="cpu", density_variance=10.0 if kind == "mixed" else 1.0)
+        pts, nrm = p.numpy(), q.numpy()
+    rad = synth.knn_radii(pts, min(24, n))
+    bb = synth.bounding_box(pts, 0.1)
+    return pts, nrm, rad, bb
+
+
+CASES = [("sphere", 50000, 0), ("scan", 20000, 1), ("mixed", 30000, 2), ("scan", 300, 3)]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=lambda c: "%s-%d" % (c[0], c[1]))
+def case(request, gpu):
+    from asr_hip import ops
+    kind, n, seed = request.param
+    pts, nrm, rad, bb = _cloud(kind, n, seed)
+    o = O.Oracle()
+    o.build_octree(pts, rad, *bb)
+    grids = o.create_grids(5)
+    frame = _lib.frame_init(*bb)
+    d = dict(pts=pts, rad=rad, bb=bb, o=o, grids=grids, frame=frame, ops=ops,
+             tpts=torch.from_numpy(pts).to(gpu), trad=torch.from_numpy(rad).to(gpu))
+    return d
+
+
+def test_point_keys_bit_exact(case):
+    keys = case["ops"].point_keys(case["frame"], case["tpts"], case["trad"])
+    assert np.array_equal(_u64(keys), case["o"].point_keys(case["pts"], case["rad"]))
+    k5 = case["ops"].point_keys(case["frame"], case["tpts"], case["trad"], 1.5, 5)
+    assert np.array_equal(_u64(k5), case["o"].point_keys(case["pts"], case["rad"], 1.5, 5))
+
+
+def test_octree_nodes_and_leaves_bit_exact(case):
+    nodes, leaves = case["ops"].octree_build(case["frame"], case["tpts"], case["trad"])
+    assert np.array_equal(_u64(nodes), case["o"].nodes)
+    assert np.array_equal(_u64(leaves), case["o"].leaves)
+
+
+def test_grid_hierarchy_bit_exact(case, gpu):
+    ops, grids = case["ops"], case["grids"]
+    keys = torch.from_numpy(grids[0]["voxel_keys"].view(np.int64)).to(gpu)
+    for i, g in enumerate(grids):
+        assert np.array_equal(_u64(keys), g["voxel_keys"])
+        centers, sizes = ops.voxel_info(case["frame"], keys)
+        assert np.array_equal(centers.cpu().numpy(), g["voxel_centers"])
+        assert np.array_equal(sizes.cpu().numpy(), g["voxel_sizes"])
+        idx, kidx, rs = ops.grid_neighbors(keys)
+        assert np.array_equal(rs.cpu().numpy(), g["neighbors_row_splits"])
+        assert np.array_equal(idx.cpu().numpy(), g["neighbors_index"])
+        assert np.array_equal(kidx.cpu().numpy(), g["neighbors_kernel_index"])
+        if i < 4:
+            nxt, up_idx, up_kidx, up_rs = ops.grid_coarsen(keys)
+            assert np.array_equal(up_idx.cpu().numpy(), g["up_neighbors_index"])
+            assert np.array_equal(up_kidx.cpu().numpy(), g["up_neighbors_kernel_index"])
+            assert np.array_equal(up_rs.cpu().numpy(), g["up_neighbors_row_splits"])
+            n_coarse = len(grids[i + 1]["voxel_keys"])
+            d_idx, d_rs, d_attr = ops.invert_neighbors_list(n_coarse, up_idx, up_rs, up_kidx)
+            o_idx, o_rs, o_attr = O.invert_neighbors_list(n_coarse, g["up_neighbors_index"],
+                                                          g["up_neighbors_row_splits"],
+                                                          g["up_neighbors_kernel_index"])
+            assert np.array_equal(d_idx.cpu().numpy(), o_idx)
+            assert np.array_equal(d_rs.cpu().numpy(), o_rs)
+            assert np.array_equal(d_attr.cpu().numpy(), o_attr)
+            keys = nxt
+
+
+def test_multi_radius_search(case, gpu):
+    g = case["grids"][0]
+    idx, dist, rs, compat = case["ops"].multi_radius_search(
+        case["frame"], case["tpts"], case["trad"], torch.from_numpy(g["voxel_centers"]).to(gpu),
+        torch.from_numpy(g["voxel_sizes"]).to(gpu))
+    o_idx, o_dist, o_rs, o_compat = case["o"].radius_search(case["pts"], case["rad"],
+                                                            g["voxel_centers"], g["voxel_sizes"])
+    assert np.array_equal(rs.cpu().numpy(), o_rs)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)          # membership AND (distance, index) order
+    assert np.array_equal(dist.cpu().numpy(), o_dist)        # squared distances, bit exact
+    assert np.abs(compat.cpu().numpy() - o_compat).max() <= 1e-6
+
+
+def test_reference_module_mirror(case):
+    """adaptivesurfacereconstruction.create_octree / create_grids_from_octree
+    (cpp/pybind/module.cpp:372-441) return what the oracle builds"""
+    import adaptivesurfacereconstruction as asr
+    tree = asr.create_octree(case["pts"], case["rad"], case["bb"][0], case["bb"][1], radius_scale=1,
+                             grow_steps=0, max_depth=21)
+    grids = asr.create_grids_from_octree(tree, 5, voxel_info_all_levels=True)
+    assert len(grids) == 5
+    for g, og in zip(grids, case["grids"]):
+        assert set(g) == set(og)  # empty arrays omitted like the reference (up_* on grid 4)
+        for k in og:
+            assert g[k].dtype == og[k].dtype and np.array_equal(g[k], og[k]), k
+    g2 = asr.create_grids_from_octree(tree, 2)
+    assert "voxel_centers" in g2[0] and "voxel_centers" not in g2[1]
+    with pytest.raises(ValueError):
+        asr.create_octree(case["pts"][:, :2], case["rad"], case["bb"][0], case["bb"][1])
+    with pytest.raises(NotImplementedError):
+        asr.create_dual_vertex_indices(tree)
+
+
+# ---- edge cases ---------------------------------------------------------------------------------
+def test_edge_single_point_and_duplicates(gpu):
+    from asr_hip import ops
+    for pts, rad in (
+            (np.array([[0.3, 0.2, 0.1]], np.float32), np.array([0.05], np.float32)),
+            (np.tile(np.array([[0.3, 0.2, 0.1]], np.float32), (100, 1)), np.full(100, 0.01, np.float32)),
+            (np.array([[0.1, 0.1, 0.1], [0.9, 0.9, 0.9]], np.float32), np.array([5.0, 1e-7], np.float32))):
+        bb = (np.zeros(3, np.float32), np.ones(3, np.float32))
+        o = O.Oracle()
+        o.build_octree(pts, rad, *bb)
+        frame = _lib.frame_init(*bb)
+        nodes, leaves = ops.octree_build(frame, torch.from_numpy(pts).to(gpu), torch.from_numpy(rad).to(gpu))
+        assert np.array_equal(_u64(nodes), o.nodes) and np.array_equal(_u64(leaves), o.leaves)
+        grids = o.create_grids(5)
+        idx, kidx, rs = ops.grid_neighbors(leaves)
+        assert np.array_equal(idx.cpu().numpy(), grids[0]["neighbors_index"])
+
+
+def test_edge_points_outside_bbox_and_on_max_face(gpu):
+    """points outside the box are skipped (octree.cpp:248-251); a point on the max face maps to
+    INVALID_KEY, which the reference inserts (UB) and this build skips"""
+    from asr_hip import ops
+    pts, nrm, rad, bb = _cloud("scan", 5000, 7)
+    bb_small = (bb[0] + np.float32(0.8), bb[1] - np.float32(0.6))
+    pts2 = np.concatenate([pts, bb_small[1][None, :]]).astype(np.float32)
+    rad2 = np.concatenate([rad, [0.01]]).astype(np.float32)
+    o = O.Oracle()
+    o.build_octree(pts2, rad2, *bb_small)
+    frame = _lib.frame_init(*bb_small)
+    nodes, leaves = ops.octree_build(frame, torch.from_numpy(pts2).to(gpu), torch.from_numpy(rad2).to(gpu))
+    assert np.array_equal(_u64(nodes), o.nodes) and np.array_equal(_u64(leaves), o.leaves)
+    assert 0 not in set(_u64(nodes).tolist())
+    # the radius search still sees every point, also those outside the root cube
+    g = o.create_grids(1)[0]
+    a = ops.multi_radius_search(frame, torch.from_numpy(pts2).to(gpu), torch.from_numpy(rad2).to(gpu),
+                                torch.from_numpy(g["voxel_centers"]).to(gpu),
+                                torch.from_numpy(g["voxel_sizes"]).to(gpu))
+    b = o.radius_search(pts2, rad2, g["voxel_centers"], g["voxel_sizes"], brute=True)
+    assert np.array_equal(a[0].cpu().numpy(), b[0]) and np.array_equal(a[2].cpu().numpy(), b[2])
+
+
+def test_edge_max_depth_and_empty(gpu):
+    from asr_hip import ops
+    pts, nrm, rad, bb = _cloud("scan", 4000, 9)
+    frame = _lib.frame_init(*bb)
+    for depth in (0, 1, 3, 6):
+        o = O.Oracle()
+        o.build_octree(pts, rad, *bb, max_depth=depth)
+        nodes, leaves = ops.octree_build(frame, torch.from_numpy(pts).to(gpu), torch.from_numpy(rad).to(gpu),
+                                         1.0, depth)
+        assert np.array_equal(_u64(leaves), o.leaves), depth
+    # no point inside the box -> empty tree
+    far = (pts + 100).astype(np.float32)
+    nodes, leaves = ops.octree_build(frame, torch.from_numpy(far).to(gpu), torch.from_numpy(rad).to(gpu))
+    assert nodes.numel() == 0 and leaves.numel() == 0
+    # empty key list
+    idx, kidx, rs = ops.grid_neighbors(torch.zeros(0, dtype=torch.int64, device=gpu))
+    assert idx.numel() == 0 and rs.cpu().tolist() == [0]
+
+
+def test_error_behaviour(gpu):
+    from asr_hip import ops
+    with pytest.raises(_lib.AsrHipError):
+        ops.point_keys(_lib.frame_init([0, 0, 0], [1, 1, 1]), torch.zeros(4, 3), torch.zeros(4))  # CPU tensors
+    ctx = ops.context()
+    rc = ctx.lib.asr_hip_octree_build(ctx._h, None, None, None, ctypes.c_int64(3), ctypes.c_float(1), 21,
+                                      None, None)
+    assert rc == 1 and b"null" in ctx.lib.asr_hip_last_error(ctx._h)

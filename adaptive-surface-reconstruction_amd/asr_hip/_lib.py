@@ -52,6 +52,7 @@ class SparseConvArgs(ctypes.Structure):
         ("out_ld", ctypes.c_int64),
         ("out_importance", ctypes.c_void_p),
         ("algo", ctypes.c_int),
+        ("row_perm", ctypes.c_void_p),
     ]
 
 
@@ -93,7 +94,7 @@ EXPORTS = [
     "asr_hip_grid_neighbors_count", "asr_hip_grid_neighbors_fill", "asr_hip_grid_coarsen_count",
     "asr_hip_grid_coarsen_fill", "asr_hip_voxel_info", "asr_hip_multi_radius_search_count",
     "asr_hip_multi_radius_search_fill", "asr_hip_continuous_conv_f32",
-    "asr_hip_aggregation_importance", "asr_hip_sparse_conv_f32", "asr_hip_invert_neighbors_list",
+    "asr_hip_aggregation_importance", "asr_hip_sparse_conv_f32", "asr_hip_invert_neighbors_list", "asr_hip_row_groups",
     "asr_hip_reduce_subarrays_sum", "asr_hip_decode_mlp", "asr_hip_implicit_build",
     "asr_hip_implicit_network", "asr_hip_implicit_forward", "asr_hip_implicit_get",
     "asr_hip_implicit_stage_ms",

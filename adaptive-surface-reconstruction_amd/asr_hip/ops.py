@@ -168,7 +168,7 @@ def continuous_conv(filters, out_positions, extents, inp_positions, inp_features
 def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
                 neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False,
                 residual=None, out=None, return_importance=False, algo=0,
-                neighbors_importance=None):
+                neighbors_importance=None, row_perm=None):
     """SpecialSparseConv.forward (models/common_torch.py:95-148) in one launch."""
     filters = _dev(filters, torch.float32)
     K, cin, cout = filters.shape
@@ -209,10 +209,22 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     a.out_ld = out.stride(0)
     a.out_importance = oimp.data_ptr() if oimp is not None else None
     a.algo = int(algo)
+    perm = _dev(row_perm, torch.int32) if row_perm is not None else None
+    a.row_perm = perm.data_ptr() if perm is not None else None
     context().call("asr_hip_sparse_conv_f32", ctypes.byref(a))
     if return_importance:
         return out, oimp
     return out
+
+
+def row_groups(neighbors_kernel_index, neighbors_row_splits, segment_rows=0):
+    """MFMA tiling order of a CSR's rows (asr_hip_row_groups)"""
+    nk = _dev(neighbors_kernel_index, torch.uint8)
+    rs = _dev(neighbors_row_splits, torch.int64)
+    v = rs.shape[0] - 1
+    perm = torch.empty(v, dtype=torch.int32, device=rs.device)
+    context().call("asr_hip_row_groups", ptr(nk), ptr(rs), i64(v), i64(segment_rows), ptr(perm))
+    return perm
 
 
 def invert_neighbors_list(num_points, inp_neighbors_index, inp_neighbors_row_splits,

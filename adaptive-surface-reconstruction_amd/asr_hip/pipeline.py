@@ -129,7 +129,7 @@ class ImplicitPipeline:
 
     def get(self, name):
         """copy of one named array of the last forward (see include/asr_hip.h)"""
-        base = name.rstrip("0123456789")
+        base = name if name in _ARRAY_TYPES else name.rstrip("0123456789")
         if base not in _ARRAY_TYPES:
             raise KeyError(name)
         dtype, cols = _ARRAY_TYPES[base]

@@ -7,6 +7,7 @@
 
 #include "asr_common.h"
 
+#define ASR_ROW_GROUP_SEGMENT 4096
 #define CTX_GUARD(ctx)                      \
     if (!(ctx)) return ASR_HIP_EINVAL;      \
     (ctx)->err.clear();
@@ -43,6 +44,7 @@ void asr_hip_context_destroy(asr_hip_context* ctx) {
     ctx->persist.release();
     ctx->scratch.release();
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->ev_ok)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
@@ -205,6 +207,14 @@ int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* a)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: null argument");
     return asr_conv_sparse(ctx, a);
 }
+int asr_hip_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const int64_t* rs, int64_t v,
+                       int64_t seg, int32_t* perm_out) {
+    CTX_GUARD(ctx);
+    if (v < 0 || (v > 0 && (!kidx || !rs || !perm_out)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "row_groups: null argument");
+    ctx->scratch.reset();
+    return asr_geom_row_groups(ctx, kidx, rs, v, seg > 0 ? seg : ASR_ROW_GROUP_SEGMENT, perm_out);
+}
 int asr_hip_invert_neighbors_list(asr_hip_context* ctx, int64_t num_points, const int32_t* idx,
                                   const int64_t* rs, int64_t num_rows, const uint8_t* attr,
                                   int32_t* out_idx, int64_t* out_rs, uint8_t* out_attr) {
@@ -289,8 +299,9 @@ struct Net {
 
     // one SpecialSparseConv (+bias, ReLU): models/common_torch.py:95-148
     int conv(const std::string& prefix, int K, Feat in, const int32_t* nidx, const uint8_t* nk,
-             const i64* rs, i64 num_out, i64 num_inp, const float* imp, int normalize, float* out,
-             i64 out_ld, int expect_cout, float* out_imp, const float* residual, i64 residual_ld) {
+             const i64* rs, const int32_t* perm, i64 num_out, i64 num_inp, const float* imp,
+             int normalize, float* out, i64 out_ld, int expect_cout, float* out_imp,
+             const float* residual, i64 residual_ld) {
         const asr_weight *k, *b;
         ASR_TRY(get(prefix + ".kernel", 3, &k));
         ASR_TRY(get(prefix + ".bias", 1, &b));
@@ -321,6 +332,7 @@ struct Net {
         a.out = out;
         a.out_ld = out_ld;
         a.out_importance = out_imp;
+        a.row_perm = perm;
         return asr_conv_sparse(ctx, &a);
     }
     int cout_of(const std::string& prefix, int* c) {
@@ -346,21 +358,21 @@ struct Net {
             if (ca + cb != C) ASR_FAIL(c, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != block width", name.c_str());
             float* oi = arena_alloc<float>(c->scratch, g.v);
             if (!oi) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
-            ASR_TRY(conv(name + ".conv1a", 55, in, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t1, C,
+            ASR_TRY(conv(name + ".conv1a", 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C,
                          ca, nullptr, nullptr, 0));
-            ASR_TRY(conv(name + ".conv1b", 55, in, g.nidx, g.nkidx, g.nrs, g.v, g.v, imp, 1, t1 + ca,
+            ASR_TRY(conv(name + ".conv1b", 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, imp, 1, t1 + ca,
                          C, cb, oi, nullptr, 0));
             *out_imp = oi;
         } else {
-            ASR_TRY(conv(name + ".conv1", 55, in, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t1, C,
+            ASR_TRY(conv(name + ".conv1", 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C,
                          C, nullptr, nullptr, 0));
         }
         Feat f1{t1, C, C}, f2{t2, C, C};
-        ASR_TRY(conv(name + ".conv2", 55, f1, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t2, C, C,
+        ASR_TRY(conv(name + ".conv2", 55, f1, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t2, C, C,
                      nullptr, nullptr, 0));
-        ASR_TRY(conv(name + ".conv3", 55, f2, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, t1, C, C,
+        ASR_TRY(conv(name + ".conv3", 55, f2, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C, C,
                      nullptr, nullptr, 0));
-        ASR_TRY(conv(name + ".conv4", 55, f1, g.nidx, g.nkidx, g.nrs, g.v, g.v, nullptr, 0, out.p,
+        ASR_TRY(conv(name + ".conv4", 55, f1, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, out.p,
                      out.ld, C, nullptr, nullptr, 0));
         return ASR_HIP_OK;
     }
@@ -373,9 +385,9 @@ struct Net {
         if (ca + cb != out.c) ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != width", name.c_str());
         float* oi = arena_alloc<float>(ctx->scratch, coarse.v);
         if (!oi) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(conv(name + ".conv1a", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, coarse.v,
+        ASR_TRY(conv(name + ".conv1a", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, fine.perm_down, coarse.v,
                      fine.v, nullptr, 0, out.p, out.ld, ca, nullptr, nullptr, 0));
-        ASR_TRY(conv(name + ".conv1b", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, coarse.v,
+        ASR_TRY(conv(name + ".conv1b", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, fine.perm_down, coarse.v,
                      fine.v, imp, 1, out.p + ca, out.ld, cb, oi, nullptr, 0));
         *out_imp = oi;
         return ASR_HIP_OK;
@@ -383,7 +395,7 @@ struct Net {
     // up transition (conv1): rows = fine voxels, inputs from the coarse grid
     int up(const std::string& name, Feat in, const GridDev& fine, const GridDev& coarse, Feat out,
            const float* residual, i64 residual_ld) {
-        return conv(name + ".conv1", 9, in, fine.up_idx, fine.up_kidx, fine.up_rs, fine.v, coarse.v,
+        return conv(name + ".conv1", 9, in, fine.up_idx, fine.up_kidx, fine.up_rs, fine.perm_up, fine.v, coarse.v,
                     nullptr, 0, out.p, out.ld, out.c, nullptr, residual, residual_ld);
     }
 };
@@ -434,6 +446,13 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
                 ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
             ASR_TRY(asr_geom_invert(ctx, g.v, prev.up_idx, prev.up_rs, prev.v, prev.up_kidx,
                                     prev.down_idx, prev.down_rs, prev.down_kidx));
+            prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
+            prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
+            if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_TRY(asr_geom_row_groups(ctx, prev.up_kidx, prev.up_rs, prev.v, ASR_ROW_GROUP_SEGMENT,
+                                        prev.perm_up));
+            ASR_TRY(asr_geom_row_groups(ctx, prev.down_kidx, prev.down_rs, g.v, ASR_ROW_GROUP_SEGMENT,
+                                        prev.perm_down));
             std::string s = std::to_string(i - 1);
             name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
             name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
@@ -448,6 +467,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
         ASR_TRY(asr_geom_neighbors_build(ctx, ctx->persist, g.keys, g.v, &g.nrs, &g.nidx, &g.nkidx,
                                          &g.p));
+        g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
+        if (!g.perm_nb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_row_groups(ctx, g.nkidx, g.nrs, g.v, ASR_ROW_GROUP_SEGMENT, g.perm_nb));
         ctx->sizes.num_voxels[i] = g.v;
         ctx->sizes.num_pairs[i] = g.p;
         std::string s = std::to_string(i);

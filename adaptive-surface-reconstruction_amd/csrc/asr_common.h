@@ -74,6 +74,10 @@ struct GridDev {
     int32_t* down_idx = nullptr;
     uint8_t* down_kidx = nullptr;
     i64* down_rs = nullptr;
+    // MFMA tiling orders (asr_geom_row_groups) of the three CSRs whose rows live on this grid
+    int32_t* perm_nb = nullptr;    // rows = this grid (55-slot lists)
+    int32_t* perm_up = nullptr;    // rows = this grid (up lists, inputs from the coarser grid)
+    int32_t* perm_down = nullptr;  // rows = next coarser grid (inverted up lists)
 };
 
 struct asr_hip_context {
@@ -101,6 +105,7 @@ struct asr_hip_context {
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
     int* d_flags = nullptr;  // small device scratch for counters (persistent)
+    float* d_zeros = nullptr;  // 4 KB of zeros: target of masked-out loads
     void* radius_state = nullptr;  // RadiusState of asr_geom.hip (between _count and _fill)
     std::map<std::string, std::pair<const void*, size_t>> named;  // asr_hip_implicit_get
 };
@@ -128,6 +133,15 @@ struct asr_hip_context {
         int _r = (expr);            \
         if (_r != ASR_HIP_OK) return _r; \
     } while (0)
+
+static inline int asr_ctx_zeros(asr_hip_context* ctx, const float** out) {
+    if (!ctx->d_zeros) {
+        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_zeros, 4096));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_zeros, 0, 4096, ctx->stream));
+    }
+    *out = ctx->d_zeros;
+    return ASR_HIP_OK;
+}
 
 template <class T>
 static inline T* arena_alloc(Arena& a, size_t count) {
@@ -199,6 +213,8 @@ int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const 
                             int32_t* idx, uint8_t* kidx);
 int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* keys, i64 v,
                              i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs);
+int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
+                        int32_t* perm_out);
 int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_out);
 int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out_keys, i64 v_out,
                           int32_t* up_idx, uint8_t* up_kidx, i64* up_rs);

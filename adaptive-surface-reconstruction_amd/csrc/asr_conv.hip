@@ -162,37 +162,51 @@ __global__ void k_sconv_scalar(asr_sparse_conv_args a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// a12 MFMA kernel.
-// Block = 256 threads = 4 waves; tile = 64 output rows (16 per wave) x (NT*16) output columns
-// (blockIdx.y selects the column chunk).  A dense slot table nbr[64][55] is built in LDS from
-// the CSR rows; every wave then loops over the kernel slots that occur in ITS 16 rows only
-// (wave-uniform skip of absent slots: ~8 of 55 slots are occupied per voxel).
-// For a slot k and a 16-wide cin chunk, lane (r = l&15, g = l>>4) gathers the float4
-// f[idx(r,k)][16j+4g .. +3]; MFMA step t (0..3) contracts cin index 16j+4g+t, i.e. the four
-// k-lanes of v_mfma_f32_16x16x4_f32 are mapped to a permuted cin order so the gather is 16 B
-// per lane.  B operand lanes read W[k][16j+4g+t][n0 + (l&15)] (64 B runs) from L1/L2.
-// Epilogue: normalise, bias, ReLU, residual, strided store (zero-copy concat).
+// a12 MFMA kernel (v2).
+// Block = 256 threads = 4 waves; tile = 64 output rows (16 per wave) x NCOL = NT*16 output
+// columns (blockIdx.y selects the column chunk).  Rows come from an optional permutation that
+// groups rows with equal kernel-slot signatures (asr_geom_row_groups): ~8 of 55 slots are
+// occupied per voxel and without regrouping a 16-row MFMA tile touches ~23 distinct slots.
+// A dense slot table nbr[64][55] is built in LDS from the CSR rows.  The block walks the slots
+// present in ANY of its rows; per slot and KC-deep cin chunk the W[k] panel [KC x NCOL] is staged
+// through LDS (double buffered, global loads issued before the MFMAs of the previous panel,
+// LDS write after them), shared by the four waves; a wave whose 16 rows lack the slot skips the
+// MFMAs.  Lane (r = l&15, g = l>>4) gathers the float4 f[idx(r,k)][c0+16j+4g .. +3]; MFMA step t
+// contracts cin index c0+16j+4g+t (the four k-lanes of v_mfma_f32_16x16x4_f32 are mapped to a
+// permuted cin order so the gather is 16 B per lane).  No branch sits between a load and its
+// consumer (a guarded load costs a vmcnt(0) per MFMA).  Epilogue: normalise, bias, ReLU, residual,
+// strided store (zero-copy concat).
 // ------------------------------------------------------------------------------------------
 constexpr int TM = 64;      // rows per block
 constexpr int NBR_LD = 57;  // odd stride: conflict-free column reads
 
-template <int NT, bool IMP>
-__global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a) {
+template <int NT, int KC, bool IMP>
+__global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a,
+                                                    const float* __restrict__ zeros) {
+    constexpr int NCOL = NT * 16;
+    constexpr int BLD = NCOL + 4;            // (4g+t)*BLD mod 32 separates the two 16-lane halves
+    constexpr int NJ = KC / 16;              // float4 gathers per lane per panel
+    constexpr int SV = KC * NCOL / 4 / 256;  // float4 staged per thread per panel
+    static_assert(KC * NCOL / 4 % 256 == 0, "panel must split evenly over the block");
     __shared__ int s_nbr[TM * NBR_LD];
     __shared__ float s_w[IMP ? TM * NBR_LD : 1];
     __shared__ float s_norm[TM];
+    __shared__ int s_row[TM];
     __shared__ unsigned long long s_mask[TM];
+    __shared__ __attribute__((aligned(16))) float s_B[2][KC * BLD];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const i64 row0 = (i64)blockIdx.x * TM;
-    const int n0 = blockIdx.y * (NT * 16);
+    const int n0 = blockIdx.y * NCOL;
     const int K = a.kernel_size;
+    const int cin = a.cin, cout = a.cout;
 
     for (int i = tid; i < TM * NBR_LD; i += 256) s_nbr[i] = -1;
     __syncthreads();
     if (tid < TM) {
         i64 q = row0 + tid;
+        if (q < a.num_out && a.row_perm) q = a.row_perm[q];
         unsigned long long m = 0;
         float norm = 0.f;
         if (q < a.num_out) {
@@ -209,7 +223,10 @@ __global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a) {
                 }
                 norm += w;
             }
+        } else {
+            q = -1;
         }
+        s_row[tid] = (int)q;
         s_mask[tid] = m;
         s_norm[tid] = norm;
     }
@@ -217,58 +234,133 @@ __global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a) {
 
     const int r = lane & 15, g = lane >> 4;
     const int lrow = wave * 16 + r;
-    unsigned long long wmask = s_mask[wave * 16 + (lane & 15)];
+    // slot masks: this wave's 16 rows and the whole block (both wave uniform)
+    unsigned long long wmask = s_mask[lrow];
+    unsigned long long bmask = s_mask[lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bmask |= __shfl_xor(bmask, o, 64);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) wmask |= __shfl_xor(wmask, o, 64);
     wmask = __builtin_amdgcn_readfirstlane((unsigned)(wmask)) |
             ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(wmask >> 32)) << 32);
+    bmask = __builtin_amdgcn_readfirstlane((unsigned)(bmask)) |
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(bmask >> 32)) << 32);
 
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
 
-    const int cin = a.cin, cout = a.cout;
     const int ncol = lane & 15;
-    while (wmask) {
-        const int k = __builtin_ctzll(wmask);
-        wmask &= wmask - 1;
-        if (k >= K) break;
+    const int npanel = (cin + KC - 1) / KC;
+    // staging geometry: thread -> (panel row, float4 column) for SV float4 each
+
+    // ---- software pipeline over (slot, panel) steps ------------------------------------------
+    unsigned long long todo = bmask;
+    int k_cur = todo ? __builtin_ctzll(todo) : -1;
+    int p_cur = 0;
+    float4 stage[SV];
+    float4 a_nxt[NJ];
+
+    auto load_panel = [&](int k, int pnl) {
+        const float* Wk = a.filters + (i64)k * cin * cout;
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            int e = tid + s * 256;            // float4 index inside the panel
+            int pr = e / (NCOL / 4);          // panel row
+            int pc = (e % (NCOL / 4)) * 4;    // column
+            int ci = pnl * KC + pr, col = n0 + pc;
+            // cout % 4 == 0 and col % 4 == 0: a float4 is entirely inside or outside the row.
+            // Out-of-range entries read a zero line instead of being masked after the load: a
+            // select on the loaded value would force the vmcnt wait in front of the MFMAs.
+            bool ok = ci < cin && col < cout;
+            const float* src = ok ? Wk + (i64)ci * cout + col : zeros;
+            float4 v = *reinterpret_cast<const float4*>(src);
+            stage[s] = v;
+        }
+    };
+    auto store_panel = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            int e = tid + s * 256;
+            int pr = e / (NCOL / 4);
+            int pc = (e % (NCOL / 4)) * 4;
+            *reinterpret_cast<float4*>(&s_B[buf][pr * BLD + pc]) = stage[s];
+        }
+    };
+    float imp_nxt = 1.f;
+    auto gather_a = [&](int k, int pnl) {
         const int idx = s_nbr[lrow * NBR_LD + k];
         const bool valid = idx >= 0;
         const float* frow = a.inp_features + (i64)(valid ? idx : 0) * a.inp_ld;
-        const float imp = (IMP && valid) ? s_w[lrow * NBR_LD + k] : 1.f;
-        const float* Wk = a.filters + (i64)k * cin * cout;
-        for (int c0 = 0; c0 < cin; c0 += 16) {
-            const int c = c0 + 4 * g;
-            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid && c < cin) av = *reinterpret_cast<const float4*>(frow + c);
-            if (IMP) {
-                av.x *= imp;
-                av.y *= imp;
-                av.z *= imp;
-                av.w *= imp;
-            }
-            const float avs[4] = {av.x, av.y, av.z, av.w};
+        if (IMP) imp_nxt = valid ? s_w[lrow * NBR_LD + k] : 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ci = c + t;
-                const float* wrow = Wk + (i64)ci * cout + n0 + ncol;
+        for (int j = 0; j < NJ; ++j) {
+            int c = pnl * KC + 16 * j + 4 * g;
+            const float* src = (valid && c < cin) ? frow + c : zeros;
+            a_nxt[j] = *reinterpret_cast<const float4*>(src);
+        }
+    };
+
+    if (k_cur >= 0) {
+        load_panel(k_cur, 0);
+        gather_a(k_cur, 0);
+        store_panel(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    while (k_cur >= 0) {
+        // next step
+        int k_nxt = k_cur, p_nxt = p_cur + 1;
+        if (p_nxt == npanel) {
+            p_nxt = 0;
+            todo &= todo - 1;
+            k_nxt = todo ? __builtin_ctzll(todo) : -1;
+        }
+        float4 a_cur[NJ];
 #pragma unroll
-                for (int nb = 0; nb < NT; ++nb) {
-                    float bv = 0.f;
-                    if (ci < cin && n0 + nb * 16 + ncol < cout) bv = wrow[nb * 16];
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(avs[t], bv, acc[nb], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) a_cur[j] = a_nxt[j];
+        const float imp_cur = imp_nxt;
+        if (k_nxt >= 0) {
+            load_panel(k_nxt, p_nxt);   // global loads stay in flight during the MFMAs below
+            gather_a(k_nxt, p_nxt);
+        }
+        // (a wave whose 16 rows lack slot k_cur multiplies zero rows: with regrouped rows the
+        // block and wave masks nearly coincide, and a conditional MFMA block makes hipcc shuttle
+        // all accumulators between VGPRs and AGPRs every panel)
+        {
+            const float* sb = &s_B[buf][(4 * g) * BLD + ncol];
+            float bv[2][NT];
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) bv[0][nb] = sb[nb * 16];
+#pragma unroll
+            for (int jt = 0; jt < NJ * 4; ++jt) {
+                const int j = jt >> 2, t = jt & 3;
+                if (jt + 1 < NJ * 4) {
+                    const int j1 = (jt + 1) >> 2, t1 = (jt + 1) & 3;
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb)
+                        bv[(jt + 1) & 1][nb] = sb[(16 * j1 + t1) * BLD + nb * 16];
                 }
+                float av = t == 0 ? a_cur[j].x : t == 1 ? a_cur[j].y : t == 2 ? a_cur[j].z : a_cur[j].w;
+                if (IMP) av *= imp_cur;
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[jt & 1][nb], acc[nb], 0, 0, 0);
             }
         }
+        if (k_nxt >= 0) store_panel(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        k_cur = k_nxt;
+        p_cur = p_nxt;
     }
 
     // epilogue: acc[nb][i] is C[row = 4*g + i][col = ncol] of the wave's 16 x 16 block
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int lr = wave * 16 + 4 * g + i;
-        const i64 q = row0 + lr;
-        if (q >= a.num_out) continue;
+        const i64 q = s_row[lr];
+        if (q < 0) continue;
         const float norm = s_norm[lr];
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) {
@@ -282,8 +374,8 @@ __global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a) {
             a.out[q * a.out_ld + col] = v;
         }
     }
-    if (a.out_importance && blockIdx.y == 0 && tid < TM && row0 + tid < a.num_out)
-        a.out_importance[row0 + tid] = s_norm[tid];
+    if (a.out_importance && blockIdx.y == 0 && tid < TM && s_row[tid] >= 0)
+        a.out_importance[s_row[tid]] = s_norm[tid];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -390,7 +482,8 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     if (a.cin < 1 || a.cout < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: bad channel count");
     if (a.inp_ld < a.cin || a.out_ld < a.cout)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: row stride smaller than channel count");
-    bool mfma_ok = (a.cin % 4 == 0) && (a.inp_ld % 4 == 0) &&
+    bool mfma_ok = (a.cin % 4 == 0) && (a.cout % 4 == 0) && (a.inp_ld % 4 == 0) &&
+                   ((uintptr_t)a.filters % 16 == 0) &&
                    ((uintptr_t)a.inp_features % 16 == 0);
     int algo = a.algo;
     if (algo == 0) algo = mfma_ok ? 2 : 1;
@@ -402,22 +495,32 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
         ASR_CHECK_LAUNCH(ctx);
         return ASR_HIP_OK;
     }
+    if (a.cout % 4 != 0)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: MFMA path needs cout %% 4 == 0");
+    const float* zeros = nullptr;
+    ASR_TRY(asr_ctx_zeros(ctx, &zeros));
     dim3 block(256);
     unsigned tiles = (unsigned)((a.num_out + TM - 1) / TM);
-    int nt = a.cout > 64 ? 8 : a.cout > 32 ? 4 : a.cout > 16 ? 2 : 1;
-    dim3 grid(tiles, (a.cout + nt * 16 - 1) / (nt * 16));
     const bool imp = a.inp_importance || a.neighbors_importance;
-#define ASR_LAUNCH_SCONV(NT_)                                              \
-    if (imp)                                                               \
-        k_sconv_mfma<NT_, true><<<grid, block, 0, ctx->stream>>>(a);       \
-    else                                                                   \
-        k_sconv_mfma<NT_, false><<<grid, block, 0, ctx->stream>>>(a);
-    switch (nt) {
-        case 1: ASR_LAUNCH_SCONV(1) break;
-        case 2: ASR_LAUNCH_SCONV(2) break;
-        case 4: ASR_LAUNCH_SCONV(4) break;
-        default: ASR_LAUNCH_SCONV(8) break;
+    // column tile: 16 / 32 / 64 / 128 / 256 wide; panel depth so that a panel is >= 4 KB
+#define ASR_LAUNCH_SCONV(NT_, KC_)                                                  \
+    {                                                                               \
+        dim3 grid(tiles, (a.cout + NT_ * 16 - 1) / (NT_ * 16));                     \
+        if (imp)                                                                    \
+            k_sconv_mfma<NT_, KC_, true><<<grid, block, 0, ctx->stream>>>(a, zeros);       \
+        else                                                                        \
+            k_sconv_mfma<NT_, KC_, false><<<grid, block, 0, ctx->stream>>>(a, zeros);      \
     }
+    if (a.cout > 128)
+        ASR_LAUNCH_SCONV(16, 16)
+    else if (a.cout > 64)
+        ASR_LAUNCH_SCONV(8, 16)
+    else if (a.cout > 32)
+        ASR_LAUNCH_SCONV(4, 32)
+    else if (a.cout > 16)
+        ASR_LAUNCH_SCONV(2, 64)
+    else
+        ASR_LAUNCH_SCONV(1, 64)
 #undef ASR_LAUNCH_SCONV
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;

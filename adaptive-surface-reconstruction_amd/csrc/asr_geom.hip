@@ -568,6 +568,26 @@ __global__ void k_invert_fill(const int32_t* sorted_src, i64 p, const i64* rs, i
 }
 
 // ------------------------------------------------------------------------------------------
+// row regrouping for the MFMA sparse conv: rows of one CSR are reordered inside segments of
+// `seg` consecutive rows so that rows with the same set of kernel slots sit in the same 16-row
+// MFMA tile (ascending 55-bit slot mask).  Purely a tiling order: results do not depend on it.
+// ------------------------------------------------------------------------------------------
+__global__ void k_row_masks(const uint8_t* kidx, const i64* rs, i64 v, u64* masks, int32_t* ids) {
+    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (q >= v) return;
+    u64 m = 0;
+    for (i64 p = rs[q]; p < rs[q + 1]; ++p) m |= u64(1) << (kidx[p] & 63);
+    masks[q] = m;
+    ids[q] = (int32_t)q;
+}
+__global__ void k_seg_offsets(unsigned int* off, i64 nseg, i64 seg, i64 v) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i > nseg) return;
+    i64 o = i * seg;
+    off[i] = (unsigned int)(o < v ? o : v);
+}
+
+// ------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------
 int ensure_flags(asr_hip_context* ctx) {
@@ -785,6 +805,33 @@ int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* 
     *rs_out = rs;
     *idx_out = idx;
     *kidx_out = kidx;
+    return ASR_HIP_OK;
+}
+
+int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
+                        int32_t* perm_out) {
+    if (v <= 0) return ASR_HIP_OK;
+    if (seg < 16) seg = 16;
+    if (v >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "row_groups: too many rows");
+    i64 nseg = (v + seg - 1) / seg;
+    u64* masks = arena_alloc<u64>(ctx->scratch, v);
+    u64* masks_s = arena_alloc<u64>(ctx->scratch, v);
+    int32_t* ids = arena_alloc<int32_t>(ctx->scratch, v);
+    unsigned int* off = arena_alloc<unsigned int>(ctx->scratch, nseg + 1);
+    if (!masks || !masks_s || !ids || !off) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_row_masks<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(kidx, rs, v, masks, ids);
+    ASR_CHECK_LAUNCH(ctx);
+    k_seg_offsets<<<grid_for(nseg + 1, BLK), BLK, 0, ctx->stream>>>(off, nseg, seg, v);
+    ASR_CHECK_LAUNCH(ctx);
+    size_t tb = 0;
+    ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tb, masks, masks_s, ids, perm_out,
+                                                           (unsigned int)v, (unsigned int)nseg, off,
+                                                           off + 1, 0, 56, ctx->stream));
+    void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+    if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_pairs(tmp, tb, masks, masks_s, ids, perm_out,
+                                                           (unsigned int)v, (unsigned int)nseg, off,
+                                                           off + 1, 0, 56, ctx->stream));
     return ASR_HIP_OK;
 }
 

@@ -165,8 +165,18 @@ typedef struct asr_sparse_conv_args {
     float* out_importance;             /* dev [num_out] or NULL: sum of neighbour importance
                                           (reduce_subarrays_sum, :127-128)                   */
     int algo;                          /* 0 = auto, 1 = scalar reference kernel, 2 = MFMA    */
+    const int32_t* row_perm;           /* dev [num_out] or NULL: order in which the MFMA kernel
+                                          tiles the output rows (asr_hip_row_groups); results
+                                          do not depend on it                                */
 } asr_sparse_conv_args;
 int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* args);
+
+/* MFMA tiling order for asr_hip_sparse_conv_f32: reorders the rows of a CSR inside segments of
+ * `segment_rows` consecutive rows (0 = default) by their set of kernel slots, so that 16-row MFMA
+ * tiles see few distinct slots. perm_out_dev [num_rows] goes into asr_sparse_conv_args.row_perm. */
+int asr_hip_row_groups(asr_hip_context* ctx, const uint8_t* kernel_index_dev,
+                       const int64_t* row_splits_dev, int64_t num_rows, int64_t segment_rows,
+                       int32_t* perm_out_dev);
 
 /* ---- a11: open3d::invert_neighbors_list (net_definitions_torch.py:22-36,548-559) -------- */
 int asr_hip_invert_neighbors_list(asr_hip_context* ctx, int64_t num_points,

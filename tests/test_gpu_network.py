@@ -18,11 +18,15 @@ ATOL = 1e-5
 
 
 def _close(a, b, atol=ATOL, rtol=1e-5):
+    """|a - b| <= atol * max(1, max|b|) + rtol * |b|: fp32 sums of O(max|b|) terms may cancel, so
+    the absolute part scales with the magnitude of the tensor (1e-5 of it)"""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     err = np.abs(a - b)
     assert a.shape == b.shape
-    assert np.all(err <= atol + rtol * np.abs(b)), "max err %.3e (ref max %.3e)" % (err.max(), np.abs(b).max())
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    assert np.all(err <= atol * scale + rtol * np.abs(b)), \
+        "max err %.3e (ref max %.3e)" % (err.max(), np.abs(b).max())
 
 
 def _t(a, gpu):
@@ -96,6 +100,14 @@ def test_sparse_conv_k55(geo, gpu, algo, cin, cout):
     ref = np.maximum(O.sparse_conv(W, f, idx, kidx, nimp, rs, True) + b, 0)
     _close(out.cpu().numpy(), ref)
     _close(oimp.cpu().numpy(), O.reduce_subarrays_sum(nimp, rs), 1e-5)
+    # row regrouping changes the tiling only: identical bits with and without the permutation
+    if algo == 2:
+        perm = ops.row_groups(_t(kidx, gpu), _t(rs, gpu), 256)
+        assert sorted(perm.cpu().tolist()) == list(range(v))
+        out_p, oimp_p = ops.sparse_conv(_t(W, gpu), _t(f, gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu),
+                                        inp_importance=_t(imp, gpu), normalize=True, bias=_t(b, gpu),
+                                        relu=True, return_importance=True, algo=2, row_perm=perm)
+        assert torch.equal(out_p, out) and torch.equal(oimp_p, oimp)
     # per-pair importance (open3d::sparse_conv signature), no normalisation, no activation
     pimp = rng.uniform(0.05, 1.0, size=len(idx)).astype(np.float32)
     out = ops.sparse_conv(_t(W, gpu), _t(f, gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu),

@@ -179,9 +179,10 @@ def scan_cloud(n, seed=0, device="cpu", density_variance=1.0, num_cameras=50):
                                2.0 * np.log(spread)) if spread > 1 else torch.full(
                                    (num_cameras,), 4.0, device=dev)
     rounds = 0
-    while have < n and rounds < 8:
+    rate = 0.5  # fraction of rays that become points; refined after the first round
+    while have < n and rounds < 12:
         rounds += 1
-        per_cam = int((n - have) * 1.6 / num_cameras) + 64
+        per_cam = int((n - have) * 1.15 / rate / num_cameras) + 64
         m = per_cam * num_cameras
         cam = torch.arange(num_cameras, device=dev).repeat_interleave(per_cam)
         origin = cam_dirs[cam] * cam_dist[cam, None]
@@ -212,6 +213,7 @@ def scan_cloud(n, seed=0, device="cpu", density_variance=1.0, num_cameras=50):
         pts.append(p)
         nrm.append(nn_)
         have += p.shape[0]
+        rate = max(0.05, p.shape[0] / float(m))
     points = torch.cat(pts)[:n].contiguous().float()
     normals = torch.cat(nrm)[:n].contiguous().float()
     if points.shape[0] < n:

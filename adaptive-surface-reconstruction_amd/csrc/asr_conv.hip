@@ -241,10 +241,13 @@ __global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a,
     for (int o = 32; o > 0; o >>= 1) bmask |= __shfl_xor(bmask, o, 64);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) wmask |= __shfl_xor(wmask, o, 64);
-    wmask = __builtin_amdgcn_readfirstlane((unsigned)(wmask)) |
-            ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(wmask >> 32)) << 32);
-    bmask = __builtin_amdgcn_readfirstlane((unsigned)(bmask)) |
-            ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(bmask >> 32)) << 32);
+    // readfirstlane returns a signed int: go through unsigned or bit 31 smears into bits 32..63
+    wmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wmask) |
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wmask >> 32)) << 32);
+    bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
+    bmask &= (1ull << K) - 1;  // K <= 56
+    (void)wmask;
 
     f32x4 acc[NT];
 #pragma unroll

@@ -189,6 +189,7 @@ int asr_hip_continuous_conv_f32(asr_hip_context* ctx, const float* filters, cons
     CTX_GUARD(ctx);
     if (num_out > 0 && (!filters || !out_pos || !extents || !inp_pos || !inp_feat || !rs || !out))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: null argument");
+    ctx->scratch.reset();
     return asr_conv_cconv(ctx, filters, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs, num_out,
                           cin, cout, normalize, bias, relu, out);
 }

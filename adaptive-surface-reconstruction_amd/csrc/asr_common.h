@@ -12,6 +12,7 @@
 
 typedef uint64_t u64;
 typedef int64_t i64;
+typedef uint32_t u32;
 
 // ---------------------------------------------------------------------------------------
 // Device arena: a list of hipMalloc'd slabs with bump allocation.  reset() rewinds the bump

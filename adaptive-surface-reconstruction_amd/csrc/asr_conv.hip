@@ -47,12 +47,13 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
                                                const i64* __restrict__ rs, i64 num_out, int cin,
                                                int cout, int normalize,
                                                const float* __restrict__ bias, int relu,
-                                               float* __restrict__ out) {
+                                               float* __restrict__ out, i64 heavy_rows) {
     const int lane = threadIdx.x & 63;
     const i64 q = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
     if (q >= num_out) return;
     const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
     const i64 b = rs[q], e = rs[q + 1];
+    if (e - b > heavy_rows) return;  // long rows go to k_cconv_heavy (16 waves per row)
     const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
     const float inv_e = 1.f / extents[q];
     const float sc2 = 2.f * inv_e;
@@ -128,6 +129,126 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
         float r = mine;
         if (normalize && norm != 0.f) r = r / norm;
         (void)inv_norm;
+        if (bias) r += bias[lane];
+        if (relu) r = fmaxf(r, 0.f);
+        out[q * cout + lane] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a10, long rows: a coarse voxel next to the surface can have tens of thousands of neighbours
+// while the mean is ~15.  Rows above CCONV_HEAVY pairs are collected and handled by one
+// 1024-thread block each: the 16 waves take interleaved pairs, partial B sums are combined
+// through LDS in wave order (deterministic), wave 0 does the contraction.
+// ------------------------------------------------------------------------------------------
+constexpr i64 CCONV_HEAVY = 1024;
+__global__ void k_cconv_heavy_list(const i64* rs, i64 num_out, i64 thr, int32_t* list, int* count) {
+    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (q >= num_out) return;
+    if (rs[q + 1] - rs[q] > thr) list[atomicAdd(count, 1)] = (int32_t)q;
+}
+
+template <int COUT_MAX>
+__global__ __launch_bounds__(1024) void k_cconv_heavy(
+        const float* __restrict__ filters, const float* __restrict__ out_pos,
+        const float* __restrict__ extents, const float* __restrict__ inp_pos,
+        const float* __restrict__ inp_feat, const int32_t* __restrict__ nidx,
+        const float* __restrict__ nimp, const i64* __restrict__ rs, const int32_t* __restrict__ list,
+        int cin, int cout, int normalize, const float* __restrict__ bias, int relu,
+        float* __restrict__ out) {
+    __shared__ float s_part[16][64][4];
+    __shared__ float s_norm[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 q = list[blockIdx.x];
+    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const i64 b = rs[q], e = rs[q + 1];
+    const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
+    const float sc2 = 2.f * (1.f / extents[q]);
+    float acc[COUT_MAX];
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+    float norm_total = 0.f;
+    for (int c0 = 0; c0 < cin; c0 += 4) {
+        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm = 0.f;
+        for (i64 p = b + wave; p < e; p += 16) {
+            const int32_t i = nidx[p];
+            const float w = nimp ? nimp[p] : 1.f;
+            norm += w;
+            float dx = (inp_pos[3 * (i64)i] - ox) * sc2;
+            float dy = (inp_pos[3 * (i64)i + 1] - oy) * sc2;
+            float dz = (inp_pos[3 * (i64)i + 2] - oz) * sc2;
+            float r = sqrtf(dx * dx + dy * dy + dz * dz);
+            float m = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
+            if (m < 1e-8f) {
+                dx = dy = dz = 0.f;
+            } else {
+                float s = 0.5f * r / m;
+                dx *= s;
+                dy *= s;
+                dz *= s;
+            }
+            float ux = fminf(fmaxf((dx + 0.5f) * 3.f, 0.f), 3.f);
+            float uy = fminf(fmaxf((dy + 0.5f) * 3.f, 0.f), 3.f);
+            float uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
+            float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+            int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+            int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
+            float ax = ux - fx, ay = uy - fy, az = uz - fz;
+            float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
+            float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
+            float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
+            float wt = wx * wy * wz;
+            if (wt != 0.f) {
+                const float* f = inp_feat + (i64)i * cin + c0;
+                B0 += wt * (w * f[0]);
+                if (c0 + 1 < cin) B1 += wt * (w * f[1]);
+                if (c0 + 2 < cin) B2 += wt * (w * f[2]);
+                if (c0 + 3 < cin) B3 += wt * (w * f[3]);
+            }
+        }
+        __syncthreads();  // previous chunk's partials consumed
+        s_part[wave][lane][0] = B0;
+        s_part[wave][lane][1] = B1;
+        s_part[wave][lane][2] = B2;
+        s_part[wave][lane][3] = B3;
+        if (lane == 0) s_norm[wave] = norm;
+        __syncthreads();
+        if (wave == 0) {
+            B0 = B1 = B2 = B3 = 0.f;
+            float nt = 0.f;
+            for (int w2 = 0; w2 < 16; ++w2) {
+                B0 += s_part[w2][lane][0];
+                B1 += s_part[w2][lane][1];
+                B2 += s_part[w2][lane][2];
+                B3 += s_part[w2][lane][3];
+                nt += s_norm[w2];
+            }
+            if (c0 == 0) norm_total = nt;
+            const float* wrow = filters + ((i64)lane * cin + c0) * cout;
+#pragma unroll
+            for (int o = 0; o < COUT_MAX; ++o) {
+                if (o < cout) {
+                    float s = wrow[o] * B0;
+                    if (c0 + 1 < cin) s += wrow[cout + o] * B1;
+                    if (c0 + 2 < cin) s += wrow[2 * cout + o] * B2;
+                    if (c0 + 3 < cin) s += wrow[3 * cout + o] * B3;
+                    acc[o] += s;
+                }
+            }
+        }
+    }
+    if (wave != 0) return;
+    float mine = 0.f;
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+        if (o < cout) {
+            float s = wave_reduce_sum(acc[o]);
+            if (lane == o) mine = s;
+        }
+    }
+    if (lane < cout) {
+        float r = mine;
+        if (normalize && norm_total != 0.f) r = r / norm_total;
         if (bias) r += bias[lane];
         if (relu) r = fmaxf(r, 0.f);
         out[q * cout + lane] = r;
@@ -461,18 +582,42 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     if (cout < 1 || cout > 64) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cout must be 1..64");
     if (cin < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cin must be >= 1");
     unsigned blocks = grid_for(num_out * 64, 256);
+    // long rows: collect, then one 1024-thread block per row
+    int32_t* heavy = arena_alloc<int32_t>(ctx->scratch, (size_t)num_out);
+    int* d_count = arena_alloc<int>(ctx->scratch, 4);
+    if (!heavy || !d_count) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    k_cconv_heavy_list<<<grid_for(num_out, 256), 256, 0, ctx->stream>>>(rs, num_out, CCONV_HEAVY, heavy,
+                                                                      d_count);
+    ASR_CHECK_LAUNCH(ctx);
+#define ASR_LAUNCH_CCONV(C_)                                                                      \
+    k_cconv<C_><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, \
+                                                 nimp, rs, num_out, cin, cout, normalize, bias,    \
+                                                 relu, out, CCONV_HEAVY);
+#define ASR_LAUNCH_CCONV_HEAVY(C_)                                                                 \
+    k_cconv_heavy<C_><<<n_heavy, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos,        \
+                                                         inp_feat, nidx, nimp, rs, heavy, cin, cout, \
+                                                         normalize, bias, relu, out);
     if (cout <= 8)
-        k_cconv<8><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat,
-                                                    nidx, nimp, rs, num_out, cin, cout, normalize,
-                                                    bias, relu, out);
+        ASR_LAUNCH_CCONV(8)
     else if (cout <= 32)
-        k_cconv<32><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat,
-                                                     nidx, nimp, rs, num_out, cin, cout, normalize,
-                                                     bias, relu, out);
+        ASR_LAUNCH_CCONV(32)
     else
-        k_cconv<64><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat,
-                                                     nidx, nimp, rs, num_out, cin, cout, normalize,
-                                                     bias, relu, out);
+        ASR_LAUNCH_CCONV(64)
+    ASR_CHECK_LAUNCH(ctx);
+    int n_heavy = 0;
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(&n_heavy, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_heavy > 0) {
+        if (cout <= 8)
+            ASR_LAUNCH_CCONV_HEAVY(8)
+        else if (cout <= 32)
+            ASR_LAUNCH_CCONV_HEAVY(32)
+        else
+            ASR_LAUNCH_CCONV_HEAVY(64)
+    }
+#undef ASR_LAUNCH_CCONV
+#undef ASR_LAUNCH_CCONV_HEAVY
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }

@@ -468,72 +468,103 @@ __device__ inline float sqdist3(float ax, float ay, float az, float bx, float by
     return s;
 }
 
-// MODE 0: count, MODE 1: write unsorted candidates
+// One WAVE per query: lanes 0..26 look up the 3^3 cells, the candidate points of all cells are
+// then walked 64 at a time (flattened through a prefix of the cell counts).  Row lengths range
+// from 0 to tens of thousands (a coarse voxel near the surface sees every point within one voxel
+// size), so a thread-per-query loop is dominated by its longest row.
+// MODE 0: count, MODE 1: write (distance, index) keys in candidate order (sorted afterwards)
 template <int MODE>
-__global__ void k_radius_query(asr_octree_frame f, const float4* sorted, const float* centers,
-                               const float* sizes, i64 v, HashTab t, const int32_t* start,
-                               const int32_t* end, i64* counts, const i64* rs, int32_t* tmp_idx,
-                               float* tmp_dist, int32_t* tmp_row) {
-    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (MODE == 0 && q == v) counts[v] = 0;
+__global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
+                                                      const float* centers, const float* sizes,
+                                                      i64 v, HashTab t, const int32_t* start,
+                                                      const int32_t* end, i64* counts,
+                                                      const i64* rs, u64* keys_out,
+                                                      int32_t* row_out) {
+    __shared__ int s_pref[4][28];
+    __shared__ int s_beg[4][28];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 q = blockIdx.x * (i64)4 + wave;
+    if (MODE == 0 && q == v && lane == 0) counts[v] = 0;
     if (q >= v) return;
-    float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
-    float r = sizes[q];
-    float r2 = r * r;
-    int lev = query_level(f, r);
+    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
+    const float r = sizes[q];
+    const float r2 = r * r;
+    const int lev = query_level(f, r);
     int x, y, z;
     frame_coord(f, cx, cy, cz, lev, x, y, z);
-    int lim = (1 << lev) - 1;
-    u64 marker = u64(1) << (3 * lev);
-    i64 n = 0;
-    i64 o = MODE == 1 ? rs[q] : 0;
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                int xx = x + dx, yy = y + dy, zz = z + dz;
-                if (xx < 0 || yy < 0 || zz < 0 || xx > lim || yy > lim || zz > lim) continue;
-                i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | marker);
-                if (slot < 0) continue;
-                int32_t b = start[slot], e = end[slot];
-                for (int32_t p = b; p < e; ++p) {
-                    float4 pt = sorted[p];
-                    float d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
-                    if (d < r2) {
-                        if (MODE == 1) {
-                            tmp_idx[o + n] = __float_as_int(pt.w);
-                            tmp_dist[o + n] = d;
-                            tmp_row[o + n] = (int32_t)q;
-                        }
-                        ++n;
-                    }
-                }
+    const int lim = (1 << lev) - 1;
+    int b = 0, n = 0;
+    if (lane < 27) {
+        int xx = x + lane % 3 - 1, yy = y + (lane / 3) % 3 - 1, zz = z + lane / 9 - 1;
+        if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim) {
+            i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | (u64(1) << (3 * lev)));
+            if (slot >= 0) {
+                b = start[slot];
+                n = end[slot] - b;
             }
-    if (MODE == 0) counts[q] = n;
+        }
+    }
+    // inclusive prefix of n over lanes 0..26
+    int pre = n;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        int up = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += up;
+    }
+    if (lane < 27) {
+        s_pref[wave][lane + 1] = pre;
+        s_beg[wave][lane] = b;
+    }
+    if (lane == 0) s_pref[wave][0] = 0;
+    const int total = __shfl(pre, 26, 64);
+    __builtin_amdgcn_wave_barrier();
+    i64 found = 0;
+    const i64 base = MODE == 1 ? rs[q] : 0;
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        bool hit = false;
+        float d = 0.f;
+        int id = 0;
+        if (i < total) {
+            // cell c with pref[c] <= i < pref[c+1]
+            int lo = 0, hi = 27;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (s_pref[wave][mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const float4 pt = sorted[s_beg[wave][lo] + (i - s_pref[wave][lo])];
+            d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+            hit = d < r2;
+            id = __float_as_int(pt.w);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (MODE == 1 && hit) {
+            const i64 o = base + found + __popcll(m & ((1ull << lane) - 1));
+            keys_out[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+            row_out[o] = (int32_t)q;
+        }
+        found += __popcll(m);
+    }
+    if (MODE == 0 && lane == 0) counts[q] = found;
 }
-// order every row by (distance, index): rank by counting, one thread per pair
-__global__ void k_radius_rank(const int32_t* tmp_idx, const float* tmp_dist, const int32_t* tmp_row,
-                              i64 num_pairs, const i64* rs, const float* sizes, const float* radii,
-                              int32_t* idx, float* dist, float* compat) {
+// rows are sorted by a segmented radix sort on (distance bits, index) keys; unpack + compat
+__global__ void k_radius_unpack(const u64* keys, const int32_t* rows, i64 num_pairs,
+                                const float* sizes, const float* radii, int32_t* idx, float* dist,
+                                float* compat) {
     i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (p >= num_pairs) return;
-    int32_t q = tmp_row[p];
-    i64 b = rs[q], e = rs[q + 1];
-    float d = tmp_dist[p];
-    int32_t id = tmp_idx[p];
-    i64 rank = 0;
-    for (i64 t = b; t < e; ++t) {
-        float dt = tmp_dist[t];
-        int32_t it = tmp_idx[t];
-        rank += (dt < d || (dt == d && it < id)) ? 1 : 0;
-    }
-    i64 o = b + rank;
-    idx[o] = id;
-    dist[o] = d;
+    const u64 k = keys[p];
+    const int32_t id = (int32_t)(k & 0xffffffffu);
+    idx[p] = id;
+    dist[p] = __uint_as_float((unsigned)(k >> 32));
     if (compat) {
-        float a = sizes[q];
+        float a = sizes[rows[p]];
         float bb = 2 * radii[id];
         float ratio = fminf(a, bb) / fmaxf(a, bb);
-        compat[o] = ratio * ratio;
+        compat[p] = ratio * ratio;
     }
 }
 
@@ -955,9 +986,9 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     }
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_radius_query<0><<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(
+    k_radius_query<0><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(
             *frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, counts, nullptr, nullptr,
-            nullptr, nullptr);
+            nullptr);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
     ASR_TRY(read_i64(ctx, rs + v, num_pairs));
@@ -979,16 +1010,28 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
     i64 num_pairs = 0;
     ASR_TRY(read_i64(ctx, rs + v, &num_pairs));
     if (num_pairs > 0) {
-        int32_t* t_idx = arena_alloc<int32_t>(ctx->scratch, num_pairs);
-        float* t_dist = arena_alloc<float>(ctx->scratch, num_pairs);
+        if (num_pairs >= (i64(1) << 32)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many aggregation pairs");
+        u64* k_u = arena_alloc<u64>(ctx->scratch, num_pairs);
+        u64* k_s = arena_alloc<u64>(ctx->scratch, num_pairs);
         int32_t* t_row = arena_alloc<int32_t>(ctx->scratch, num_pairs);
-        if (!t_idx || !t_dist || !t_row) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_radius_query<1><<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(
-                st.frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, nullptr, rs, t_idx,
-                t_dist, t_row);
+        if (!k_u || !k_s || !t_row) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_radius_query<1><<<grid_for(v, 4), BLK, 0, ctx->stream>>>(
+                st.frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, nullptr, rs, k_u,
+                t_row);
         ASR_CHECK_LAUNCH(ctx);
-        k_radius_rank<<<grid_for(num_pairs, BLK), BLK, 0, ctx->stream>>>(
-                t_idx, t_dist, t_row, num_pairs, rs, sizes, radii, idx, dist, compat);
+        // order every row by (squared distance, index): distances are >= 0 so their float bits
+        // order like unsigned integers
+        size_t tb = 0;
+        ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, k_u, k_s,
+                                                              (unsigned int)num_pairs, (unsigned int)v,
+                                                              rs, rs + 1, 0, 64, ctx->stream));
+        void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+        if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(tmp, tb, k_u, k_s,
+                                                              (unsigned int)num_pairs, (unsigned int)v,
+                                                              rs, rs + 1, 0, 64, ctx->stream));
+        k_radius_unpack<<<grid_for(num_pairs, BLK), BLK, 0, ctx->stream>>>(k_s, t_row, num_pairs, sizes,
+                                                                          radii, idx, dist, compat);
         ASR_CHECK_LAUNCH(ctx);
     }
     st.valid = false;

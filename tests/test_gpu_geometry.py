@@ -178,6 +178,27 @@ def test_edge_max_depth_and_empty(gpu):
     assert idx.numel() == 0 and rs.cpu().tolist() == [0]
 
 
+def test_multi_radius_search_long_rows(gpu):
+    """a few huge radii: rows with thousands of members, (distance, index) order incl. ties"""
+    from asr_hip import ops
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(0.05, 0.95, size=(20000, 3)).astype(np.float32)
+    pts[100:200] = pts[0:100]  # exact duplicates -> distance ties, ordered by index
+    rad = np.full(len(pts), 0.01, np.float32)
+    bb = (np.zeros(3, np.float32), np.ones(3, np.float32))
+    frame = _lib.frame_init(*bb)
+    o = O.Oracle()
+    o.build_octree(pts, rad, *bb)
+    centers = np.array([[0.5, 0.5, 0.5], [0.25, 0.25, 0.25], [0.9, 0.1, 0.5], [0.5, 0.5, 0.5]], np.float32)
+    sizes = np.array([0.5, 0.25, 0.03125, 1.0], np.float32)
+    a = ops.multi_radius_search(frame, torch.from_numpy(pts).to(gpu), torch.from_numpy(rad).to(gpu),
+                                torch.from_numpy(centers).to(gpu), torch.from_numpy(sizes).to(gpu))
+    b = o.radius_search(pts, rad, centers, sizes, brute=True)
+    assert b[2][-1] > 15000
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x.cpu().numpy(), y)
+
+
 def test_error_behaviour(gpu):
     from asr_hip import ops
     with pytest.raises(_lib.AsrHipError):

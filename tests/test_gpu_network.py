@@ -73,6 +73,31 @@ def test_aggregation_importance_and_continuous_conv(geo, gpu):
         assert np.allclose(out.cpu().numpy()[empty], np.maximum(b, 0))
 
 
+def test_continuous_conv_ragged_and_long_rows(gpu):
+    """rows of 0 .. 6000 neighbours: rows above 1024 pairs take the 16-wave path"""
+    from asr_hip import ops
+    rng = np.random.default_rng(3)
+    n, cin, cout = 8000, 4, 32
+    pos = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    feat = rng.standard_normal((n, cin)).astype(np.float32)
+    lens = np.array([0, 3, 1500, 1, 6000, 1024, 1025, 0, 64, 2500])
+    v = len(lens)
+    out_pos = rng.uniform(-0.3, 0.3, size=(v, 3)).astype(np.float32)
+    ext = rng.uniform(1.5, 3.0, size=v).astype(np.float32)
+    rs = np.zeros(v + 1, np.int64)
+    rs[1:] = np.cumsum(lens)
+    idx = np.concatenate([rng.choice(n, size=l, replace=False) for l in lens]).astype(np.int32)
+    imp = rng.uniform(0.1, 1, size=rs[-1]).astype(np.float32)
+    W = (rng.standard_normal((4, 4, 4, cin, cout)) * 0.5).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    for nimp, normalize in ((imp, True), (None, False)):
+        out = ops.continuous_conv(_t(W, gpu), _t(out_pos, gpu), _t(ext, gpu), _t(pos, gpu), _t(feat, gpu),
+                                  _t(idx, gpu), _t(nimp, gpu) if nimp is not None else None, _t(rs, gpu),
+                                  normalize, bias=_t(b, gpu), relu=True)
+        ref = np.maximum(O.continuous_conv(W, out_pos, ext, pos, feat, idx, nimp, rs, normalize) + b, 0)
+        _close(out.cpu().numpy(), ref, 2e-5)
+
+
 @pytest.mark.parametrize("algo", [1, 2])
 @pytest.mark.parametrize("cin,cout", [(32, 56), (32, 8), (64, 64), (128, 120), (12, 20), (256, 256)])
 def test_sparse_conv_k55(geo, gpu, algo, cin, cout):

@@ -36,6 +36,41 @@ __device__ inline float wave_reduce_sum(float v) {
     return v;
 }
 
+// per-pair geometry: ball -> cube -> 4^3 filter coordinates
+struct PairGeom {
+    float ax, ay, az;
+    int x0, y0, z0;
+};
+__device__ inline PairGeom cconv_pair_geom(float dx, float dy, float dz) {
+    float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    float m = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
+    if (m < 1e-8f) {
+        dx = dy = dz = 0.f;
+    } else {
+        float s = 0.5f * r / m;
+        dx *= s;
+        dy *= s;
+        dz *= s;
+    }
+    float ux = fminf(fmaxf((dx + 0.5f) * 3.f, 0.f), 3.f);
+    float uy = fminf(fmaxf((dy + 0.5f) * 3.f, 0.f), 3.f);
+    float uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
+    float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
+    PairGeom g;
+    g.x0 = (int)fx;
+    g.y0 = (int)fy;
+    g.z0 = (int)fz;
+    g.ax = ux - fx;
+    g.ay = uy - fy;
+    g.az = uz - fz;
+    return g;
+}
+
+// One wave per output voxel.  The row is consumed 64 pairs at a time: lane j loads pair j
+// (index, position, importance, 4 features) and computes its filter coordinates; the wave then
+// walks the batch with scalar broadcasts (v_readlane, the loop counter is uniform) while lane l,
+// owner of filter cell l, accumulates B[l][0..3] with its own trilinear weight.  No memory access
+// sits in the inner loop.
 template <int COUT_MAX>
 __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters,
                                                const float* __restrict__ out_pos,
@@ -55,8 +90,7 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
     const i64 b = rs[q], e = rs[q + 1];
     if (e - b > heavy_rows) return;  // long rows go to k_cconv_heavy (16 waves per row)
     const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
-    const float inv_e = 1.f / extents[q];
-    const float sc2 = 2.f * inv_e;
+    const float sc2 = 2.f * (1.f / extents[q]);
 
     float acc[COUT_MAX];
 #pragma unroll
@@ -65,42 +99,37 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
 
     for (int c0 = 0; c0 < cin; c0 += 4) {
         float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f;
-        for (i64 p = b; p < e; ++p) {
-            const int32_t i = nidx[p];
-            const float w = nimp ? nimp[p] : 1.f;
-            if (c0 == 0) norm += w;
-            float dx = (inp_pos[3 * (i64)i] - ox) * sc2;
-            float dy = (inp_pos[3 * (i64)i + 1] - oy) * sc2;
-            float dz = (inp_pos[3 * (i64)i + 2] - oz) * sc2;
-            float r = sqrtf(dx * dx + dy * dy + dz * dz);
-            float m = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
-            if (m < 1e-8f) {
-                dx = dy = dz = 0.f;
-            } else {
-                float s = 0.5f * r / m;
-                dx *= s;
-                dy *= s;
-                dz *= s;
-            }
-            float ux = fminf(fmaxf((dx + 0.5f) * 3.f, 0.f), 3.f);
-            float uy = fminf(fmaxf((dy + 0.5f) * 3.f, 0.f), 3.f);
-            float uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
-            float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
-            int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-            int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
-            float ax = ux - fx, ay = uy - fy, az = uz - fz;
-            // this lane's trilinear weight (sums both corners when x0 == x1 at the border)
-            float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
-            float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
-            float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
-            // same association as the oracle: ((wx*wy)*wz) * (w*f)
-            float wt = wx * wy * wz;
-            if (wt != 0.f) {
+        for (i64 p0 = b; p0 < e; p0 += 64) {
+            const int cnt = (int)((e - p0) < 64 ? (e - p0) : 64);
+            // lane j: pair p0 + j
+            PairGeom g = {0.f, 0.f, 0.f, 0, 0, 0};
+            float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+            if (lane < cnt) {
+                const i64 p = p0 + lane;
+                const int32_t i = nidx[p];
+                w = nimp ? nimp[p] : 1.f;
+                g = cconv_pair_geom((inp_pos[3 * (i64)i] - ox) * sc2, (inp_pos[3 * (i64)i + 1] - oy) * sc2,
+                                    (inp_pos[3 * (i64)i + 2] - oz) * sc2);
                 const float* f = inp_feat + (i64)i * cin + c0;
-                B0 += wt * (w * f[0]);
-                if (c0 + 1 < cin) B1 += wt * (w * f[1]);
-                if (c0 + 2 < cin) B2 += wt * (w * f[2]);
-                if (c0 + 3 < cin) B3 += wt * (w * f[3]);
+                f0 = w * f[0];
+                if (c0 + 1 < cin) f1 = w * f[1];
+                if (c0 + 2 < cin) f2 = w * f[2];
+                if (c0 + 3 < cin) f3 = w * f[3];
+            }
+            for (int j = 0; j < cnt; ++j) {
+                const float ax = __shfl(g.ax, j, 64), ay = __shfl(g.ay, j, 64), az = __shfl(g.az, j, 64);
+                const int x0 = __shfl(g.x0, j, 64), y0 = __shfl(g.y0, j, 64), z0 = __shfl(g.z0, j, 64);
+                const int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
+                // this lane's trilinear weight (sums both corners when x0 == x1 at the border)
+                const float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
+                const float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
+                const float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
+                const float wt = wx * wy * wz;  // same association as the oracle
+                if (c0 == 0) norm += __shfl(w, j, 64);
+                B0 += wt * __shfl(f0, j, 64);
+                B1 += wt * __shfl(f1, j, 64);
+                B2 += wt * __shfl(f2, j, 64);
+                B3 += wt * __shfl(f3, j, 64);
             }
         }
         // partial contraction: acc[o] += sum_c W[lane][c0+c][o] * B_c
@@ -116,7 +145,6 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
             }
         }
     }
-    const float inv_norm = (normalize && norm != 0.f) ? 1.f / norm : 0.f;
     float mine = 0.f;
 #pragma unroll
     for (int o = 0; o < COUT_MAX; ++o) {
@@ -128,7 +156,6 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
     if (lane < cout) {
         float r = mine;
         if (normalize && norm != 0.f) r = r / norm;
-        (void)inv_norm;
         if (bias) r += bias[lane];
         if (relu) r = fmaxf(r, 0.f);
         out[q * cout + lane] = r;
@@ -519,14 +546,17 @@ __global__ void k_reduce_rows(const float* values, const int32_t* gidx, const i6
 // weights staged in LDS.
 // ------------------------------------------------------------------------------------------
 constexpr int DEC_MAX = 64;
-__global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, i64 v, int c,
+// CT/H1T/H2T > 0: compile-time widths (registers, fully unrolled); 0: runtime widths (generic)
+template <int CT, int H1T, int H2T>
+__global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, i64 v, int c_,
                                                 const float* __restrict__ w1,
-                                                const float* __restrict__ b1, int h1,
+                                                const float* __restrict__ b1, int h1_,
                                                 const float* __restrict__ w2,
-                                                const float* __restrict__ b2, int h2,
+                                                const float* __restrict__ b2, int h2_,
                                                 const float* __restrict__ w3,
                                                 const float* __restrict__ sizes,
                                                 float* __restrict__ out) {
+    const int c = CT ? CT : c_, h1 = H1T ? H1T : h1_, h2 = H2T ? H2T : h2_;
     extern __shared__ float s_w[];
     float* sw1 = s_w;                 // [h1][c]   (shift columns dropped: shifts are zero)
     float* sb1 = sw1 + h1 * c;        // [h1]
@@ -541,22 +571,54 @@ __global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, 
     __syncthreads();
     i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (q >= v) return;
-    float x[DEC_MAX], f1[DEC_MAX];
-    for (int k = 0; k < c; ++k) x[k] = code[q * c + k];
-    for (int j = 0; j < h1; ++j) {
-        float s = 0.f;
-        for (int k = 0; k < c; ++k) s += x[k] * sw1[j * c + k];
-        s += sb1[j];
-        f1[j] = fmaxf(s, 0.f);
+    float x[CT ? CT : DEC_MAX], f1[H1T ? H1T : DEC_MAX];
+    if (CT) {
+#pragma unroll
+        for (int k = 0; k < (CT ? CT : 1); k += 4) {
+            float4 t = *reinterpret_cast<const float4*>(code + q * c + k);
+            x[k] = t.x;
+            x[k + 1] = t.y;
+            x[k + 2] = t.z;
+            x[k + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < (H1T ? H1T : 1); ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < (CT ? CT : 1); ++k) s += x[k] * sw1[j * c + k];
+            s += sb1[j];
+            f1[j] = fmaxf(s, 0.f);
+        }
+    } else {
+        for (int k = 0; k < c; ++k) x[k] = code[q * c + k];
+        for (int j = 0; j < h1; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < c; ++k) s += x[k] * sw1[j * c + k];
+            s += sb1[j];
+            f1[j] = fmaxf(s, 0.f);
+        }
     }
     float o0 = 0.f, o1 = 0.f;
-    for (int j = 0; j < h2; ++j) {
-        float s = 0.f;
-        for (int k = 0; k < h1; ++k) s += f1[k] * sw2[j * h1 + k];
-        s += sb2[j];
-        s = fmaxf(s, 0.f);
-        o0 += s * sw3[j];
-        o1 += s * sw3[h2 + j];
+    if (CT) {
+#pragma unroll 4
+        for (int j = 0; j < (H2T ? H2T : 1); ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < (H1T ? H1T : 1); ++k) s += f1[k] * sw2[j * h1 + k];
+            s += sb2[j];
+            s = fmaxf(s, 0.f);
+            o0 += s * sw3[j];
+            o1 += s * sw3[h2 + j];
+        }
+    } else {
+        for (int j = 0; j < h2; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < h1; ++k) s += f1[k] * sw2[j * h1 + k];
+            s += sb2[j];
+            s = fmaxf(s, 0.f);
+            o0 += s * sw3[j];
+            o1 += s * sw3[h2 + j];
+        }
     }
     if (sizes) o0 *= sizes[q];
     out[2 * q] = o0;
@@ -689,8 +751,12 @@ int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const
     if (c > DEC_MAX || h1 > DEC_MAX || h2 > DEC_MAX || c < 1 || h1 < 1 || h2 < 1)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "decode_mlp: layer widths must be 1..64");
     size_t lds = sizeof(float) * (size_t)(h1 * c + h1 + h2 * h1 + h2 + 2 * h2);
-    k_decode<<<grid_for(v, 256), 256, lds, ctx->stream>>>(code, v, c, w1, b1, h1, w2, b2, h2, w3,
-                                                          sizes, out);
+    if (c == 32 && h1 == 32 && h2 == 32 && ((uintptr_t)code % 16 == 0))
+        k_decode<32, 32, 32><<<grid_for(v, 256), 256, lds, ctx->stream>>>(code, v, c, w1, b1, h1, w2, b2, h2,
+                                                                          w3, sizes, out);
+    else
+        k_decode<0, 0, 0><<<grid_for(v, 256), 256, lds, ctx->stream>>>(code, v, c, w1, b1, h1, w2, b2, h2, w3,
+                                                                       sizes, out);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }

@@ -81,6 +81,19 @@ __device__ inline i64 tab_find_slot(const HashTab& t, u64 key) {
     return -1;
 }
 
+// append with ONE atomic per wave (ballot + popcount); must be reached by every lane of the wave
+__device__ inline int wave_append(bool pred, int* counter) {
+    const unsigned long long m = __ballot(pred);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        if (lane == leader) base = atomicAdd(counter, __popcll(m));
+        base = __shfl(base, leader, 64);
+    }
+    return base + __popcll(m & ((1ull << lane) - 1));
+}
+
 u64 next_pow2(u64 x) {
     u64 p = 1;
     while (p < x) p <<= 1;
@@ -175,10 +188,10 @@ __global__ void k_octree_insert_points(asr_octree_frame f, const float* pts, con
 // frontier of BalanceFaces: all first siblings (octree.cpp:159-166)
 __global__ void k_collect_first_siblings(HashTab t, u64* frontier, int* cnt, int frontier_cap) {
     u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (s > t.mask) return;
-    u64 k = t.keys[s];
-    if (k != 0 && (k & 7) == 0) {
-        int pos = atomicAdd(&cnt[2], 1);
+    u64 k = s <= t.mask ? t.keys[s] : 0;
+    bool take = k != 0 && (k & 7) == 0;
+    int pos = wave_append(take, &cnt[2]);
+    if (take) {
         if (pos < frontier_cap)
             frontier[pos] = k;
         else
@@ -212,12 +225,13 @@ __global__ void k_balance_insert(HashTab t, const u64* frontier, int m, u64* nex
 }
 __global__ void k_collect_nodes(HashTab t, u64* nodes, u64* leaves, int* cnt) {
     u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    if (s > t.mask) return;
-    u64 k = t.keys[s];
-    if (k == 0) return;
-    nodes[atomicAdd(&cnt[3], 1)] = k;
-    bool has_child = (__clzll((long long)k) > 1) && tab_contains(t, k << 3);
-    if (!has_child) leaves[atomicAdd(&cnt[4], 1)] = k;
+    u64 k = s <= t.mask ? t.keys[s] : 0;
+    bool node = k != 0;
+    int pn = wave_append(node, &cnt[3]);
+    if (node) nodes[pn] = k;
+    bool leaf = node && !((__clzll((long long)k) > 1) && tab_contains(t, k << 3));
+    int pl = wave_append(leaf, &cnt[4]);
+    if (leaf) leaves[pl] = k;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,15 +350,14 @@ __device__ inline int coarsen_state(const u64* keys, i64 v, i64 i) {
 }
 __global__ void k_coarsen_count(const u64* keys, i64 v, int* cnt) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (i >= v) return;
-    if (coarsen_state(keys, v, i) != 2) atomicAdd(&cnt[5], 1);
+    bool keep = i < v && coarsen_state(keys, v, i) != 2;
+    (void)wave_append(keep, &cnt[5]);
 }
 __global__ void k_coarsen_emit(const u64* keys, i64 v, u64* out_keys, int32_t* out_src, int* cnt) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (i >= v) return;
-    int st = coarsen_state(keys, v, i);
+    int st = i < v ? coarsen_state(keys, v, i) : 2;
+    int pos = wave_append(st != 2, &cnt[5]);
     if (st == 2) return;
-    int pos = atomicAdd(&cnt[5], 1);
     out_keys[pos] = st == 1 ? keys[i] >> 3 : keys[i];
     out_src[pos] = (int32_t)i;
 }

@@ -66,9 +66,11 @@ __device__ inline PairGeom cconv_pair_geom(float dx, float dy, float dz) {
     return g;
 }
 
-// One wave per output voxel.  The row is consumed 64 pairs at a time: lane j loads pair j
-// (index, position, importance, 4 features) and computes its filter coordinates; the wave then
-// walks the batch with scalar broadcasts (v_readlane, the loop counter is uniform) while lane l,
+// One wave per output voxel, persistent blocks (grid-stride over voxels).  The 4-channel slice
+// of the filter, [64 cells][4][COUT_MAX] zero padded, is staged in LDS once per block (a guarded
+// global load per filter element costs a vmcnt(0) round trip each: 128 per voxel).  The row is
+// consumed 64 pairs at a time: lane j loads pair j (index, position, importance, 4 features) and
+// computes its filter coordinates; the wave then walks the batch with broadcasts while lane l,
 // owner of filter cell l, accumulates B[l][0..3] with its own trilinear weight.  No memory access
 // sits in the inner loop.
 template <int COUT_MAX>
@@ -83,82 +85,98 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
                                                int cout, int normalize,
                                                const float* __restrict__ bias, int relu,
                                                float* __restrict__ out, i64 heavy_rows) {
+    constexpr int LSTR = 4 * COUT_MAX + 4;  // lane stride in floats: conflict-free ds_read_b128
+    __shared__ __attribute__((aligned(16))) float s_f[64 * LSTR];
     const int lane = threadIdx.x & 63;
-    const i64 q = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
-    if (q >= num_out) return;
     const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
-    const i64 b = rs[q], e = rs[q + 1];
-    if (e - b > heavy_rows) return;  // long rows go to k_cconv_heavy (16 waves per row)
-    const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
-    const float sc2 = 2.f * (1.f / extents[q]);
-
-    float acc[COUT_MAX];
-#pragma unroll
-    for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
-    float norm = 0.f;
+    const i64 wave0 = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
+    const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    const float bias_l = (bias && lane < cout) ? bias[lane] : 0.f;
 
     for (int c0 = 0; c0 < cin; c0 += 4) {
-        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f;
-        for (i64 p0 = b; p0 < e; p0 += 64) {
-            const int cnt = (int)((e - p0) < 64 ? (e - p0) : 64);
-            // lane j: pair p0 + j
-            PairGeom g = {0.f, 0.f, 0.f, 0, 0, 0};
-            float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
-            if (lane < cnt) {
-                const i64 p = p0 + lane;
-                const int32_t i = nidx[p];
-                w = nimp ? nimp[p] : 1.f;
-                g = cconv_pair_geom((inp_pos[3 * (i64)i] - ox) * sc2, (inp_pos[3 * (i64)i + 1] - oy) * sc2,
-                                    (inp_pos[3 * (i64)i + 2] - oz) * sc2);
-                const float* f = inp_feat + (i64)i * cin + c0;
-                f0 = w * f[0];
-                if (c0 + 1 < cin) f1 = w * f[1];
-                if (c0 + 2 < cin) f2 = w * f[2];
-                if (c0 + 3 < cin) f3 = w * f[3];
-            }
-            for (int j = 0; j < cnt; ++j) {
-                const float ax = __shfl(g.ax, j, 64), ay = __shfl(g.ay, j, 64), az = __shfl(g.az, j, 64);
-                const int x0 = __shfl(g.x0, j, 64), y0 = __shfl(g.y0, j, 64), z0 = __shfl(g.z0, j, 64);
-                const int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
-                // this lane's trilinear weight (sums both corners when x0 == x1 at the border)
-                const float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
-                const float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
-                const float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
-                const float wt = wx * wy * wz;  // same association as the oracle
-                if (c0 == 0) norm += __shfl(w, j, 64);
-                B0 += wt * __shfl(f0, j, 64);
-                B1 += wt * __shfl(f1, j, 64);
-                B2 += wt * __shfl(f2, j, 64);
-                B3 += wt * __shfl(f3, j, 64);
-            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 4 * COUT_MAX; e += blockDim.x) {
+            int cell = e / (4 * COUT_MAX), c = (e / COUT_MAX) % 4, o = e % COUT_MAX;
+            bool ok = c0 + c < cin && o < cout;
+            s_f[cell * LSTR + c * COUT_MAX + o] =
+                    ok ? filters[((i64)cell * cin + c0 + c) * cout + o] : 0.f;
         }
-        // partial contraction: acc[o] += sum_c W[lane][c0+c][o] * B_c
-        const float* wrow = filters + ((i64)lane * cin + c0) * cout;
+        __syncthreads();
+        for (i64 q = wave0; q < num_out; q += nwaves) {
+            const i64 b = rs[q], e = rs[q + 1];
+            if (e - b > heavy_rows) continue;  // long rows go to k_cconv_heavy (16 waves per row)
+            float* orow = out + q * cout;
+            if (e == b) {
+                // no neighbour: conv = 0 -> activation(bias)
+                if (c0 == 0 && lane < cout) orow[lane] = relu ? fmaxf(bias_l, 0.f) : bias_l;
+                continue;
+            }
+            const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
+            const float sc2 = 2.f * (1.f / extents[q]);
+            float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm = 0.f;
+            for (i64 p0 = b; p0 < e; p0 += 64) {
+                const int cnt = (int)((e - p0) < 64 ? (e - p0) : 64);
+                PairGeom g = {0.f, 0.f, 0.f, 0, 0, 0};
+                float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+                if (lane < cnt) {  // lane j: pair p0 + j
+                    const i64 p = p0 + lane;
+                    const int32_t i = nidx[p];
+                    w = nimp ? nimp[p] : 1.f;
+                    g = cconv_pair_geom((inp_pos[3 * (i64)i] - ox) * sc2,
+                                        (inp_pos[3 * (i64)i + 1] - oy) * sc2,
+                                        (inp_pos[3 * (i64)i + 2] - oz) * sc2);
+                    const float* f = inp_feat + (i64)i * cin + c0;
+                    f0 = w * f[0];
+                    if (c0 + 1 < cin) f1 = w * f[1];
+                    if (c0 + 2 < cin) f2 = w * f[2];
+                    if (c0 + 3 < cin) f3 = w * f[3];
+                }
+                for (int j = 0; j < cnt; ++j) {
+                    const float ax = __shfl(g.ax, j, 64), ay = __shfl(g.ay, j, 64), az = __shfl(g.az, j, 64);
+                    const int x0 = __shfl(g.x0, j, 64), y0 = __shfl(g.y0, j, 64), z0 = __shfl(g.z0, j, 64);
+                    const int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
+                    // this lane's trilinear weight (sums both corners when x0 == x1 at the border)
+                    const float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
+                    const float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
+                    const float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
+                    const float wt = wx * wy * wz;  // same association as the oracle
+                    norm += __shfl(w, j, 64);
+                    B0 += wt * __shfl(f0, j, 64);
+                    B1 += wt * __shfl(f1, j, 64);
+                    B2 += wt * __shfl(f2, j, 64);
+                    B3 += wt * __shfl(f3, j, 64);
+                }
+            }
+            // contraction: out[o] (+)= sum_cells sum_c W[cell][c0+c][o] * B_c, one o per lane
+            const float* wl = &s_f[lane * LSTR];
+            float mine = 0.f;
 #pragma unroll
-        for (int o = 0; o < COUT_MAX; ++o) {
-            if (o < cout) {
-                float s = wrow[o] * B0;
-                if (c0 + 1 < cin) s += wrow[cout + o] * B1;
-                if (c0 + 2 < cin) s += wrow[2 * cout + o] * B2;
-                if (c0 + 3 < cin) s += wrow[3 * cout + o] * B3;
-                acc[o] += s;
+            for (int o4 = 0; o4 < COUT_MAX; o4 += 4) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wl + o4);
+                const float4 w1 = *reinterpret_cast<const float4*>(wl + COUT_MAX + o4);
+                const float4 w2 = *reinterpret_cast<const float4*>(wl + 2 * COUT_MAX + o4);
+                const float4 w3 = *reinterpret_cast<const float4*>(wl + 3 * COUT_MAX + o4);
+                float s0 = w0.x * B0 + w1.x * B1 + w2.x * B2 + w3.x * B3;
+                float s1 = w0.y * B0 + w1.y * B1 + w2.y * B2 + w3.y * B3;
+                float s2 = w0.z * B0 + w1.z * B1 + w2.z * B2 + w3.z * B3;
+                float s3 = w0.w * B0 + w1.w * B1 + w2.w * B2 + w3.w * B3;
+                s0 = wave_reduce_sum(s0);
+                s1 = wave_reduce_sum(s1);
+                s2 = wave_reduce_sum(s2);
+                s3 = wave_reduce_sum(s3);
+                mine = lane == o4 ? s0 : lane == o4 + 1 ? s1 : lane == o4 + 2 ? s2 : lane == o4 + 3 ? s3 : mine;
+            }
+            if (lane < cout) {
+                float r = mine;
+                if (c0 > 0) r += orow[lane];  // wider inputs: accumulate the raw sums over chunks
+                if (c0 + 4 >= cin) {
+                    if (normalize && norm != 0.f) r = r / norm;
+                    r += bias_l;
+                    if (relu) r = fmaxf(r, 0.f);
+                }
+                orow[lane] = r;
             }
         }
-    }
-    float mine = 0.f;
-#pragma unroll
-    for (int o = 0; o < COUT_MAX; ++o) {
-        if (o < cout) {
-            float s = wave_reduce_sum(acc[o]);
-            if (lane == o) mine = s;
-        }
-    }
-    if (lane < cout) {
-        float r = mine;
-        if (normalize && norm != 0.f) r = r / norm;
-        if (bias) r += bias[lane];
-        if (relu) r = fmaxf(r, 0.f);
-        out[q * cout + lane] = r;
     }
 }
 
@@ -644,6 +662,7 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     if (cout < 1 || cout > 64) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cout must be 1..64");
     if (cin < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cin must be >= 1");
     unsigned blocks = grid_for(num_out * 64, 256);
+    if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: the filter slice is staged once per block
     // long rows: collect, then one 1024-thread block per row
     int32_t* heavy = arena_alloc<int32_t>(ctx->scratch, (size_t)num_out);
     int* d_count = arena_alloc<int>(ctx->scratch, 4);

@@ -140,17 +140,20 @@ __global__ void k_point_keys(asr_octree_frame f, const float* pts, const float* 
 }
 
 // ------------------------------------------------------------------------------------------
-// a4: octree node set.  cnt[0] = nodes inserted, cnt[1] = overflow flag, cnt[2] = next frontier
+// a4: octree node set.  Nodes live in an open-addressing hash set (membership) AND in an append
+// only list of sibling groups (8 consecutive keys, first sibling first): the list gives the
+// BalanceFaces frontiers and the final node array without ever scanning the (mostly empty) table.
+// cnt[0] = list entries (multiple of 8), cnt[1] = overflow flag, cnt[9] = root inserted.
 // ------------------------------------------------------------------------------------------
 // insert the sibling group of `a` and all missing ancestor groups (+ root).
 // The thread that wins the CAS on a group's first sibling creates the other seven and
 // continues upwards; losers stop (CreateAncestorsAndSiblings, octree.cpp:110-150).
-__device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, u64* frontier,
-                                             int frontier_cap) {
+__device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, u64* list,
+                                             int list_cap) {
     while (true) {
         if (a == 1) {
             int r = tab_insert(t, 1);
-            if (r == 1) atomicAdd(&cnt[0], 1);
+            if (r == 1) cnt[9] = 1;
             if (r < 0) cnt[1] = 1;
             return;
         }
@@ -163,13 +166,11 @@ __device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, 
         if (r == 0) return;
         for (int j = 1; j < 8; ++j)
             if (tab_insert(t, first + j) < 0) cnt[1] = 1;
-        atomicAdd(&cnt[0], 8);
-        if (frontier) {
-            int pos = atomicAdd(&cnt[2], 1);
-            if (pos < frontier_cap)
-                frontier[pos] = first;
-            else
-                cnt[1] = 1;
+        int pos = atomicAdd(&cnt[0], 8);
+        if (pos + 8 <= list_cap) {
+            for (int j = 0; j < 8; ++j) list[pos + j] = first + j;
+        } else {
+            cnt[1] = 1;
         }
         a >>= 3;
     }
@@ -177,42 +178,30 @@ __device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, 
 
 __global__ void k_octree_insert_points(asr_octree_frame f, const float* pts, const float* radii,
                                        i64 n, float radius_scale, int max_depth, HashTab t,
-                                       int* cnt) {
+                                       int* cnt, u64* list, int list_cap) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 key = point_key(f, pts, radii, i, radius_scale, max_depth);
     if (key == 0) return;  // the reference inserts key 0 here and then hits UB
-    insert_with_ancestors(t, key, cnt, nullptr, 0);
+    insert_with_ancestors(t, key, cnt, list, list_cap);
 }
 
-// frontier of BalanceFaces: all first siblings (octree.cpp:159-166)
-__global__ void k_collect_first_siblings(HashTab t, u64* frontier, int* cnt, int frontier_cap) {
-    u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    u64 k = s <= t.mask ? t.keys[s] : 0;
-    bool take = k != 0 && (k & 7) == 0;
-    int pos = wave_append(take, &cnt[2]);
-    if (take) {
-        if (pos < frontier_cap)
-            frontier[pos] = k;
-        else
-            cnt[1] = 1;
-    }
-}
-// leaf test against the node set at round start (octree.cpp:175)
-__global__ void k_balance_classify(HashTab t, u64* frontier, int m) {
+// BalanceFaces (octree.cpp:152-206), one round: the frontier is the list range [lo, hi) of sibling
+// groups.  Leaf test against the node set at round start (octree.cpp:175) ...
+__global__ void k_balance_classify(HashTab t, const u64* list, int lo, int ngroups, uint8_t* flag) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    u64 k = frontier[i];
+    if (i >= ngroups) return;
+    u64 k = list[lo + 8 * i];
     bool has_child = (__clzll((long long)k) > 1) && tab_contains(t, k << 3);
-    if (has_child || k == 1) frontier[i] = 0;  // drop
+    flag[i] = has_child ? 0 : 1;
 }
-// octree.cpp:177-203 for all surviving frontier entries
-__global__ void k_balance_insert(HashTab t, const u64* frontier, int m, u64* next, int* cnt,
-                                 int frontier_cap) {
+// ... then octree.cpp:177-203 for all leaf groups: the 6 face neighbours of the parent must exist
+__global__ void k_balance_insert(HashTab t, u64* list, int lo, int ngroups, const uint8_t* flag,
+                                 int* cnt, int list_cap) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m * 6) return;
-    u64 k = frontier[i / 6];
-    if (k == 0) return;
+    if (i >= ngroups * 6) return;
+    if (!flag[i / 6]) return;
+    u64 k = list[lo + 8 * (i / 6)];
     int j = i % 6;
     const int ox = (j == 0) ? -1 : (j == 3) ? 1 : 0;
     const int oy = (j == 1) ? -1 : (j == 4) ? 1 : 0;
@@ -221,15 +210,13 @@ __global__ void k_balance_insert(HashTab t, const u64* frontier, int m, u64* nex
     asr_key_coord(k >> 3, x, y, z, lev);
     u64 key = asr_coord_key(x + ox, y + oy, z + oz, lev);
     if (key == 0) return;
-    insert_with_ancestors(t, key, cnt, next, frontier_cap);
+    insert_with_ancestors(t, key, cnt, list, list_cap);
 }
-__global__ void k_collect_nodes(HashTab t, u64* nodes, u64* leaves, int* cnt) {
-    u64 s = blockIdx.x * (u64)blockDim.x + threadIdx.x;
-    u64 k = s <= t.mask ? t.keys[s] : 0;
-    bool node = k != 0;
-    int pn = wave_append(node, &cnt[3]);
-    if (node) nodes[pn] = k;
-    bool leaf = node && !((__clzll((long long)k) > 1) && tab_contains(t, k << 3));
+// leaves = nodes without first child (InitAttributesAndLeaves, octree.cpp:208-228)
+__global__ void k_collect_leaves(HashTab t, const u64* nodes, i64 n, u64* leaves, int* cnt) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    u64 k = i < n ? nodes[i] : 0;
+    bool leaf = k != 0 && !((__clzll((long long)k) > 1) && tab_contains(t, k << 3));
     int pl = wave_append(leaf, &cnt[4]);
     if (leaf) leaves[pl] = k;
 }
@@ -735,56 +722,55 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
         ctx->scratch.reset();
         HashTab t;
         ASR_TRY(make_table(ctx, ctx->scratch, cap, false, t));
-        int fcap = (int)std::min<u64>(cap / 8, u64(1) << 30);
-        u64* fr_a = arena_alloc<u64>(ctx->scratch, fcap);
-        u64* fr_b = arena_alloc<u64>(ctx->scratch, fcap);
-        if (!fr_a || !fr_b) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        // the table is kept at most half full, so the node list never exceeds cap / 2 entries
+        int lcap = (int)std::min<u64>(cap / 2, u64(1) << 30);
+        u64* list = arena_alloc<u64>(ctx->scratch, (size_t)lcap + 8);
+        uint8_t* flag = arena_alloc<uint8_t>(ctx->scratch, (size_t)lcap / 8 + 8);
+        if (!list || !flag) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
         if (n > 0) {
             k_octree_insert_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
-                    *frame, pts, radii, n, radius_scale, max_depth, t, ctx->d_flags);
+                    *frame, pts, radii, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);
             ASR_CHECK_LAUNCH(ctx);
         }
-        k_collect_first_siblings<<<grid_for((i64)cap, BLK), BLK, 0, ctx->stream>>>(
-                t, fr_a, ctx->d_flags, fcap);
-        ASR_CHECK_LAUNCH(ctx);
         ASR_TRY(read_flags(ctx, host));
         bool overflow = host[1] != 0 || (u64)host[0] * 2 > cap;
-        int m = host[2];
-        while (!overflow && m > 0) {
-            ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 2, 0, sizeof(int), ctx->stream));
-            k_balance_classify<<<grid_for(m, BLK), BLK, 0, ctx->stream>>>(t, fr_a, m);
+        int lo = 0, hi = host[0];
+        while (!overflow && hi > lo) {
+            int ngroups = (hi - lo) / 8;
+            k_balance_classify<<<grid_for(ngroups, BLK), BLK, 0, ctx->stream>>>(t, list, lo, ngroups, flag);
             ASR_CHECK_LAUNCH(ctx);
-            k_balance_insert<<<grid_for((i64)m * 6, BLK), BLK, 0, ctx->stream>>>(
-                    t, fr_a, m, fr_b, ctx->d_flags, fcap);
+            k_balance_insert<<<grid_for((i64)ngroups * 6, BLK), BLK, 0, ctx->stream>>>(
+                    t, list, lo, ngroups, flag, ctx->d_flags, lcap);
             ASR_CHECK_LAUNCH(ctx);
             ASR_TRY(read_flags(ctx, host));
             overflow = host[1] != 0 || (u64)host[0] * 2 > cap;
-            m = host[2];
-            std::swap(fr_a, fr_b);
+            lo = hi;
+            hi = host[0];
         }
         if (overflow) continue;
-        i64 num_nodes = host[0];
+        i64 num_nodes = (i64)host[0] + (host[9] ? 1 : 0);
         if (num_nodes == 0) {
             ctx->num_nodes = ctx->num_leaves = 0;
             ctx->nodes = ctx->leaves = nullptr;
             return ASR_HIP_OK;
         }
-        u64* nodes_u = arena_alloc<u64>(ctx->scratch, num_nodes);
+        if (host[9]) {  // the root closes the list
+            const u64 one = 1;
+            ASR_HIP_CHECK(ctx, hipMemcpyAsync(list + host[0], &one, sizeof(u64), hipMemcpyHostToDevice,
+                                              ctx->stream));
+        }
         u64* leaves_u = arena_alloc<u64>(ctx->scratch, num_nodes);
-        if (!nodes_u || !leaves_u) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_collect_nodes<<<grid_for((i64)cap, BLK), BLK, 0, ctx->stream>>>(t, nodes_u, leaves_u,
-                                                                         ctx->d_flags);
+        if (!leaves_u) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_collect_leaves<<<grid_for(num_nodes, BLK), BLK, 0, ctx->stream>>>(t, list, num_nodes, leaves_u,
+                                                                           ctx->d_flags);
         ASR_CHECK_LAUNCH(ctx);
         ASR_TRY(read_flags(ctx, host));
-        if (host[3] != num_nodes)
-            ASR_FAIL(ctx, ASR_HIP_ELOGIC, "octree node count mismatch %d vs %lld", host[3],
-                     (long long)num_nodes);
         i64 num_leaves = host[4];
         ctx->nodes = arena_alloc<u64>(ctx->persist, num_nodes);
         ctx->leaves = arena_alloc<u64>(ctx->persist, num_leaves);
         if (!ctx->nodes || !ctx->leaves) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(sort_keys(ctx, ctx->scratch, nodes_u, ctx->nodes, num_nodes));
+        ASR_TRY(sort_keys(ctx, ctx->scratch, list, ctx->nodes, num_nodes));
         ASR_TRY(sort_keys(ctx, ctx->scratch, leaves_u, ctx->leaves, num_leaves));
         ctx->num_nodes = num_nodes;
         ctx->num_leaves = num_leaves;

@@ -55,6 +55,25 @@ def conv_flops(sizes, shapes):
     return total, launches
 
 
+def rank_seed(rank):
+    """one scan per rank: the path shards by scan, no data moves between ranks"""
+    return 1000 + rank
+
+
+def max_over_ranks(dt, world, device):
+    """contract: the step time of the job is the slowest rank's"""
+    if world <= 1:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_value(world, points_per_rank, steps, dt):
+    """whole-job throughput: points processed by all ranks / max-over-ranks time"""
+    return world * points_per_rank * steps / dt
+
+
 def cpu_baseline(n_sample, seed):
     """the oracle ("port" of the reference path incl. the Open3D op semantics) timed on the host
     cores on a bounded sample of the same workload generator"""
@@ -106,7 +125,7 @@ def main():
 
     # ---- inputs (untimed): one scan per rank, radii = exact 24-NN distance -------------------
     n = args.points
-    pts, nrm = synth.scan_cloud(n, seed=1000 + rank, device=dev)
+    pts, nrm = synth.scan_cloud(n, seed=rank_seed(rank), device=dev)
     radii = torch.from_numpy(synth.knn_radii(pts.cpu().numpy(), 24)).to(dev)
     bb_min, bb_max = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(1, seed=0, init="reference")  # released weights are not in the repo
@@ -133,10 +152,7 @@ def main():
             stage_sum[k] += v
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, world, dev)
     assert values.shape[0] == pipe.sizes.num_voxels[0] and bool(torch.isfinite(values).all())
 
     if rank == 0:
@@ -148,7 +164,7 @@ def main():
         achieved = flops / unet_s / 1e12 if unet_s > 0 else 0.0
         out = {
             "metric": "input points/sec to signed implicit values",
-            "value": world * n / (dt / steps),
+            "value": job_value(world, n, steps, dt),
             "unit": "points/s",
             "n_gpus": world,
             "steps": args.steps,

@@ -347,7 +347,7 @@ constexpr int TM = 64;      // rows per block
 constexpr int NBR_LD = 57;  // odd stride: conflict-free column reads
 
 template <int NT, int KC, bool IMP>
-__global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a,
+__global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse_conv_args a,
                                                     const float* __restrict__ zeros) {
     constexpr int NCOL = NT * 16;
     constexpr int BLD = NCOL + 4;            // (4g+t)*BLD mod 32 separates the two 16-lane halves
@@ -524,23 +524,39 @@ __global__ __launch_bounds__(256) void k_sconv_mfma(asr_sparse_conv_args a,
         p_cur = p_nxt;
     }
 
-    // epilogue: acc[nb][i] is C[row = 4*g + i][col = ncol] of the wave's 16 x 16 block
+    // epilogue: acc[nb][i] is C[row = 4*g + i][col = ncol] of the wave's 16 x 16 block.
+    // All loads (bias, residual) are unconditional (absent -> zero line) and issued before the
+    // stores: a guarded load per element would cost one memory round trip per store.
+    float bv[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        const int col = n0 + nb * 16 + ncol;
+        const float* bp = (a.bias && col < cout) ? a.bias + col : zeros;
+        bv[nb] = *bp;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int lr = wave * 16 + 4 * g + i;
         const i64 q = s_row[lr];
-        if (q < 0) continue;
+        const bool rowok = q >= 0;
         const float norm = s_norm[lr];
+        const bool do_norm = a.normalize && norm != 0.f;
+        float res[NT];
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) {
             const int col = n0 + nb * 16 + ncol;
-            if (col >= cout) continue;
+            const float* rp = (a.residual && rowok && col < cout) ? a.residual + q * a.residual_ld + col : zeros;
+            res[nb] = *rp;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
             float v = acc[nb][i];
-            if (a.normalize && norm != 0.f) v /= norm;
-            if (a.bias) v += a.bias[col];
+            v = do_norm ? v / norm : v;
+            v += bv[nb];
             if (a.relu) v = fmaxf(v, 0.f);
-            if (a.residual) v += a.residual[q * a.residual_ld + col];
-            a.out[q * a.out_ld + col] = v;
+            v += res[nb];
+            if (rowok && col < cout) a.out[q * a.out_ld + col] = v;
         }
     }
     if (a.out_importance && blockIdx.y == 0 && tid < TM && s_row[tid] >= 0)
@@ -740,16 +756,18 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
         else                                                                        \
             k_sconv_mfma<NT_, KC_, false><<<grid, block, 0, ctx->stream>>>(a, zeros);      \
     }
-    if (a.cout > 128)
-        ASR_LAUNCH_SCONV(16, 16)
-    else if (a.cout > 64)
-        ASR_LAUNCH_SCONV(8, 16)
-    else if (a.cout > 32)
-        ASR_LAUNCH_SCONV(4, 32)
-    else if (a.cout > 16)
-        ASR_LAUNCH_SCONV(2, 64)
-    else
-        ASR_LAUNCH_SCONV(1, 64)
+    // widest column tile that fits cout, narrowed while the launch has too few blocks to fill
+    // 256 CUs (coarse grids have only a few thousand rows; the gather is then repeated per
+    // column chunk, which those levels can afford)
+    int nt = a.cout > 128 ? 16 : a.cout > 64 ? 8 : a.cout > 32 ? 4 : a.cout > 16 ? 2 : 1;
+    while (nt > 2 && (i64)tiles * ((a.cout + nt * 16 - 1) / (nt * 16)) < 1024) nt >>= 1;
+    switch (nt) {
+        case 16: ASR_LAUNCH_SCONV(16, 16) break;
+        case 8: ASR_LAUNCH_SCONV(8, 16) break;
+        case 4: ASR_LAUNCH_SCONV(4, 32) break;
+        case 2: ASR_LAUNCH_SCONV(2, 64) break;
+        default: ASR_LAUNCH_SCONV(1, 64) break;
+    }
 #undef ASR_LAUNCH_SCONV
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;

@@ -3,11 +3,22 @@
 // (cpp/lib/asr.cpp:143-336) plus UNet5.aggregate/unet/decode
 // (models/v0/net_definitions_torch.py:535-666).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "asr_common.h"
 
-#define ASR_ROW_GROUP_SEGMENT 4096
+// rows are regrouped inside segments of this many consecutive rows (env ASR_ROW_SEGMENT overrides,
+// for experiments)
+static i64 asr_row_group_segment() {
+    static i64 v = [] {
+        const char* e = getenv("ASR_ROW_SEGMENT");
+        i64 x = e ? atoll(e) : 0;
+        return x > 0 ? x : (i64)131072;
+    }();
+    return v;
+}
+#define ASR_ROW_GROUP_SEGMENT asr_row_group_segment()
 #define CTX_GUARD(ctx)                      \
     if (!(ctx)) return ASR_HIP_EINVAL;      \
     (ctx)->err.clear();

@@ -413,7 +413,6 @@ __global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse
     bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
     bmask &= (1ull << K) - 1;  // K <= 56
-    (void)wmask;
 
     f32x4 acc[NT];
 #pragma unroll
@@ -493,10 +492,9 @@ __global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse
             load_panel(k_nxt, p_nxt);   // global loads stay in flight during the MFMAs below
             gather_a(k_nxt, p_nxt);
         }
-        // (a wave whose 16 rows lack slot k_cur multiplies zero rows: with regrouped rows the
-        // block and wave masks nearly coincide, and a conditional MFMA block makes hipcc shuttle
-        // all accumulators between VGPRs and AGPRs every panel)
-        {
+        // a wave whose 16 rows lack slot k_cur skips the MFMAs (PMC: executing them
+        // unconditionally doubles the MFMA work, the block-level slot union is ~2x a wave's)
+        if ((wmask >> k_cur) & 1) {
             const float* sb = &s_B[buf][(4 * g) * BLD + ncol];
             float bv[2][NT];
 #pragma unroll

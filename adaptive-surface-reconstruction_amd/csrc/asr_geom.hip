@@ -611,11 +611,9 @@ __global__ void k_row_masks(const uint8_t* kidx, const i64* rs, i64 v, u64* mask
     masks[q] = m;
     ids[q] = (int32_t)q;
 }
-__global__ void k_seg_offsets(unsigned int* off, i64 nseg, i64 seg, i64 v) {
+__global__ void k_segment_of(const int32_t* rows, i64 v, i64 seg, int32_t* out) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (i > nseg) return;
-    i64 o = i * seg;
-    off[i] = (unsigned int)(o < v ? o : v);
+    if (i < v) out[i] = (int32_t)(rows[i] / seg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -843,25 +841,26 @@ int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs
     if (v <= 0) return ASR_HIP_OK;
     if (seg < 16) seg = 16;
     if (v >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "row_groups: too many rows");
-    i64 nseg = (v + seg - 1) / seg;
     u64* masks = arena_alloc<u64>(ctx->scratch, v);
     u64* masks_s = arena_alloc<u64>(ctx->scratch, v);
     int32_t* ids = arena_alloc<int32_t>(ctx->scratch, v);
-    unsigned int* off = arena_alloc<unsigned int>(ctx->scratch, nseg + 1);
-    if (!masks || !masks_s || !ids || !off) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    if (!masks || !masks_s || !ids) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     k_row_masks<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(kidx, rs, v, masks, ids);
     ASR_CHECK_LAUNCH(ctx);
-    k_seg_offsets<<<grid_for(nseg + 1, BLK), BLK, 0, ctx->stream>>>(off, nseg, seg, v);
+    // order by (segment, mask) with two stable LSD radix sorts: by mask, then by segment id
+    if (seg >= v) {
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, perm_out, v, 56)));
+        return ASR_HIP_OK;
+    }
+    int32_t* ids_m = arena_alloc<int32_t>(ctx->scratch, v);
+    int32_t* segk = arena_alloc<int32_t>(ctx->scratch, v);
+    int32_t* segk_s = arena_alloc<int32_t>(ctx->scratch, v);
+    if (!ids_m || !segk || !segk_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, ids_m, v, 56)));
+    k_segment_of<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(ids_m, v, seg, segk);
     ASR_CHECK_LAUNCH(ctx);
-    size_t tb = 0;
-    ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tb, masks, masks_s, ids, perm_out,
-                                                           (unsigned int)v, (unsigned int)nseg, off,
-                                                           off + 1, 0, 56, ctx->stream));
-    void* tmp = ctx->scratch.alloc(tb ? tb : 256);
-    if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_pairs(tmp, tb, masks, masks_s, ids, perm_out,
-                                                           (unsigned int)v, (unsigned int)nseg, off,
-                                                           off + 1, 0, 56, ctx->stream));
+    ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, segk, segk_s, ids_m, perm_out, v,
+                                          bits_for((v + seg - 1) / seg + 1))));
     return ASR_HIP_OK;
 }
 

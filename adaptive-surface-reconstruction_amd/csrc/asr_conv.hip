@@ -343,17 +343,18 @@ __global__ void k_sconv_scalar(asr_sparse_conv_args a) {
 // consumer (a guarded load costs a vmcnt(0) per MFMA).  Epilogue: normalise, bias, ReLU, residual,
 // strided store (zero-copy concat).
 // ------------------------------------------------------------------------------------------
-constexpr int TM = 64;      // rows per block
 constexpr int NBR_LD = 57;  // odd stride: conflict-free column reads
 
-template <int NT, int KC, bool IMP>
-__global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse_conv_args a,
+template <int NT, int KC, bool IMP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) void k_sconv_mfma(asr_sparse_conv_args a,
                                                     const float* __restrict__ zeros) {
+    constexpr int TM = WAVES * 16;   // rows per block: more rows share one staged weight panel
+    constexpr int NTHR = WAVES * 64;
     constexpr int NCOL = NT * 16;
     constexpr int BLD = NCOL + 4;            // (4g+t)*BLD mod 32 separates the two 16-lane halves
     constexpr int NJ = KC / 16;              // float4 gathers per lane per panel
-    constexpr int SV = KC * NCOL / 4 / 256;  // float4 staged per thread per panel
-    static_assert(KC * NCOL / 4 % 256 == 0, "panel must split evenly over the block");
+    constexpr int SV = KC * NCOL / 4 / NTHR;  // float4 staged per thread per panel
+    static_assert(KC * NCOL / 4 % NTHR == 0, "panel must split evenly over the block");
     __shared__ int s_nbr[TM * NBR_LD];
     __shared__ float s_w[IMP ? TM * NBR_LD : 1];
     __shared__ float s_norm[TM];
@@ -363,12 +364,15 @@ __global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const i64 row0 = (i64)blockIdx.x * TM;
+    // (an XCD-contiguous tile order was measured and is slower: tiles are sorted by slot mask, so a
+    // contiguous range per XCD is unbalanced -- 59 -> 70 ms for the 10 M U-Net)
+    const i64 tile = blockIdx.x;
+    const i64 row0 = tile * TM;
     const int n0 = blockIdx.y * NCOL;
     const int K = a.kernel_size;
     const int cin = a.cin, cout = a.cout;
 
-    for (int i = tid; i < TM * NBR_LD; i += 256) s_nbr[i] = -1;
+    for (int i = tid; i < TM * NBR_LD; i += NTHR) s_nbr[i] = -1;
     __syncthreads();
     if (tid < TM) {
         i64 q = row0 + tid;
@@ -403,6 +407,7 @@ __global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse
     // slot masks: this wave's 16 rows and the whole block (both wave uniform)
     unsigned long long wmask = s_mask[lrow];
     unsigned long long bmask = s_mask[lane];
+    if (TM > 64) bmask |= s_mask[64 + lane];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bmask |= __shfl_xor(bmask, o, 64);
 #pragma unroll
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse
         const float* Wk = a.filters + (i64)k * cin * cout;
 #pragma unroll
         for (int s = 0; s < SV; ++s) {
-            int e = tid + s * 256;            // float4 index inside the panel
+            int e = tid + s * NTHR;            // float4 index inside the panel
             int pr = e / (NCOL / 4);          // panel row
             int pc = (e % (NCOL / 4)) * 4;    // column
             int ci = pnl * KC + pr, col = n0 + pc;
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256, NT >= 16 ? 3 : 4) void k_sconv_mfma(asr_sparse
     auto store_panel = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < SV; ++s) {
-            int e = tid + s * 256;
+            int e = tid + s * NTHR;
             int pr = e / (NCOL / 4);
             int pc = (e % (NCOL / 4)) * 4;
             *reinterpret_cast<float4*>(&s_B[buf][pr * BLD + pc]) = stage[s];
@@ -742,30 +747,37 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: MFMA path needs cout %% 4 == 0");
     const float* zeros = nullptr;
     ASR_TRY(asr_ctx_zeros(ctx, &zeros));
-    dim3 block(256);
-    unsigned tiles = (unsigned)((a.num_out + TM - 1) / TM);
     const bool imp = a.inp_importance || a.neighbors_importance;
-    // column tile: 16 / 32 / 64 / 128 / 256 wide; panel depth so that a panel is >= 4 KB
-#define ASR_LAUNCH_SCONV(NT_, KC_)                                                  \
-    {                                                                               \
-        dim3 grid(tiles, (a.cout + NT_ * 16 - 1) / (NT_ * 16));                     \
-        if (imp)                                                                    \
-            k_sconv_mfma<NT_, KC_, true><<<grid, block, 0, ctx->stream>>>(a, zeros);       \
-        else                                                                        \
-            k_sconv_mfma<NT_, KC_, false><<<grid, block, 0, ctx->stream>>>(a, zeros);      \
-    }
     // widest column tile that fits cout, narrowed while the launch has too few blocks to fill
     // 256 CUs (coarse grids have only a few thousand rows; the gather is then repeated per
-    // column chunk, which those levels can afford)
+    // column chunk, which those levels can afford).  128-row blocks (8 waves) halve the weight
+    // panel traffic per MFMA and are used whenever they still give enough blocks.
     int nt = a.cout > 128 ? 16 : a.cout > 64 ? 8 : a.cout > 32 ? 4 : a.cout > 16 ? 2 : 1;
-    while (nt > 2 && (i64)tiles * ((a.cout + nt * 16 - 1) / (nt * 16)) < 1024) nt >>= 1;
-    switch (nt) {
-        case 16: ASR_LAUNCH_SCONV(16, 16) break;
-        case 8: ASR_LAUNCH_SCONV(8, 16) break;
-        case 4: ASR_LAUNCH_SCONV(4, 32) break;
-        case 2: ASR_LAUNCH_SCONV(2, 64) break;
-        default: ASR_LAUNCH_SCONV(1, 64) break;
+    const i64 tiles64 = (a.num_out + 63) / 64;
+    while (nt > 2 && tiles64 * ((a.cout + nt * 16 - 1) / (nt * 16)) < 1024) nt >>= 1;
+    const i64 tiles128 = (a.num_out + 127) / 128;
+    const bool wide = nt >= 2 && tiles128 * ((a.cout + nt * 16 - 1) / (nt * 16)) >= 2048;
+#define ASR_LAUNCH_SCONV(NT_, KC_, W_)                                                           \
+    {                                                                                            \
+        dim3 grid((unsigned)((a.num_out + W_ * 16 - 1) / (W_ * 16)), (a.cout + NT_ * 16 - 1) / (NT_ * 16)); \
+        if (imp)                                                                                 \
+            k_sconv_mfma<NT_, KC_, true, W_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(a, zeros);   \
+        else                                                                                     \
+            k_sconv_mfma<NT_, KC_, false, W_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(a, zeros);  \
     }
+#define ASR_LAUNCH_SCONV_W(NT_, KC_)   \
+    if (wide)                          \
+        ASR_LAUNCH_SCONV(NT_, KC_, 8)  \
+    else                               \
+        ASR_LAUNCH_SCONV(NT_, KC_, 4)
+    switch (nt) {
+        case 16: ASR_LAUNCH_SCONV_W(16, 16) break;
+        case 8: ASR_LAUNCH_SCONV_W(8, 16) break;
+        case 4: ASR_LAUNCH_SCONV_W(4, 32) break;
+        case 2: ASR_LAUNCH_SCONV_W(2, 64) break;
+        default: ASR_LAUNCH_SCONV(1, 64, 4) break;
+    }
+#undef ASR_LAUNCH_SCONV_W
 #undef ASR_LAUNCH_SCONV
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;

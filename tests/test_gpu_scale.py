@@ -1,0 +1,102 @@
+"""GPU parity at the benchmark sizes.  1 M points (C2-sized): every integer structure bit exact vs
+the oracle and the network within tolerance (narrow model so the CPU oracle finishes in seconds).
+10 M points (C3): size-independent properties -- sortedness, CSR well-formedness, inversion round
+trip, slot uniqueness, symmetric neighbour relation, run-to-run bit reproducibility."""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from asr_hip import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _prep(n, seed, gpu):
+    pts, nrm = synth.scan_cloud(n, seed=seed, device=gpu)
+    radii = torch.from_numpy(synth.knn_radii(pts.cpu().numpy(), 24)).to(gpu)
+    bb = synth.bounding_box(pts, 0.1)
+    return pts, nrm, radii, bb
+
+
+def test_one_million_points_vs_oracle(gpu):
+    from asr_hip.pipeline import ImplicitPipeline
+    pts, nrm, radii, bb = _prep(1_000_000, 31, gpu)
+    weights = synth.make_weights(4, seed=31)
+    pipe = ImplicitPipeline(weights, device=gpu)
+    values = pipe.forward(pts, nrm, radii, bb[0], bb[1])
+    ref = parity.oracle_forward(pts.cpu().numpy(), nrm.cpu().numpy(), radii.cpu().numpy(), bb[0], bb[1], weights)
+    assert np.array_equal(pipe.get("nodes").cpu().numpy().view(np.uint64), ref["nodes"])
+    for i in range(5):
+        s = str(i)
+        assert np.array_equal(pipe.get("voxel_keys" + s).cpu().numpy().view(np.uint64), ref["voxel_keys" + s])
+        for k in ("voxel_centers", "voxel_sizes", "neighbors_index", "neighbors_kernel_index", "neighbors_row_splits"):
+            assert np.array_equal(pipe.get(k + s).cpu().numpy(), ref[k + s]), k + s
+        if i < 4:
+            for k in ("up_neighbors_index", "up_neighbors_kernel_index", "up_neighbors_row_splits"):
+                assert np.array_equal(pipe.get(k + s).cpu().numpy(), ref[k + s]), k + s
+    for k in ("aggregation_neighbors_index", "aggregation_neighbors_dist", "aggregation_row_splits"):
+        assert np.array_equal(pipe.get(k).cpu().numpy(), ref[k]), k
+    assert np.abs(pipe.get("aggregation_scale_compat").cpu().numpy() - ref["aggregation_scale_compat"]).max() <= 1e-6
+    scale = max(1.0, float(np.abs(ref["code"]).max()))
+    assert np.abs(pipe.get("code").cpu().numpy() - ref["code"]).max() <= 2e-5 * scale
+    vs = max(1.0, float(np.abs(ref["values"]).max()))
+    assert np.abs(values.cpu().numpy() - ref["values"]).max() <= 1e-5 * vs
+
+
+def test_ten_million_points_properties(gpu):
+    from asr_hip.pipeline import ImplicitPipeline
+    pts, nrm, radii, bb = _prep(10_000_000, 1000, gpu)
+    weights = synth.make_weights(4, seed=2)
+    pipe = ImplicitPipeline(weights, device=gpu)
+    values = pipe.forward(pts, nrm, radii, bb[0], bb[1]).clone()
+    assert bool(torch.isfinite(values).all())
+    sizes = pipe.sizes
+    v = [int(x) for x in sizes.num_voxels]
+    assert v[0] > v[1] > v[2] > v[3] > v[4] > 0
+    for i in range(5):
+        s = str(i)
+        keys = pipe.get("voxel_keys" + s)
+        # sorted as UNSIGNED 64 bit (level-21 keys have the top bit set): compare after a bias flip
+        ku = keys ^ torch.tensor(-2**63, dtype=torch.int64, device=gpu)
+        assert bool((ku[1:] > ku[:-1]).all())
+        rs = pipe.get("neighbors_row_splits" + s)
+        idx = pipe.get("neighbors_index" + s).long()
+        kidx = pipe.get("neighbors_kernel_index" + s).long()
+        assert int(rs[0]) == 0 and int(rs[-1]) == idx.numel() == int(sizes.num_pairs[i])
+        ln = rs[1:] - rs[:-1]
+        assert int(ln.min()) >= 1 and int(ln.max()) <= 55
+        assert bool((idx[rs[:-1]] == torch.arange(v[i], device=gpu)).all())   # slot 0 = self
+        assert bool((kidx[rs[:-1]] == 0).all())
+        inner = torch.ones(idx.numel(), dtype=torch.bool, device=gpu)
+        inner[rs[:-1]] = False
+        assert bool((kidx[1:] > kidx[:-1])[inner[1:]].all())                    # ascending slots per row
+        assert int(idx.min()) >= 0 and int(idx.max()) < v[i]
+        # symmetric relation: the multiset of (row, col) equals the multiset of (col, row)
+        row = torch.repeat_interleave(torch.arange(v[i], device=gpu), ln)
+        a = torch.sort(row * v[i] + idx).values
+        b = torch.sort(idx * v[i] + row).values
+        assert torch.equal(a, b)
+        if i < 4:
+            up = pipe.get("up_neighbors_index" + s).long()
+            upk = pipe.get("up_neighbors_kernel_index" + s).long()
+            assert int(up.max()) == v[i + 1] - 1 and int(upk.max()) <= 8
+            d_idx = pipe.get("down_neighbors_index" + s).long()
+            d_rs = pipe.get("down_neighbors_row_splits" + s)
+            d_k = pipe.get("down_neighbors_kernel_index" + s).long()
+            # inversion round trip: entry j of coarse row r is a fine voxel whose up index is r
+            rows = torch.repeat_interleave(torch.arange(v[i + 1], device=gpu), d_rs[1:] - d_rs[:-1])
+            assert torch.equal(up[d_idx], rows) and torch.equal(upk[d_idx], d_k)
+            assert set(torch.unique(d_rs[1:] - d_rs[:-1]).tolist()) <= {1, 8}
+    ars = pipe.get("aggregation_row_splits")
+    adist = pipe.get("aggregation_neighbors_dist")
+    assert int(ars[-1]) == adist.numel() == int(sizes.num_agg_pairs) >= v[0]
+    inner = torch.ones(adist.numel(), dtype=torch.bool, device=gpu)
+    inner[ars[:-1][ars[:-1] < adist.numel()]] = False
+    assert bool((adist[1:] >= adist[:-1])[inner[1:]].all())                      # rows sorted by distance
+    vs = pipe.get("voxel_sizes0")
+    q = torch.repeat_interleave(torch.arange(v[0], device=gpu), ars[1:] - ars[:-1])
+    assert bool((adist < vs[q] * vs[q]).all())                                   # strict radius test
+    # same input again on the same context: identical bits
+    v2 = pipe.forward(pts, nrm, radii, bb[0], bb[1])
+    assert torch.equal(values, v2)

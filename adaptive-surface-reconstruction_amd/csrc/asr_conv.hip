@@ -36,12 +36,9 @@ __device__ inline float wave_reduce_sum(float v) {
     return v;
 }
 
-// per-pair geometry: ball -> cube -> 4^3 filter coordinates
-struct PairGeom {
-    float ax, ay, az;
-    int x0, y0, z0;
-};
-__device__ inline PairGeom cconv_pair_geom(float dx, float dy, float dz) {
+// per-pair filter coordinates u in [0,3]^3: ball -> cube (radial) -> 4^3 grid, align_corners
+// 
+__device__ inline void cconv_pair_coords(float dx, float dy, float dz, float& ux, float& uy, float& uz) {
     float r = sqrtf(dx * dx + dy * dy + dz * dz);
     float m = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
     if (m < 1e-8f) {
@@ -52,27 +49,101 @@ __device__ inline PairGeom cconv_pair_geom(float dx, float dy, float dz) {
         dy *= s;
         dz *= s;
     }
-    float ux = fminf(fmaxf((dx + 0.5f) * 3.f, 0.f), 3.f);
-    float uy = fminf(fmaxf((dy + 0.5f) * 3.f, 0.f), 3.f);
-    float uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
-    float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
-    PairGeom g;
-    g.x0 = (int)fx;
-    g.y0 = (int)fy;
-    g.z0 = (int)fz;
-    g.ax = ux - fx;
-    g.ay = uy - fy;
-    g.az = uz - fz;
-    return g;
+    ux = fminf(fmaxf((dx + 0.5f) * 3.f, 0.f), 3.f);
+    uy = fminf(fmaxf((dy + 0.5f) * 3.f, 0.f), 3.f);
+    uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
+}
+
+// Accumulates pairs [p0, p0+cnt) (cnt <= 64) of one output voxel into this lane's filter cell:
+// lane j loads pair j (index, position, importance, 4 features) and computes its coordinates; the
+// wave then walks the batch with scalar broadcasts (v_readlane: the loop counter is uniform).
+// The trilinear weight of cell c along an axis is the hat function max(0, 1 - |u - c|), which
+// equals the (1-a, a) corner weights of linear interpolation with border clamping.
+// No memory access sits in the inner loop.
+__device__ inline void cconv_batch(const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
+                                   const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
+                                   i64 p0, int cnt, int lane, int cin, int c0, float ox, float oy,
+                                   float oz, float sc2, float cxf, float cyf, float czf, float& B0,
+                                   float& B1, float& B2, float& B3, float& norm_lane) {
+    float ux = 0.f, uy = 0.f, uz = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+    if (lane < cnt) {
+        const i64 p = p0 + lane;
+        const int32_t i = nidx[p];
+        const float w = nimp ? nimp[p] : 1.f;
+        norm_lane += w;
+        cconv_pair_coords((inp_pos[3 * (i64)i] - ox) * sc2, (inp_pos[3 * (i64)i + 1] - oy) * sc2,
+                          (inp_pos[3 * (i64)i + 2] - oz) * sc2, ux, uy, uz);
+        const float* f = inp_feat + (i64)i * cin + c0;
+        f0 = w * f[0];
+        if (c0 + 1 < cin) f1 = w * f[1];
+        if (c0 + 2 < cin) f2 = w * f[2];
+        if (c0 + 3 < cin) f3 = w * f[3];
+    }
+    for (int j = 0; j < cnt; ++j) {
+        const float wx = fmaxf(0.f, 1.f - fabsf(__shfl(ux, j, 64) - cxf));
+        const float wy = fmaxf(0.f, 1.f - fabsf(__shfl(uy, j, 64) - cyf));
+        const float wz = fmaxf(0.f, 1.f - fabsf(__shfl(uz, j, 64) - czf));
+        const float wt = wx * wy * wz;
+        B0 += wt * __shfl(f0, j, 64);
+        B1 += wt * __shfl(f1, j, 64);
+        B2 += wt * __shfl(f2, j, 64);
+        B3 += wt * __shfl(f3, j, 64);
+    }
+}
+
+// out[o] (+)= sum over the 64 cells of sum_c W[cell][c][o] * B_c for o < COUT_MAX, with this lane's
+// cell row `wl` in LDS.  Reduce-scatter butterfly: 32 + 16 + ... exchanges instead of one full wave
+// reduction per output channel.  Returns the value of output channel cconv_lane_channel(lane)
+// (valid in every lane; lanes l and l^1... hold duplicates when COUT_MAX < 64).
+template <int COUT_MAX>
+__device__ inline float cconv_contract(const float* wl, float B0, float B1, float B2, float B3, int lane) {
+    float v[COUT_MAX];
+#pragma unroll
+    for (int o4 = 0; o4 < COUT_MAX; o4 += 4) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + o4);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + COUT_MAX + o4);
+        const float4 w2 = *reinterpret_cast<const float4*>(wl + 2 * COUT_MAX + o4);
+        const float4 w3 = *reinterpret_cast<const float4*>(wl + 3 * COUT_MAX + o4);
+        v[o4 + 0] = w0.x * B0 + w1.x * B1 + w2.x * B2 + w3.x * B3;
+        v[o4 + 1] = w0.y * B0 + w1.y * B1 + w2.y * B2 + w3.y * B3;
+        v[o4 + 2] = w0.z * B0 + w1.z * B1 + w2.z * B2 + w3.z * B3;
+        v[o4 + 3] = w0.w * B0 + w1.w * B1 + w2.w * B2 + w3.w * B3;
+    }
+    // halve the number of live values at every step: lanes with bit `m` set keep the upper half
+    int n = COUT_MAX;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        if (n > 1) {
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int i = 0; i < COUT_MAX / 2; ++i) {
+                if (i < n / 2) {
+                    const float send = up ? v[i] : v[i + n / 2];
+                    const float keep = up ? v[i + n / 2] : v[i];
+                    v[i] = keep + __shfl_xor(send, m, 64);
+                }
+            }
+            n >>= 1;
+        } else {
+            v[0] += __shfl_xor(v[0], m, 64);
+        }
+    }
+    return v[0];
+}
+// output channel whose sum cconv_contract leaves in `lane`
+template <int COUT_MAX>
+__device__ inline int cconv_lane_channel(int lane) {
+    int o = 0, n = COUT_MAX;
+    for (int m = 32; m >= 1 && n > 1; m >>= 1) {
+        n >>= 1;
+        if (lane & m) o += n;
+    }
+    return o;
 }
 
 // One wave per output voxel, persistent blocks (grid-stride over voxels).  The 4-channel slice
 // of the filter, [64 cells][4][COUT_MAX] zero padded, is staged in LDS once per block (a guarded
-// global load per filter element costs a vmcnt(0) round trip each: 128 per voxel).  The row is
-// consumed 64 pairs at a time: lane j loads pair j (index, position, importance, 4 features) and
-// computes its filter coordinates; the wave then walks the batch with broadcasts while lane l,
-// owner of filter cell l, accumulates B[l][0..3] with its own trilinear weight.  No memory access
-// sits in the inner loop.
+// global load per filter element costs a vmcnt(0) round trip each: 128 per voxel).
 template <int COUT_MAX>
 __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters,
                                                const float* __restrict__ out_pos,
@@ -88,10 +159,12 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
     constexpr int LSTR = 4 * COUT_MAX + 4;  // lane stride in floats: conflict-free ds_read_b128
     __shared__ __attribute__((aligned(16))) float s_f[64 * LSTR];
     const int lane = threadIdx.x & 63;
-    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const float cxf = (float)(lane & 3), cyf = (float)((lane >> 2) & 3), czf = (float)(lane >> 4);
     const i64 wave0 = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
-    const float bias_l = (bias && lane < cout) ? bias[lane] : 0.f;
+    const int my_o = cconv_lane_channel<COUT_MAX>(lane);
+    const bool writer = my_o < cout && (COUT_MAX == 64 || (lane & (64 / COUT_MAX - 1)) == 0);
+    const float bias_o = (bias && my_o < cout) ? bias[my_o] : 0.f;
 
     for (int c0 = 0; c0 < cin; c0 += 4) {
         __syncthreads();
@@ -108,73 +181,25 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
             float* orow = out + q * cout;
             if (e == b) {
                 // no neighbour: conv = 0 -> activation(bias)
-                if (c0 == 0 && lane < cout) orow[lane] = relu ? fmaxf(bias_l, 0.f) : bias_l;
+                if (c0 == 0 && writer) orow[my_o] = relu ? fmaxf(bias_o, 0.f) : bias_o;
                 continue;
             }
             const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
             const float sc2 = 2.f * (1.f / extents[q]);
-            float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm = 0.f;
-            for (i64 p0 = b; p0 < e; p0 += 64) {
-                const int cnt = (int)((e - p0) < 64 ? (e - p0) : 64);
-                PairGeom g = {0.f, 0.f, 0.f, 0, 0, 0};
-                float w = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
-                if (lane < cnt) {  // lane j: pair p0 + j
-                    const i64 p = p0 + lane;
-                    const int32_t i = nidx[p];
-                    w = nimp ? nimp[p] : 1.f;
-                    g = cconv_pair_geom((inp_pos[3 * (i64)i] - ox) * sc2,
-                                        (inp_pos[3 * (i64)i + 1] - oy) * sc2,
-                                        (inp_pos[3 * (i64)i + 2] - oz) * sc2);
-                    const float* f = inp_feat + (i64)i * cin + c0;
-                    f0 = w * f[0];
-                    if (c0 + 1 < cin) f1 = w * f[1];
-                    if (c0 + 2 < cin) f2 = w * f[2];
-                    if (c0 + 3 < cin) f3 = w * f[3];
-                }
-                for (int j = 0; j < cnt; ++j) {
-                    const float ax = __shfl(g.ax, j, 64), ay = __shfl(g.ay, j, 64), az = __shfl(g.az, j, 64);
-                    const int x0 = __shfl(g.x0, j, 64), y0 = __shfl(g.y0, j, 64), z0 = __shfl(g.z0, j, 64);
-                    const int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
-                    // this lane's trilinear weight (sums both corners when x0 == x1 at the border)
-                    const float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
-                    const float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
-                    const float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
-                    const float wt = wx * wy * wz;  // same association as the oracle
-                    norm += __shfl(w, j, 64);
-                    B0 += wt * __shfl(f0, j, 64);
-                    B1 += wt * __shfl(f1, j, 64);
-                    B2 += wt * __shfl(f2, j, 64);
-                    B3 += wt * __shfl(f3, j, 64);
-                }
-            }
-            // contraction: out[o] (+)= sum_cells sum_c W[cell][c0+c][o] * B_c, one o per lane
-            const float* wl = &s_f[lane * LSTR];
-            float mine = 0.f;
-#pragma unroll
-            for (int o4 = 0; o4 < COUT_MAX; o4 += 4) {
-                const float4 w0 = *reinterpret_cast<const float4*>(wl + o4);
-                const float4 w1 = *reinterpret_cast<const float4*>(wl + COUT_MAX + o4);
-                const float4 w2 = *reinterpret_cast<const float4*>(wl + 2 * COUT_MAX + o4);
-                const float4 w3 = *reinterpret_cast<const float4*>(wl + 3 * COUT_MAX + o4);
-                float s0 = w0.x * B0 + w1.x * B1 + w2.x * B2 + w3.x * B3;
-                float s1 = w0.y * B0 + w1.y * B1 + w2.y * B2 + w3.y * B3;
-                float s2 = w0.z * B0 + w1.z * B1 + w2.z * B2 + w3.z * B3;
-                float s3 = w0.w * B0 + w1.w * B1 + w2.w * B2 + w3.w * B3;
-                s0 = wave_reduce_sum(s0);
-                s1 = wave_reduce_sum(s1);
-                s2 = wave_reduce_sum(s2);
-                s3 = wave_reduce_sum(s3);
-                mine = lane == o4 ? s0 : lane == o4 + 1 ? s1 : lane == o4 + 2 ? s2 : lane == o4 + 3 ? s3 : mine;
-            }
-            if (lane < cout) {
-                float r = mine;
-                if (c0 > 0) r += orow[lane];  // wider inputs: accumulate the raw sums over chunks
+            float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
+            for (i64 p0 = b; p0 < e; p0 += 64)
+                cconv_batch(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane,
+                            cin, c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
+            float r = cconv_contract<COUT_MAX>(&s_f[lane * LSTR], B0, B1, B2, B3, lane);
+            const float norm = wave_reduce_sum(norm_lane);
+            if (writer) {
+                if (c0 > 0) r += orow[my_o];  // wider inputs: accumulate the raw sums over chunks
                 if (c0 + 4 >= cin) {
                     if (normalize && norm != 0.f) r = r / norm;
-                    r += bias_l;
+                    r += bias_o;
                     if (relu) r = fmaxf(r, 0.f);
                 }
-                orow[lane] = r;
+                orow[my_o] = r;
             }
         }
     }
@@ -183,8 +208,8 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
 // ------------------------------------------------------------------------------------------
 // a10, long rows: a coarse voxel next to the surface can have tens of thousands of neighbours
 // while the mean is ~15.  Rows above CCONV_HEAVY pairs are collected and handled by one
-// 1024-thread block each: the 16 waves take interleaved pairs, partial B sums are combined
-// through LDS in wave order (deterministic), wave 0 does the contraction.
+// 1024-thread block each: the 16 waves take interleaved 64-pair batches, partial B sums are
+// combined through LDS in wave order (deterministic), wave 0 does the contraction.
 // ------------------------------------------------------------------------------------------
 constexpr i64 CCONV_HEAVY = 1024;
 __global__ void k_cconv_heavy_list(const i64* rs, i64 num_out, i64 thr, int32_t* list, int* count) {
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
     __shared__ float s_norm[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 q = list[blockIdx.x];
-    const int cx = lane & 3, cy = (lane >> 2) & 3, cz = lane >> 4;
+    const float cxf = (float)(lane & 3), cyf = (float)((lane >> 2) & 3), czf = (float)(lane >> 4);
     const i64 b = rs[q], e = rs[q + 1];
     const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
     const float sc2 = 2.f * (1.f / extents[q]);
@@ -214,43 +239,11 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
     for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
     float norm_total = 0.f;
     for (int c0 = 0; c0 < cin; c0 += 4) {
-        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm = 0.f;
-        for (i64 p = b + wave; p < e; p += 16) {
-            const int32_t i = nidx[p];
-            const float w = nimp ? nimp[p] : 1.f;
-            norm += w;
-            float dx = (inp_pos[3 * (i64)i] - ox) * sc2;
-            float dy = (inp_pos[3 * (i64)i + 1] - oy) * sc2;
-            float dz = (inp_pos[3 * (i64)i + 2] - oz) * sc2;
-            float r = sqrtf(dx * dx + dy * dy + dz * dz);
-            float m = fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz)));
-            if (m < 1e-8f) {
-                dx = dy = dz = 0.f;
-            } else {
-                float s = 0.5f * r / m;
-                dx *= s;
-                dy *= s;
-                dz *= s;
-            }
-            float ux = fminf(fmaxf((dx + 0.5f) * 3.f, 0.f), 3.f);
-            float uy = fminf(fmaxf((dy + 0.5f) * 3.f, 0.f), 3.f);
-            float uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
-            float fx = floorf(ux), fy = floorf(uy), fz = floorf(uz);
-            int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-            int x1 = min(x0 + 1, 3), y1 = min(y0 + 1, 3), z1 = min(z0 + 1, 3);
-            float ax = ux - fx, ay = uy - fy, az = uz - fz;
-            float wx = (cx == x0 ? 1.f - ax : 0.f) + (cx == x1 ? ax : 0.f);
-            float wy = (cy == y0 ? 1.f - ay : 0.f) + (cy == y1 ? ay : 0.f);
-            float wz = (cz == z0 ? 1.f - az : 0.f) + (cz == z1 ? az : 0.f);
-            float wt = wx * wy * wz;
-            if (wt != 0.f) {
-                const float* f = inp_feat + (i64)i * cin + c0;
-                B0 += wt * (w * f[0]);
-                if (c0 + 1 < cin) B1 += wt * (w * f[1]);
-                if (c0 + 2 < cin) B2 += wt * (w * f[2]);
-                if (c0 + 3 < cin) B3 += wt * (w * f[3]);
-            }
-        }
+        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
+        for (i64 p0 = b + 64 * (i64)wave; p0 < e; p0 += 64 * 16)
+            cconv_batch(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane, cin,
+                        c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
+        const float norm = wave_reduce_sum(norm_lane);
         __syncthreads();  // previous chunk's partials consumed
         s_part[wave][lane][0] = B0;
         s_part[wave][lane][1] = B1;

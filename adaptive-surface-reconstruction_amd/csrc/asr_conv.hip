@@ -3,6 +3,8 @@
 //   a12 sparse conv (gather -> f32 MFMA 16x16x4, slot-skipping row tiles; scalar reference
 //       kernel for odd shapes and cross-checking),
 //   importance sums, a14 decoder MLP.
+#include <cstdlib>
+
 #include "asr_common.h"
 
 namespace {
@@ -79,73 +81,31 @@ __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const floa
         if (c0 + 2 < cin) f2 = w * f[2];
         if (c0 + 3 < cin) f3 = w * f[3];
     }
+    // v_readlane with a uniform lane index: a scalar broadcast, not an LDS round trip (ds_bpermute)
+#define ASR_BCAST(x_) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_), j))
     for (int j = 0; j < cnt; ++j) {
-        const float wx = fmaxf(0.f, 1.f - fabsf(__shfl(ux, j, 64) - cxf));
-        const float wy = fmaxf(0.f, 1.f - fabsf(__shfl(uy, j, 64) - cyf));
-        const float wz = fmaxf(0.f, 1.f - fabsf(__shfl(uz, j, 64) - czf));
+        const float wx = fmaxf(0.f, 1.f - fabsf(ASR_BCAST(ux) - cxf));
+        const float wy = fmaxf(0.f, 1.f - fabsf(ASR_BCAST(uy) - cyf));
+        const float wz = fmaxf(0.f, 1.f - fabsf(ASR_BCAST(uz) - czf));
         const float wt = wx * wy * wz;
-        B0 += wt * __shfl(f0, j, 64);
-        B1 += wt * __shfl(f1, j, 64);
-        B2 += wt * __shfl(f2, j, 64);
-        B3 += wt * __shfl(f3, j, 64);
+        B0 += wt * ASR_BCAST(f0);
+        B1 += wt * ASR_BCAST(f1);
+        B2 += wt * ASR_BCAST(f2);
+        B3 += wt * ASR_BCAST(f3);
     }
-}
-
-// out[o] (+)= sum over the 64 cells of sum_c W[cell][c][o] * B_c for o < COUT_MAX, with this lane's
-// cell row `wl` in LDS.  Reduce-scatter butterfly: 32 + 16 + ... exchanges instead of one full wave
-// reduction per output channel.  Returns the value of output channel cconv_lane_channel(lane)
-// (valid in every lane; lanes l and l^1... hold duplicates when COUT_MAX < 64).
-template <int COUT_MAX>
-__device__ inline float cconv_contract(const float* wl, float B0, float B1, float B2, float B3, int lane) {
-    float v[COUT_MAX];
-#pragma unroll
-    for (int o4 = 0; o4 < COUT_MAX; o4 += 4) {
-        const float4 w0 = *reinterpret_cast<const float4*>(wl + o4);
-        const float4 w1 = *reinterpret_cast<const float4*>(wl + COUT_MAX + o4);
-        const float4 w2 = *reinterpret_cast<const float4*>(wl + 2 * COUT_MAX + o4);
-        const float4 w3 = *reinterpret_cast<const float4*>(wl + 3 * COUT_MAX + o4);
-        v[o4 + 0] = w0.x * B0 + w1.x * B1 + w2.x * B2 + w3.x * B3;
-        v[o4 + 1] = w0.y * B0 + w1.y * B1 + w2.y * B2 + w3.y * B3;
-        v[o4 + 2] = w0.z * B0 + w1.z * B1 + w2.z * B2 + w3.z * B3;
-        v[o4 + 3] = w0.w * B0 + w1.w * B1 + w2.w * B2 + w3.w * B3;
-    }
-    // halve the number of live values at every step: lanes with bit `m` set keep the upper half
-    int n = COUT_MAX;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        if (n > 1) {
-            const bool up = (lane & m) != 0;
-#pragma unroll
-            for (int i = 0; i < COUT_MAX / 2; ++i) {
-                if (i < n / 2) {
-                    const float send = up ? v[i] : v[i + n / 2];
-                    const float keep = up ? v[i + n / 2] : v[i];
-                    v[i] = keep + __shfl_xor(send, m, 64);
-                }
-            }
-            n >>= 1;
-        } else {
-            v[0] += __shfl_xor(v[0], m, 64);
-        }
-    }
-    return v[0];
-}
-// output channel whose sum cconv_contract leaves in `lane`
-template <int COUT_MAX>
-__device__ inline int cconv_lane_channel(int lane) {
-    int o = 0, n = COUT_MAX;
-    for (int m = 32; m >= 1 && n > 1; m >>= 1) {
-        n >>= 1;
-        if (lane & m) o += n;
-    }
-    return o;
+#undef ASR_BCAST
 }
 
 // One wave per output voxel, persistent blocks (grid-stride over voxels).  The 4-channel slice
-// of the filter, [64 cells][4][COUT_MAX] zero padded, is staged in LDS once per block (a guarded
-// global load per filter element costs a vmcnt(0) round trip each: 128 per voxel).
+// of the filter is staged in LDS once per block as [cell][cout][4] (a guarded global load per
+// filter element costs a vmcnt(0) round trip each: 128 per voxel).
+// Contraction out[o] = sum_cell sum_c W[cell][c][o] * B[cell][c]: the wave writes its B (one
+// float4 per lane = cell) to LDS, then lane (part, o) with part = lane / COUT_MAX sums the cells of
+// its part (broadcast B reads, contiguous W reads) and log2(64 / COUT_MAX) shuffles join the parts.
+// (A per-lane partial product followed by a 32-value reduce-scatter butterfly was measured at
+// 6.4 ms of this kernel's 9.8 ms on the 10 M cloud.)
 template <int COUT_MAX>
-__global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters,
+__global__ __launch_bounds__(512) void k_cconv(const float* __restrict__ filters,
                                                const float* __restrict__ out_pos,
                                                const float* __restrict__ extents,
                                                const float* __restrict__ inp_pos,
@@ -156,23 +116,27 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
                                                int cout, int normalize,
                                                const float* __restrict__ bias, int relu,
                                                float* __restrict__ out, i64 heavy_rows) {
-    constexpr int LSTR = 4 * COUT_MAX + 4;  // lane stride in floats: conflict-free ds_read_b128
-    __shared__ __attribute__((aligned(16))) float s_f[64 * LSTR];
-    const int lane = threadIdx.x & 63;
+    constexpr int PARTS = 64 / COUT_MAX;      // lane = (part, o)
+    constexpr int CELLS = 64 / PARTS;         // cells summed by one lane
+    __shared__ __attribute__((aligned(16))) float4 s_f[64 * COUT_MAX];  // [cell][o] -> 4 channels
+    __shared__ __attribute__((aligned(16))) float4 s_b[8][64];           // per wave: B[cell]
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const float cxf = (float)(lane & 3), cyf = (float)((lane >> 2) & 3), czf = (float)(lane >> 4);
     const i64 wave0 = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
     const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
-    const int my_o = cconv_lane_channel<COUT_MAX>(lane);
-    const bool writer = my_o < cout && (COUT_MAX == 64 || (lane & (64 / COUT_MAX - 1)) == 0);
+    const int my_o = lane % COUT_MAX, part = lane / COUT_MAX;
+    const bool writer = part == 0 && my_o < cout;
     const float bias_o = (bias && my_o < cout) ? bias[my_o] : 0.f;
 
     for (int c0 = 0; c0 < cin; c0 += 4) {
         __syncthreads();
-        for (int e = threadIdx.x; e < 64 * 4 * COUT_MAX; e += blockDim.x) {
-            int cell = e / (4 * COUT_MAX), c = (e / COUT_MAX) % 4, o = e % COUT_MAX;
-            bool ok = c0 + c < cin && o < cout;
-            s_f[cell * LSTR + c * COUT_MAX + o] =
-                    ok ? filters[((i64)cell * cin + c0 + c) * cout + o] : 0.f;
+        for (int e = threadIdx.x; e < 64 * COUT_MAX; e += blockDim.x) {
+            const int cell = e / COUT_MAX, o = e % COUT_MAX;
+            float w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                w[c] = (c0 + c < cin && o < cout) ? filters[((i64)cell * cin + c0 + c) * cout + o] : 0.f;
+            s_f[e] = make_float4(w[0], w[1], w[2], w[3]);
         }
         __syncthreads();
         for (i64 q = wave0; q < num_out; q += nwaves) {
@@ -190,8 +154,20 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
             for (i64 p0 = b; p0 < e; p0 += 64)
                 cconv_batch(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane,
                             cin, c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
-            float r = cconv_contract<COUT_MAX>(&s_f[lane * LSTR], B0, B1, B2, B3, lane);
+            s_b[wib][lane] = make_float4(B0, B1, B2, B3);
             const float norm = wave_reduce_sum(norm_lane);
+            __builtin_amdgcn_wave_barrier();  // LDS ops of one wave complete in order
+            float r = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < CELLS; ++i) {
+                const int cell = part * CELLS + i;
+                const float4 bb = s_b[wib][cell];
+                const float4 ww = s_f[cell * COUT_MAX + my_o];
+                r += ww.x * bb.x + ww.y * bb.y + ww.z * bb.z + ww.w * bb.w;
+            }
+#pragma unroll
+            for (int m = COUT_MAX; m < 64; m <<= 1) r += __shfl_xor(r, m, 64);
+            __builtin_amdgcn_wave_barrier();
             if (writer) {
                 if (c0 > 0) r += orow[my_o];  // wider inputs: accumulate the raw sums over chunks
                 if (c0 + 4 >= cin) {
@@ -211,7 +187,7 @@ __global__ __launch_bounds__(256) void k_cconv(const float* __restrict__ filters
 // 1024-thread block each: the 16 waves take interleaved 64-pair batches, partial B sums are
 // combined through LDS in wave order (deterministic), wave 0 does the contraction.
 // ------------------------------------------------------------------------------------------
-constexpr i64 CCONV_HEAVY = 1024;
+constexpr i64 CCONV_HEAVY = 256;
 __global__ void k_cconv_heavy_list(const i64* rs, i64 num_out, i64 thr, int32_t* list, int* count) {
     i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (q >= num_out) return;
@@ -673,7 +649,9 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     if (num_out <= 0) return ASR_HIP_OK;
     if (cout < 1 || cout > 64) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cout must be 1..64");
     if (cin < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cin must be >= 1");
-    unsigned blocks = grid_for(num_out * 64, 256);
+    // 512-thread blocks, <= 4 per CU: 32 waves per CU hide the dependent row_splits -> index ->
+    // position load chain of every voxel
+    unsigned blocks = grid_for(num_out * 64, 512);
     if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: the filter slice is staged once per block
     // long rows: collect, then one 1024-thread block per row
     int32_t* heavy = arena_alloc<int32_t>(ctx->scratch, (size_t)num_out);
@@ -684,7 +662,7 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
                                                                       d_count);
     ASR_CHECK_LAUNCH(ctx);
 #define ASR_LAUNCH_CCONV(C_)                                                                      \
-    k_cconv<C_><<<blocks, 256, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, \
+    k_cconv<C_><<<blocks, 512, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, \
                                                  nimp, rs, num_out, cin, cout, normalize, bias,    \
                                                  relu, out, CCONV_HEAVY);
 #define ASR_LAUNCH_CCONV_HEAVY(C_)                                                                 \

@@ -420,10 +420,18 @@ __device__ inline int query_level(const asr_octree_frame& f, float r) {
 }
 __global__ void k_query_levels(asr_octree_frame f, const float* sizes, i64 v, int* cnt) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (i >= v) return;
-    int lev = query_level(f, sizes[i]);
-    atomicMin(&cnt[6], lev);
-    atomicMax(&cnt[7], lev);
+    int lo = ASR_MAX_LEVEL, hi = 0;
+    if (i < v) lo = hi = query_level(f, sizes[i]);
+    // one atomic pair per wave instead of per thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o, 64));
+        hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&cnt[6], lo);
+        atomicMax(&cnt[7], hi);
+    }
 }
 // boundaries of the sorted code array: cell (prefix,level) starts / ends at i
 template <bool COUNT_ONLY>

@@ -74,6 +74,22 @@ def job_value(world, points_per_rank, steps, dt):
     return world * points_per_rank * steps / dt
 
 
+def pmc_traffic(points):
+    """HBM bytes per sparse-conv launch from the committed rocprofv3 PMC passes of this very command
+    (profiles/r*_pmc_traffic.json, produced by scripts/make_profiles.sh); PMC counters cannot be
+    collected from inside the timed process.  None when no matching profile is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("points", 10_000_000) == points:
+            best = (d["hbm_bytes_per_launch"], os.path.basename(path))
+    return best
+
+
 def cpu_baseline(n_sample, seed):
     """the oracle ("port" of the reference path incl. the Open3D op semantics) timed on the host
     cores on a bounded sample of the same workload generator"""
@@ -162,6 +178,7 @@ def main():
         flops, launches = conv_flops(pipe.sizes, shapes)
         unet_s = stage_ms["unet"] * 1e-3
         achieved = flops / unet_s / 1e12 if unet_s > 0 else 0.0
+        tr = pmc_traffic(n)
         out = {
             "metric": "input points/sec to signed implicit values",
             "value": job_value(world, n, steps, dt),
@@ -184,7 +201,9 @@ def main():
                        "parallelism": "one scan per GPU, no collective on the data path",
                        "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": tr[0] if tr else None,
+                         "traffic_note": ("HBM bytes per launch, rocprofv3 PMC passes in profiles/%s" % tr[1]) if tr else None,
                          "kernel": "k_sconv_mfma (53 launches/step, %.3f ms avg, %.1f algorithmic "
                                    "GFLOP/step)" % (stage_ms["unet"] / launches, flops / 1e9)},
         }

@@ -130,6 +130,32 @@ def remove_connected_components(vertices, triangles, keep_n_largest_components,
 
 
 class KDTree:
+    """cpp/pybind/module.cpp:237-277,455-489 -> asr::KDTree (cpp/lib/nsearch.cpp:23-105).  The
+    reference builds a nanoflann tree; here the points are Morton sorted on the GPU and all three
+    queries are exact grid searches (asr_hip_knn_radius / asr_hip_radius_neighbor_count)."""
 
     def __init__(self, points):
-        _next_row("KDTree", "cpp/lib/nsearch.cpp:23-105")
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        if points.ndim != 2 or points.shape[1] != 3:
+            raise ValueError("points must have shape [N,3]")
+        self._points = torch.from_numpy(points).to(torch.device("cuda"))
+        lo, hi = points.min(0), points.max(0)
+        m = max(1e-3, 1e-3 * float((hi - lo).max()))
+        self._frame = _lib.frame_init(lo - np.float32(m), hi + np.float32(m))
+
+    def compute_k_radius(self, k):
+        return _ops.knn_radius(self._frame, self._points, k).cpu().numpy()
+
+    def compute_inlier(self, radii, radius_fraction=0.5, k=24, outlier_threshold=1):
+        radii = np.ascontiguousarray(radii, dtype=np.float32)
+        if radii.ndim != 1 or radii.shape[0] != self._points.shape[0]:
+            raise ValueError("radii must have shape [num_points]")
+        _, inl = _ops.knn_radius(self._frame, self._points, k, torch.from_numpy(radii).to(self._points.device),
+                                 radius_fraction, outlier_threshold, want_inlier=True)
+        return inl.cpu().numpy()
+
+    def compute_radius_neighbors(self, radii):
+        radii = np.ascontiguousarray(radii, dtype=np.float32)
+        cnt = _ops.radius_neighbor_count(self._frame, self._points,
+                                         torch.from_numpy(radii).to(self._points.device))
+        return [int(c) for c in cnt.cpu().tolist()]

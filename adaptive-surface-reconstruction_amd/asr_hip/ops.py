@@ -125,6 +125,29 @@ def multi_radius_search(frame, points, radii, centers, sizes):
     return idx, dist, rs, compat
 
 
+def knn_radius(frame, points, k, radii=None, radius_fraction=0.5, outlier_threshold=1,
+               want_inlier=False):
+    """KDTree.compute_k_radius / compute_inlier (cpp/lib/nsearch.cpp:30-86) -> radii[, inlier]"""
+    points = _dev(points, torch.float32)
+    n = points.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=points.device)
+    rin = _dev(radii, torch.float32) if radii is not None else None
+    inl = torch.empty(n, dtype=torch.uint8, device=points.device) if want_inlier else None
+    context().call("asr_hip_knn_radius", ctypes.byref(frame), ptr(points), i64(n), int(k), ptr(rin),
+                   ctypes.c_float(radius_fraction), int(outlier_threshold), ptr(out), ptr(inl))
+    return (out, inl.bool()) if want_inlier else out
+
+
+def radius_neighbor_count(frame, points, radii):
+    """KDTree.compute_radius_neighbors (cpp/lib/nsearch.cpp:88-105)"""
+    points = _dev(points, torch.float32)
+    radii = _dev(radii, torch.float32)
+    out = torch.empty(points.shape[0], dtype=torch.int64, device=points.device)
+    context().call("asr_hip_radius_neighbor_count", ctypes.byref(frame), ptr(points), ptr(radii),
+                   i64(points.shape[0]), ptr(out))
+    return out
+
+
 def aggregation_importance(compat, dist):
     compat = _dev(compat, torch.float32)
     dist = _dev(dist, torch.float32)

@@ -192,6 +192,26 @@ int asr_hip_multi_radius_search_fill(asr_hip_context* ctx, const float* points, 
                                 dist_out, compat_out);
 }
 
+int asr_hip_knn_radius(asr_hip_context* ctx, const asr_octree_frame* frame, const float* points,
+                       int64_t n, int k, const float* radii_in, float radius_fraction,
+                       int outlier_threshold, float* radii_out, uint8_t* inlier_out) {
+    CTX_GUARD(ctx);
+    if (!frame || n < 0 || (n > 0 && !points) || (inlier_out && !radii_in))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "knn_radius: null argument");
+    ctx->scratch.reset();
+    return asr_geom_knn(ctx, frame, points, n, k, radii_in, radius_fraction, outlier_threshold, radii_out,
+                        inlier_out);
+}
+int asr_hip_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame* frame,
+                                  const float* points, const float* radii, int64_t n,
+                                  int64_t* counts_out) {
+    CTX_GUARD(ctx);
+    if (!frame || n < 0 || (n > 0 && (!points || !radii || !counts_out)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "radius_neighbor_count: null argument");
+    ctx->scratch.reset();
+    return asr_geom_radius_neighbor_count(ctx, frame, points, radii, n, counts_out);
+}
+
 int asr_hip_continuous_conv_f32(asr_hip_context* ctx, const float* filters, const float* out_pos,
                                 const float* extents, const float* inp_pos, const float* inp_feat,
                                 const int32_t* nidx, const float* nimp, const int64_t* rs,

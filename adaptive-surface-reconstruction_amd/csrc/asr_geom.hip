@@ -558,6 +558,135 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     }
     if (MODE == 0 && lane == 0) counts[q] = found;
 }
+// Exact k-th nearest neighbour distance, one wave per point (in Morton order).  Level by level,
+// finest first: lanes 0..26 look up the 3^3 cells around the point's cell; if they hold >= k points
+// the k-th smallest squared distance d_k among them is selected; it is exact as soon as
+// d_k <= (cell size)^2, because every point closer than one cell size lies inside the 3^3 block.
+// Selection: binary search on the bit pattern of the (non-negative) squared distances with wave
+// ballots; up to 512 candidates are held in registers, larger sets are streamed from memory.
+__global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* sorted, i64 n, HashTab t,
+                                             const int32_t* start, const int32_t* end, int lfine, int k,
+                                             const float* radii_in, float radius_fraction,
+                                             int outlier_threshold, float* radii_out,
+                                             uint8_t* inlier_out) {
+    constexpr int CMAX = 8;
+    __shared__ int s_pref[4][28];
+    __shared__ int s_beg[4][28];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 s = blockIdx.x * (i64)4 + wave;
+    if (s >= n) return;
+    const float4 me = sorted[s];
+    const int kk = (int)(n < k ? n : k);
+    u32 kth_bits = 0;
+    int total = 0;
+    for (int lev = lfine; lev >= 0; --lev) {
+        int x, y, z;
+        frame_coord(f, me.x, me.y, me.z, lev, x, y, z);
+        const int lim = (1 << lev) - 1;
+        x = min(max(x, 0), lim);  // points outside the root cube were clamped into it
+        y = min(max(y, 0), lim);
+        z = min(max(z, 0), lim);
+        int b = 0, cnt = 0;
+        if (lane < 27) {
+            int xx = x + lane % 3 - 1, yy = y + (lane / 3) % 3 - 1, zz = z + lane / 9 - 1;
+            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim) {
+                i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | (u64(1) << (3 * lev)));
+                if (slot >= 0) {
+                    b = start[slot];
+                    cnt = end[slot] - b;
+                }
+            }
+        }
+        int pre = cnt;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            int up = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += up;
+        }
+        total = __shfl(pre, 26, 64);
+        if (total < kk && lev > 0) continue;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 27) {
+            s_pref[wave][lane + 1] = pre;
+            s_beg[wave][lane] = b;
+        }
+        if (lane == 0) s_pref[wave][0] = 0;
+        __builtin_amdgcn_wave_barrier();
+        auto cand = [&](int i) -> float {
+            int lo = 0, hi = 27;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (s_pref[wave][mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            const float4 pt = sorted[s_beg[wave][lo] + (i - s_pref[wave][lo])];
+            return sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z);
+        };
+        const int need = total < kk ? total : kk;  // lev == 0 with fewer than k points overall
+        u32 lo_bits = 0;
+        if (total <= 64 * CMAX) {
+            float d[CMAX];
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                const int i = c * 64 + lane;
+                d[c] = i < total ? cand(i) : __uint_as_float(0x7f800000u);
+            }
+            // largest bit pattern t with #{d < t} < need  ==  the need-th smallest value
+            for (int bit = 30; bit >= 0; --bit) {
+                const u32 trial = lo_bits | (1u << bit);
+                int c_lt = 0;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) c_lt += __popcll(__ballot(__float_as_uint(d[c]) < trial));
+                if (c_lt < need) lo_bits = trial;
+            }
+        } else {
+            for (int bit = 30; bit >= 0; --bit) {
+                const u32 trial = lo_bits | (1u << bit);
+                int c_lt = 0;
+                for (int i0 = 0; i0 < total; i0 += 64) {
+                    const int i = i0 + lane;
+                    const bool lt = i < total && __float_as_uint(cand(i)) < trial;
+                    c_lt += __popcll(__ballot(lt));
+                }
+                if (c_lt < need) lo_bits = trial;
+            }
+        }
+        kth_bits = lo_bits;
+        const float cs = f.voxel_size[lev];
+        if (lev == 0 || __uint_as_float(kth_bits) <= cs * cs) {
+            // exact.  Optional inlier vote (KDTree::ComputeInlier): neighbours among the k nearest
+            // whose radius is below radius_fraction * radius_i
+            if (inlier_out) {
+                const float thr = radii_in[__float_as_int(me.w)] * radius_fraction;
+                int votes = 0;
+                for (int i0 = 0; i0 < total; i0 += 64) {
+                    const int i = i0 + lane;
+                    bool v = false;
+                    if (i < total) {
+                        int lo = 0, hi = 27;
+                        while (hi - lo > 1) {
+                            int mid = (lo + hi) >> 1;
+                            if (s_pref[wave][mid] <= i)
+                                lo = mid;
+                            else
+                                hi = mid;
+                        }
+                        const float4 pt = sorted[s_beg[wave][lo] + (i - s_pref[wave][lo])];
+                        const float dd = sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z);
+                        v = __float_as_uint(dd) <= kth_bits && radii_in[__float_as_int(pt.w)] < thr;
+                    }
+                    votes += __popcll(__ballot(v));
+                }
+                if (lane == 0) inlier_out[__float_as_int(me.w)] = votes < outlier_threshold ? 1 : 0;
+            }
+            break;
+        }
+    }
+    if (lane == 0 && radii_out) radii_out[__float_as_int(me.w)] = sqrtf(__uint_as_float(kth_bits));
+}
+
 // rows are sorted by a segmented radix sort on (distance bits, index) keys; unpack + compat
 __global__ void k_radius_unpack(const u64* keys, const int32_t* rows, i64 num_pairs,
                                 const float* sizes, const float* radii, int32_t* idx, float* dist,
@@ -932,23 +1061,13 @@ void asr_geom_release(asr_hip_context* ctx) {
     ctx->radius_state = nullptr;
 }
 
-int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                          i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
-                          i64* num_pairs) {
-    ASR_TRY(ensure_flags(ctx));
-    RadiusState& st = rstate(ctx);
-    st.valid = false;
-    if (v <= 0) {
-        *num_pairs = 0;
-        if (rs) ASR_HIP_CHECK(ctx, hipMemsetAsync(rs, 0, sizeof(i64), ctx->stream));
-        return ASR_HIP_OK;
-    }
-    if (n >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many points for int32 indices");
+// points sorted by level-21 Morton code + hash map (cell, level) -> [start, end) for levels
+// lmin..lmax; everything lives in the scratch arena
+static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                             i64 n, int lmin, int lmax, RadiusState& st) {
     int host[16];
     st.frame = *frame;
     st.n = n;
-    st.v = v;
-    // sort points by code
     u64* codes_u = arena_alloc<u64>(ctx->scratch, n + 1);
     u64* codes = arena_alloc<u64>(ctx->scratch, n + 1);
     int32_t* ids_u = arena_alloc<int32_t>(ctx->scratch, n + 1);
@@ -963,16 +1082,7 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted);
         ASR_CHECK_LAUNCH(ctx);
     }
-    // level range of the queries
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
-    int init[2] = {ASR_MAX_LEVEL, 0};
-    ASR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_flags + 6, init, 2 * sizeof(int),
-                                      hipMemcpyHostToDevice, ctx->stream));
-    k_query_levels<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(*frame, sizes, v, ctx->d_flags);
-    ASR_CHECK_LAUNCH(ctx);
-    ASR_TRY(read_flags(ctx, host));
-    int lmin = host[6], lmax = host[7];
-    // cell table
     HashTab dummy{nullptr, nullptr, 0};
     if (n > 0) {
         k_cell_bounds<true><<<grid_for(n + 1, BLK), BLK, 0, ctx->stream>>>(
@@ -990,6 +1100,41 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
                 codes, n, lmin, lmax, st.tab, st.start, st.end, ctx->d_flags);
         ASR_CHECK_LAUNCH(ctx);
     }
+    return ASR_HIP_OK;
+}
+
+static int query_level_range(asr_hip_context* ctx, const asr_octree_frame* frame, const float* sizes,
+                             i64 v, int* lmin, int* lmax) {
+    int host[16];
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    int init[2] = {ASR_MAX_LEVEL, 0};
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_flags + 6, init, 2 * sizeof(int),
+                                      hipMemcpyHostToDevice, ctx->stream));
+    k_query_levels<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(*frame, sizes, v, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(read_flags(ctx, host));
+    *lmin = host[6];
+    *lmax = host[7];
+    return ASR_HIP_OK;
+}
+
+int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                          i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
+                          i64* num_pairs) {
+    ASR_TRY(ensure_flags(ctx));
+    RadiusState& st = rstate(ctx);
+    st.valid = false;
+    if (v <= 0) {
+        *num_pairs = 0;
+        if (rs) ASR_HIP_CHECK(ctx, hipMemsetAsync(rs, 0, sizeof(i64), ctx->stream));
+        return ASR_HIP_OK;
+    }
+    if (n >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many points for int32 indices");
+    int host[16];
+    st.v = v;
+    int lmin, lmax;
+    ASR_TRY(query_level_range(ctx, frame, sizes, v, &lmin, &lmax));
+    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st));
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     k_radius_query<0><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(
@@ -1001,6 +1146,52 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     ASR_TRY(read_flags(ctx, host));
     if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search cell table overflow");
     st.valid = true;
+    return ASR_HIP_OK;
+}
+
+// KDTree::ComputeRadiusNeighbors (cpp/lib/nsearch.cpp:88-105): per point the number of points with
+// squared distance < radius_i^2 (the point itself included)
+int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                                   const float* radii, i64 n, i64* counts_out) {
+    ASR_TRY(ensure_flags(ctx));
+    if (n <= 0) return ASR_HIP_OK;
+    if (n >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many points for int32 indices");
+    RadiusState st;
+    int host[16], lmin, lmax;
+    ASR_TRY(query_level_range(ctx, frame, radii, n, &lmin, &lmax));
+    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st));
+    i64* counts = arena_alloc<i64>(ctx->scratch, n + 1);
+    if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_radius_query<0><<<grid_for(n + 1, 4), BLK, 0, ctx->stream>>>(
+            *frame, st.sorted, pts, radii, n, st.tab, st.start, st.end, counts, nullptr, nullptr, nullptr);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, counts, n * sizeof(i64), hipMemcpyDeviceToDevice,
+                                      ctx->stream));
+    ASR_TRY(read_flags(ctx, host));
+    if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "cell table overflow");
+    return ASR_HIP_OK;
+}
+
+// KDTree::ComputeKRadius / ComputeInlier (cpp/lib/nsearch.cpp:30-86)
+int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts, i64 n, int k,
+                 const float* radii_in, float radius_fraction, int outlier_threshold, float* radii_out,
+                 uint8_t* inlier_out) {
+    ASR_TRY(ensure_flags(ctx));
+    if (n <= 0) return ASR_HIP_OK;
+    if (k < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "knn: k must be >= 1");
+    if (n >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many points for int32 indices");
+    // finest level: about one point per cell if the cloud filled the cube
+    int lfine = 1;
+    while (lfine < ASR_MAX_LEVEL - 1 && (i64(1) << (3 * lfine)) < n) ++lfine;
+    RadiusState st;
+    int host[16];
+    ASR_TRY(build_point_index(ctx, frame, pts, n, 0, lfine, st));
+    k_knn<<<grid_for(n, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lfine, k,
+                                                   radii_in, radius_fraction, outlier_threshold, radii_out,
+                                                   inlier_out);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(read_flags(ctx, host));
+    if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "cell table overflow");
     return ASR_HIP_OK;
 }
 

@@ -120,6 +120,19 @@ int asr_hip_multi_radius_search_fill(asr_hip_context* ctx, const float* points_d
                                      int32_t* index_out_dev, float* dist_out_dev,
                                      float* compat_out_dev);
 
+/* ---- pre-filter ("next" row D.4): asr::KDTree (cpp/lib/nsearch.cpp:23-105) -------------------- */
+/* The frame only defines the acceleration grid; any box that contains the points works.
+ * radii_out[i] = distance to the k-th nearest neighbour, the point itself included (:30-51).
+ * If inlier_out is given, radii_in is required: inlier iff fewer than outlier_threshold of the k
+ * nearest neighbours have radius < radius_fraction * radii_in[i] (:54-86). */
+int asr_hip_knn_radius(asr_hip_context* ctx, const asr_octree_frame* frame, const float* points_dev,
+                       int64_t n, int k, const float* radii_in_dev, float radius_fraction,
+                       int outlier_threshold, float* radii_out_dev, uint8_t* inlier_out_dev);
+/* counts_out[i] = number of points with squared distance < radii[i]^2 (:88-105) */
+int asr_hip_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame* frame,
+                                  const float* points_dev, const float* radii_dev, int64_t n,
+                                  int64_t* counts_out_dev);
+
 /* ---- a10: open3d::continuous_conv as used by CConvAggregationBlock
  *      (models/v0/net_definitions_torch.py:53-70,107-116): kernel 4x4x4, align_corners,
  *      linear, ball_to_cube_radial, per-output extent, per-neighbour importance ------------ */

@@ -811,6 +811,31 @@ void orc_sparse_conv(const float* filters, const float* feat, i64 feat_ld, const
                      int cout, int normalize, float* out, i64 out_ld) {
     sparse_conv(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
 }
+// nsearch.cpp:30-51 KDTree::ComputeKRadius, brute force: radius_i = sqrt of the k-th smallest
+// squared distance (the point itself included), squared distances as in sqdist() above.
+void orc_knn_radius(const float* pts, i64 n, int k, float* out) {
+#pragma omp parallel
+    {
+        std::vector<float> d(n);
+#pragma omp for schedule(dynamic, 16)
+        for (i64 i = 0; i < n; ++i) {
+            for (i64 j = 0; j < n; ++j) d[j] = sqdist(pts + 3 * j, pts + 3 * i);
+            i64 kk = std::min<i64>(k, n) - 1;
+            std::nth_element(d.begin(), d.begin() + kk, d.end());
+            out[i] = std::sqrt(d[kk]);
+        }
+    }
+}
+// nsearch.cpp:88-105 KDTree::ComputeRadiusNeighbors: points with squared distance < r_i^2
+void orc_radius_count(const float* pts, i64 n, const float* radii, int32_t* out) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (i64 i = 0; i < n; ++i) {
+        float r2 = radii[i] * radii[i];
+        int32_t c = 0;
+        for (i64 j = 0; j < n; ++j) c += sqdist(pts + 3 * j, pts + 3 * i) < r2;
+        out[i] = c;
+    }
+}
 // nsearch.cpp:148-161 on caller supplied pairs (pinned by tests/golden/scale_compat.npz)
 void orc_scale_compat(const float* sizes, const float* radii, const int32_t* idx, const i64* rs,
                       i64 v, float* out) {

@@ -227,6 +227,23 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     return out
 
 
+def knn_radius(points, k):
+    """KDTree::ComputeKRadius (cpp/lib/nsearch.cpp:30-51), brute force"""
+    points = _f32(points)
+    out = np.zeros(points.shape[0], np.float32)
+    lib().orc_knn_radius(_p(points), i64(points.shape[0]), int(k), _p(out))
+    return out
+
+
+def radius_count(points, radii):
+    """KDTree::ComputeRadiusNeighbors (cpp/lib/nsearch.cpp:88-105), brute force"""
+    points = _f32(points)
+    radii = _f32(radii)
+    out = np.zeros(points.shape[0], np.int32)
+    lib().orc_radius_count(_p(points), i64(points.shape[0]), _p(radii), _p(out))
+    return out
+
+
 def scale_compat(voxel_sizes, radii, neighbors_index, row_splits):
     sizes = _f32(voxel_sizes)
     radii = _f32(radii)

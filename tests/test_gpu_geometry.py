@@ -199,6 +199,33 @@ def test_multi_radius_search_long_rows(gpu):
         assert np.array_equal(x.cpu().numpy(), y)
 
 
+def test_kdtree_prefilter_queries(gpu):
+    """KDTree mirror (cpp/pybind/module.cpp:455-489): exact k-th neighbour radius, inlier vote and
+    radius neighbour counts vs brute force"""
+    import adaptivesurfacereconstruction as asr
+    for kind, n, seed in (("scan", 6000, 5), ("mixed", 4000, 6), ("sphere", 3000, 7)):
+        pts, nrm, rad, bb = _cloud(kind, n, seed)
+        if kind == "sphere":
+            pts[:50] = pts[50:100]  # duplicates: zero distances and ties
+        tree = asr.KDTree(pts)
+        for k in (1, 24, 60):
+            r = tree.compute_k_radius(k)
+            ref = O.knn_radius(pts, k)
+            assert r.dtype == np.float32 and np.array_equal(r, ref), (kind, k, np.abs(r - ref).max())
+        r24 = O.knn_radius(pts, 24)
+        cnt = tree.compute_radius_neighbors(r24 * 1.3)
+        assert cnt == O.radius_count(pts, (r24 * 1.3).astype(np.float32)).tolist()
+        inl = tree.compute_inlier(r24, radius_fraction=0.9, k=24, outlier_threshold=3)
+        # brute force vote over the k nearest (squared distance <= k-th smallest)
+        d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2)
+        d2 = (d2[..., 0] + d2[..., 1]) + d2[..., 2]
+        kth = np.sort(d2, axis=1)[:, 23]
+        votes = ((d2 <= kth[:, None]) & (r24[None, :] < (r24 * np.float32(0.9))[:, None])).sum(1)
+        assert np.array_equal(inl, votes < 3)
+    with pytest.raises(ValueError):
+        asr.KDTree(pts[:, :2])
+
+
 def test_error_behaviour(gpu):
     from asr_hip import ops
     with pytest.raises(_lib.AsrHipError):

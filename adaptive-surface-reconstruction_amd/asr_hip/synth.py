@@ -129,6 +129,13 @@ def knn_radii(points, k=24):
     return d[:, -1].astype(np.float32)
 
 
+def knn_radii_gpu(points, k=24):
+    """the same radii on the GPU (asr_hip_knn_radius, exact): points is a CUDA tensor"""
+    from . import _lib, ops
+    mn, mx = bounding_box(points, 1e-3)
+    return ops.knn_radius(_lib.frame_init(mn, mx), points, k)
+
+
 def bounding_box(points, margin=0.1):
     """exact bbox widened by `margin` (models/v0/datareader.py:225-227)"""
     import torch

@@ -3,7 +3,7 @@
 
 Same function names, keyword defaults, numpy in / numpy out, ValueError for shape errors and
 RuntimeError from the library.  Everything runs on the MI355X through libasr_hip.so; the rows of
-SURVEY section 8 marked "next" (KDTree pre-filter, dual cells, contouring, component filter) raise
+SURVEY section 8 marked "next" that are not built yet (contouring, component filter) raise
 NotImplementedError instead of silently falling back to a CPU path.
 """
 import numpy as np
@@ -35,7 +35,10 @@ class Octree:
     """Opaque handle returned by create_octree (module.cpp:282): sorted node and leaf keys stay on
     the GPU together with the octree frame."""
 
+    _last = None
+
     def __init__(self, frame, nodes, leaves):
+        Octree._last = self
         self.frame = frame
         self.nodes = nodes
         self.leaves = leaves
@@ -112,7 +115,12 @@ def _next_row(what, where):
 
 
 def create_dual_vertex_indices(tree):
-    _next_row("create_dual_vertex_indices", "cpp/lib/grid.cpp:316-459")
+    """module.cpp:230-235,443-453 -> asr::CreateDualVertexIndices (cpp/lib/grid.cpp:450-459):
+    uint64 [D,8] indices into the leaves.  Must be called while `tree` is the octree built last on
+    this process' context (the node set lives there)."""
+    if tree is not Octree._last:
+        raise RuntimeError("create_dual_vertex_indices needs the most recently created octree")
+    return _ops.dual_cells(tree.leaves.device).cpu().numpy().astype(np.uint64)
 
 
 def reconstruct_surface(points, normals, radii=np.empty((0,), np.float32), point_radius_scale=1.0,

@@ -67,6 +67,17 @@ def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
     return nodes, leaves
 
 
+def dual_cells(device):
+    """dual_vertex_indices [D,8] (int64) of the octree built last on this context"""
+    ctx = context()
+    d = i64(0)
+    ctx.call("asr_hip_dual_cells_count", ctypes.byref(d))
+    out = torch.empty((d.value, 8), dtype=torch.int64, device=device)
+    if d.value:
+        ctx.call("asr_hip_dual_cells_fill", ptr(out))
+    return out
+
+
 def grid_neighbors(keys):
     keys = _dev(keys, torch.int64)
     v = keys.shape[0]

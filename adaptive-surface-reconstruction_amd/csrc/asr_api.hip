@@ -129,6 +129,17 @@ int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out, uint64_t* leav
     return ASR_HIP_OK;
 }
 
+int asr_hip_dual_cells_count(asr_hip_context* ctx, int64_t* num_cells) {
+    CTX_GUARD(ctx);
+    if (!num_cells) ASR_FAIL(ctx, ASR_HIP_EINVAL, "dual_cells_count: null argument");
+    return asr_geom_dual_count(ctx, num_cells);
+}
+int asr_hip_dual_cells_fill(asr_hip_context* ctx, int64_t* out) {
+    CTX_GUARD(ctx);
+    if (!out) ASR_FAIL(ctx, ASR_HIP_EINVAL, "dual_cells_fill: null argument");
+    return asr_geom_dual_fill(ctx, out);
+}
+
 int asr_hip_grid_neighbors_count(asr_hip_context* ctx, const uint64_t* keys, int64_t v,
                                  int64_t* row_splits_out, int64_t* num_pairs) {
     CTX_GUARD(ctx);

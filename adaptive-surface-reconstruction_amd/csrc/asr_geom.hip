@@ -754,6 +754,89 @@ __global__ void k_segment_of(const int32_t* rows, i64 v, i64 seg, int32_t* out) 
 }
 
 // ------------------------------------------------------------------------------------------
+// dual cells ("next" row D.1): CreateDualVertexIndices, cpp/lib/grid.cpp:316-459 with the vertex /
+// adjacent-node key algebra of cpp/lib/octreebase.h:86-118.  One thread per leaf, 8 corners each.
+// ------------------------------------------------------------------------------------------
+__device__ inline u64 dev_morton_add(u64 a, u64 b) {
+    const u64 M = 0x9249249249249249ull;
+    u64 c = ((a | ~M) + (b & M)) & M;
+    c |= ((a | ~(M << 1)) + (b & (M << 1))) & (M << 1);
+    c |= ((a | ~(M << 2)) + (b & (M << 2))) & (M << 2);
+    return c;
+}
+__device__ inline u64 dev_morton_sub(u64 a, u64 b) {
+    const u64 M = 0x9249249249249249ull;
+    u64 c = ((a & M) - (b & M)) & M;
+    c |= ((a & (M << 1)) - (b & (M << 1))) & (M << 1);
+    c |= ((a & (M << 2)) - (b & (M << 2))) & (M << 2);
+    return c;
+}
+// map: node key -> leaf index, or -1 for inner nodes; returns -2 when the key is no node
+__device__ inline int node_lookup(const HashTab& t, u64 key) {
+    u64 slot = asr_hash64(key) & t.mask;
+    for (u64 probe = 0; probe <= t.mask; ++probe) {
+        u64 cur = t.keys[slot];
+        if (cur == key) return t.vals[slot];
+        if (cur == 0) return -2;
+        slot = (slot + 1) & t.mask;
+    }
+    return -2;
+}
+// does leaf `key` own the dual cell of its corner i? (grid.cpp:334-360)
+__device__ inline bool dual_owned(const HashTab& t, u64 key, int i, u64& vertex_key) {
+    const u64 IM = 0x9249249249249249ull;
+    const int lev = asr_key_level(key);
+    const u64 min_lev_key = u64(1) << (3 * lev);
+    const u64 vk = dev_morton_add(key, (u64)i);
+    const u64 vk_ = vk - min_lev_key;
+    if (vk >= (min_lev_key << 1) || !(vk_ & IM) || !(vk_ & (IM << 1)) || !(vk_ & (IM << 2))) return false;
+    vertex_key = vk;
+    for (int j = 0; j < 8; ++j) {
+        if (j == i) continue;
+        const u64 ak = dev_morton_sub(vk, (u64)j);
+        const int r = node_lookup(t, ak);
+        if (r == -2) continue;        // no node there: this leaf is the deeper one
+        if (r == -1) return false;    // inner node: one of its children owns the vertex
+        if (ak < key) return false;   // same-level leaf with the smaller key owns it
+    }
+    return true;
+}
+__global__ void k_dual_count(const u64* leaves, i64 v, HashTab t, i64* counts) {
+    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (q > v) return;
+    if (q == v) {
+        counts[v] = 0;
+        return;
+    }
+    const u64 key = leaves[q];
+    int n = 0;
+    u64 vk;
+    for (int i = 0; i < 8; ++i) n += dual_owned(t, key, i, vk) ? 1 : 0;
+    counts[q] = n;
+}
+__global__ void k_dual_fill(const u64* leaves, i64 v, HashTab t, const i64* offsets, i64* out, int* cnt) {
+    i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (q >= v) return;
+    const u64 key = leaves[q];
+    i64 o = offsets[q];
+    for (int i = 0; i < 8; ++i) {
+        u64 vk;
+        if (!dual_owned(t, key, i, vk)) continue;
+        for (int j = 0; j < 8; ++j) {
+            u64 k = dev_morton_sub(vk, (u64)j);
+            int r = -2;
+            while (k != 0 && (r = node_lookup(t, k)) == -2) k >>= 3;  // grid.cpp:429-441
+            if (k == 0 || r < 0) {
+                cnt[1] = 1;  // "invalid key after searching for node" / "found node is not a leaf"
+                r = -1;
+            }
+            out[o * 8 + j] = r;
+        }
+        ++o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------
 int ensure_flags(asr_hip_context* ctx) {
@@ -1232,6 +1315,56 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         ASR_CHECK_LAUNCH(ctx);
     }
     st.valid = false;
+    return ASR_HIP_OK;
+}
+
+// Dual cells of the LAST octree build (ctx->nodes / ctx->leaves).  count: number of cells; fill:
+// [D,8] leaf indices, leaf order x corner order.
+int asr_geom_dual_count(asr_hip_context* ctx, i64* num_cells) {
+    ASR_TRY(ensure_flags(ctx));
+    *num_cells = 0;
+    const i64 nn = ctx->num_nodes, nl = ctx->num_leaves;
+    if (nl <= 0) return ASR_HIP_OK;
+    ctx->scratch.reset();
+    HashTab t;
+    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * nn));
+    ASR_TRY(make_table(ctx, ctx->scratch, cap, true, t));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(t.vals, 0xFF, cap * sizeof(int32_t), ctx->stream));  // -1 = inner
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    int32_t* keep = t.vals;
+    t.vals = arena_alloc<int32_t>(ctx->scratch, cap);  // throw-away values for the node pass
+    if (!t.vals) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_map_build<<<grid_for(nn, BLK), BLK, 0, ctx->stream>>>(ctx->nodes, nn, t, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    t.vals = keep;
+    k_map_build<<<grid_for(nl, BLK), BLK, 0, ctx->stream>>>(ctx->leaves, nl, t, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    i64* counts = arena_alloc<i64>(ctx->scratch, nl + 1);
+    i64* offsets = arena_alloc<i64>(ctx->scratch, nl + 1);
+    if (!counts || !offsets) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_dual_count<<<grid_for(nl + 1, BLK), BLK, 0, ctx->stream>>>(ctx->leaves, nl, t, counts);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, offsets, nl + 1));
+    ASR_TRY(read_i64(ctx, offsets + nl, num_cells));
+    RadiusState& st = rstate(ctx);  // park the table + offsets for the fill call
+    st.valid = false;
+    st.tab = t;
+    st.start = (int32_t*)offsets;
+    st.v = -nl;  // marks "dual state"
+    return ASR_HIP_OK;
+}
+int asr_geom_dual_fill(asr_hip_context* ctx, i64* out) {
+    RadiusState& st = rstate(ctx);
+    const i64 nl = ctx->num_leaves;
+    if (nl <= 0) return ASR_HIP_OK;
+    if (st.v != -nl) ASR_FAIL(ctx, ASR_HIP_EINVAL, "dual_fill must follow the matching dual_count call");
+    int host[16];
+    k_dual_fill<<<grid_for(nl, BLK), BLK, 0, ctx->stream>>>(ctx->leaves, nl, st.tab, (const i64*)st.start, out,
+                                                            ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(read_flags(ctx, host));
+    st.v = 0;
+    if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "invalid key after searching for node (cpp/lib/grid.cpp:435-440)");
     return ASR_HIP_OK;
 }
 

@@ -84,6 +84,13 @@ int asr_hip_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame,
 /* copies the sorted node keys / sorted leaf keys (tree.leaves) of the last build */
 int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out_dev, uint64_t* leaves_out_dev);
 
+/* ---- dual cells ("next" row D.1): asr::CreateDualVertexIndices (cpp/lib/grid.cpp:316-459) ------ */
+/* For the octree of the last asr_hip_octree_build / asr_hip_implicit_build of this context.
+ * count returns the number of dual cells D; fill writes [D,8] leaf indices (leaf order x corner
+ * order), the `dual_vertex_indices` consumed by CreateTriangleMesh (cpp/lib/asr.cpp:154,340). */
+int asr_hip_dual_cells_count(asr_hip_context* ctx, int64_t* num_cells);
+int asr_hip_dual_cells_fill(asr_hip_context* ctx, int64_t* dual_vertex_indices_out_dev);
+
 /* ---- a5: CreateLeafNeighborInformation (cpp/lib/grid.cpp:43-175) ---------------------- */
 /* keys: sorted unique voxel keys. count: fills row_splits[V+1] and returns the pair count;
  * fill: writes the CSR entries in ascending kernel-slot order. */

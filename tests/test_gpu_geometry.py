@@ -114,8 +114,10 @@ def test_reference_module_mirror(case):
     assert "voxel_centers" in g2[0] and "voxel_centers" not in g2[1]
     with pytest.raises(ValueError):
         asr.create_octree(case["pts"][:, :2], case["rad"], case["bb"][0], case["bb"][1])
-    with pytest.raises(NotImplementedError):
-        asr.create_dual_vertex_indices(tree)
+    tree = asr.create_octree(case["pts"], case["rad"], case["bb"][0], case["bb"][1])
+    duals = asr.create_dual_vertex_indices(tree)
+    ref = case["o"].create_dual_vertex_indices()
+    assert duals.dtype == np.uint64 and np.array_equal(duals, ref.astype(np.uint64))
 
 
 # ---- edge cases ---------------------------------------------------------------------------------

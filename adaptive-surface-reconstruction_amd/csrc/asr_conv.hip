@@ -727,7 +727,8 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     const i64 tiles64 = (a.num_out + 63) / 64;
     while (nt > 2 && tiles64 * ((a.cout + nt * 16 - 1) / (nt * 16)) < 1024) nt >>= 1;
     const i64 tiles128 = (a.num_out + 127) / 128;
-    const bool wide = nt >= 2 && tiles128 * ((a.cout + nt * 16 - 1) / (nt * 16)) >= 2048;
+    static const i64 wide_min = getenv("ASR_SCONV_WIDE_MIN") ? atoll(getenv("ASR_SCONV_WIDE_MIN")) : 2048;
+    const bool wide = nt >= 2 && tiles128 * ((a.cout + nt * 16 - 1) / (nt * 16)) >= wide_min;
 #define ASR_LAUNCH_SCONV(NT_, KC_, W_)                                                           \
     {                                                                                            \
         dim3 grid((unsigned)((a.num_out + W_ * 16 - 1) / (W_ * 16)), (a.cout + NT_ * 16 - 1) / (NT_ * 16)); \

@@ -256,7 +256,7 @@ int asr_hip_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const int64_t*
     if (v < 0 || (v > 0 && (!kidx || !rs || !perm_out)))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "row_groups: null argument");
     ctx->scratch.reset();
-    return asr_geom_row_groups(ctx, kidx, rs, v, seg > 0 ? seg : ASR_ROW_GROUP_SEGMENT, perm_out);
+    return asr_geom_row_groups(ctx, kidx, rs, v, seg > 0 ? seg : ASR_ROW_GROUP_SEGMENT, perm_out, 56);
 }
 int asr_hip_invert_neighbors_list(asr_hip_context* ctx, int64_t num_points, const int32_t* idx,
                                   const int64_t* rs, int64_t num_rows, const uint8_t* attr,
@@ -493,9 +493,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
             if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
             ASR_TRY(asr_geom_row_groups(ctx, prev.up_kidx, prev.up_rs, prev.v, ASR_ROW_GROUP_SEGMENT,
-                                        prev.perm_up));
+                                        prev.perm_up, 9));
             ASR_TRY(asr_geom_row_groups(ctx, prev.down_kidx, prev.down_rs, g.v, ASR_ROW_GROUP_SEGMENT,
-                                        prev.perm_down));
+                                        prev.perm_down, 9));
             std::string s = std::to_string(i - 1);
             name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
             name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
@@ -512,7 +512,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
                                          &g.p));
         g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
         if (!g.perm_nb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_row_groups(ctx, g.nkidx, g.nrs, g.v, ASR_ROW_GROUP_SEGMENT, g.perm_nb));
+        ASR_TRY(asr_geom_row_groups(ctx, g.nkidx, g.nrs, g.v, ASR_ROW_GROUP_SEGMENT, g.perm_nb, 55));
         ctx->sizes.num_voxels[i] = g.v;
         ctx->sizes.num_pairs[i] = g.p;
         std::string s = std::to_string(i);

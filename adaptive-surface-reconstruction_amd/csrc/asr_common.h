@@ -215,7 +215,7 @@ int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const 
 int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* keys, i64 v,
                              i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs);
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
-                        int32_t* perm_out);
+                        int32_t* perm_out, int kbits);
 int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_out);
 int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out_keys, i64 v_out,
                           int32_t* up_idx, uint8_t* up_kidx, i64* up_rs);

@@ -1057,7 +1057,8 @@ int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* 
 }
 
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
-                        int32_t* perm_out) {
+                        int32_t* perm_out, int kbits) {
+    if (kbits < 1 || kbits > 56) kbits = 56;  // slot masks only use bits below the kernel size
     if (v <= 0) return ASR_HIP_OK;
     if (seg < 16) seg = 16;
     if (v >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "row_groups: too many rows");
@@ -1069,14 +1070,14 @@ int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs
     ASR_CHECK_LAUNCH(ctx);
     // order by (segment, mask) with two stable LSD radix sorts: by mask, then by segment id
     if (seg >= v) {
-        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, perm_out, v, 56)));
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, perm_out, v, kbits)));
         return ASR_HIP_OK;
     }
     int32_t* ids_m = arena_alloc<int32_t>(ctx->scratch, v);
     int32_t* segk = arena_alloc<int32_t>(ctx->scratch, v);
     int32_t* segk_s = arena_alloc<int32_t>(ctx->scratch, v);
     if (!ids_m || !segk || !segk_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, ids_m, v, 56)));
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, ids_m, v, kbits)));
     k_segment_of<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(ids_m, v, seg, segk);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, segk, segk_s, ids_m, perm_out, v,

@@ -2,9 +2,9 @@
 (cpp/pybind/module.cpp:279-491, re-exported by python/adaptivesurfacereconstruction/__init__.py).
 
 Same function names, keyword defaults, numpy in / numpy out, ValueError for shape errors and
-RuntimeError from the library.  Everything runs on the MI355X through libasr_hip.so; the rows of
-SURVEY section 8 marked "next" that are not built yet (contouring, component filter) raise
-NotImplementedError instead of silently falling back to a CPU path.
+RuntimeError from the library.  Everything runs on the MI355X through libasr_hip.so (no CPU
+fallback), including the "next" rows of SURVEY section 8: pre-filter, dual cells, contouring and
+component filter.
 """
 import numpy as np
 import torch
@@ -109,11 +109,6 @@ def compute_aggregation_neighbors(tree, points, radii, voxel_centers, voxel_size
             "aggregation_scale_compat": compat.cpu().numpy()}
 
 
-def _next_row(what, where):
-    raise NotImplementedError("%s (%s) is a 'next' row of the hot-path scope table and is not "
-                              "implemented on the MI355X path yet" % (what, where))
-
-
 def create_dual_vertex_indices(tree):
     """module.cpp:230-235,443-453 -> asr::CreateDualVertexIndices (cpp/lib/grid.cpp:450-459):
     uint64 [D,8] indices into the leaves.  Must be called while `tree` is the octree built last on
@@ -123,18 +118,101 @@ def create_dual_vertex_indices(tree):
     return _ops.dual_cells(tree.leaves.device).cpu().numpy().astype(np.uint64)
 
 
+def create_triangle_mesh(values, dual_vertex_indices, node_positions, contouring_value_threshold=1.0):
+    """asr::CreateTriangleMesh (cpp/lib/contouring.cpp:29-460), internal to ReconstructSurface in the
+    reference (cpp/lib/asr.cpp:340-342): values [V,2], dual_vertex_indices [D,8], node_positions
+    [V,3] -> {'vertices': f32[M,3], 'triangles': i32[T,3]}"""
+    dev = torch.device("cuda")
+    values = _f32(values, "values", "[V,2]", 2, 2)
+    pos = _f32(node_positions, "node_positions", "[V,3]", 2, 3)
+    duals = np.ascontiguousarray(dual_vertex_indices)
+    if duals.ndim != 2 or duals.shape[1] != 8:
+        raise ValueError("dual_vertex_indices must have shape [D,8]")
+    duals = duals.astype(np.int64, copy=False) if duals.dtype != np.uint64 else duals.view(np.int64)
+    if duals.size and (duals.min() < 0 or duals.max() >= values.shape[0]):
+        raise ValueError("dual_vertex_indices out of range")
+    v, t = _ops.contour(torch.from_numpy(values).to(dev), torch.from_numpy(duals).to(dev),
+                        torch.from_numpy(pos).to(dev), contouring_value_threshold)
+    return {"vertices": v.cpu().numpy(), "triangles": t.cpu().numpy()}
+
+
+def _load_weights(weights):
+    """state dict of the network (names of UNet5.state_dict()).  The reference loads the TorchScript
+    file <resource dir>/model.pt (cpp/lib/asr.cpp:138-139); here: a dict, an .npz, or a torch file
+    holding a state dict, by argument or as $ASR_RESOURCE_DIR/model_weights.{npz,pt}."""
+    import os
+    if weights is None:
+        base = os.environ.get("ASR_RESOURCE_DIR", "")
+        for cand in ("model_weights.npz", "model_weights.pt"):
+            if base and os.path.exists(os.path.join(base, cand)):
+                weights = os.path.join(base, cand)
+                break
+        if weights is None:
+            raise RuntimeError("no network weights: pass weights=... or set ASR_RESOURCE_DIR to a directory "
+                               "with model_weights.npz / model_weights.pt")
+    if isinstance(weights, str):
+        if weights.endswith(".npz"):
+            with np.load(weights) as z:
+                return {k: z[k] for k in z.files}
+        sd = torch.load(weights, map_location="cpu")
+        return sd.state_dict() if hasattr(sd, "state_dict") else sd
+    return weights
+
+
 def reconstruct_surface(points, normals, radii=np.empty((0,), np.float32), point_radius_scale=1.0,
                         density_percentile_threshold=10.0, point_radius_estimation_knn=24,
                         octree_max_depth=21, contouring_value_threshold=1.0,
-                        keep_n_connected_components=2**63 - 1, minimum_component_size=3):
-    _next_row("reconstruct_surface (pre-filter + contouring + component filter)",
-              "cpp/lib/asr.cpp:116-135,340-346; use asr_hip.pipeline.ImplicitPipeline for the "
-              "implicit values")
+                        keep_n_connected_components=2**63 - 1, minimum_component_size=3, *, weights=None):
+    """module.cpp:58-109,291-346 -> asr::ReconstructSurface (cpp/lib/asr.cpp:95-349): pre-filter,
+    implicit values, dual contouring, component filter; every stage on the MI355X.
+    `weights` (keyword only) replaces the reference's bundled model.pt, see _load_weights."""
+    from asr_hip.pipeline import ImplicitPipeline
+    points = _f32(points, "points", "[num_points,3]", 2, 3)
+    normals = _f32(normals, "normals", "[num_points,3]", 2, 3)
+    radii = np.ascontiguousarray(radii, dtype=np.float32)
+    if normals.shape != points.shape:
+        raise ValueError("normals must have shape [num_points,3]")
+    if radii.ndim != 1 or radii.shape[0] not in (0, points.shape[0]):
+        raise ValueError("radii must have shape [num_point3]")
+    if points.shape[0] == 0:
+        raise RuntimeError("points is null!\n")
+    # preprocess (asr.cpp:116-135)
+    tree = KDTree(points)
+    if radii.shape[0]:
+        counts = _ops.radius_neighbor_count(tree._frame, tree._points, torch.from_numpy(radii).to(tree._points.device))
+        inlier = _ops.density_inlier(counts.cpu().numpy(), density_percentile_threshold)
+    else:
+        r = _ops.knn_radius(tree._frame, tree._points, point_radius_estimation_knn)
+        _, inl = _ops.knn_radius(tree._frame, tree._points, point_radius_estimation_knn, r, 0.5, 1,
+                                 want_inlier=True)
+        radii = r.cpu().numpy()
+        inlier = inl.cpu().numpy().astype(bool)
+    points, normals, radii = points[inlier], normals[inlier], radii[inlier]
+    if points.shape[0] == 0:
+        raise RuntimeError("no points left after the pre-filter")
+    dev = torch.device("cuda")
+    pipe = ImplicitPipeline(_load_weights(weights), device="cuda:%d" % torch.cuda.current_device(),
+                            point_radius_scale=point_radius_scale, octree_max_depth=octree_max_depth,
+                            scale_sdf=True)
+    # exact bounding box of the filtered points (asr.cpp:148-150; quirk B.1 applies)
+    bb_min, bb_max = points.min(0), points.max(0)
+    pipe.forward(torch.from_numpy(points).to(dev), torch.from_numpy(normals).to(dev),
+                 torch.from_numpy(radii).to(dev), bb_min, bb_max)
+    v, t = pipe.mesh(contouring_value_threshold, keep_n_connected_components, minimum_component_size)
+    return {"vertices": v.cpu().numpy(), "triangles": t.cpu().numpy()}
 
 
 def remove_connected_components(vertices, triangles, keep_n_largest_components,
                                 minimum_component_size=3):
-    _next_row("remove_connected_components", "cpp/lib/postprocess.cpp:141")
+    """module.cpp:111-142,348-370 -> asr::RemoveConnectedComponents (cpp/lib/postprocess.cpp:141-176)"""
+    vertices = _f32(vertices, "vertices", "[N,3]", 2, 3)
+    triangles = np.ascontiguousarray(triangles, dtype=np.int32)
+    if triangles.ndim != 2 or triangles.shape[1] != 3:
+        raise ValueError("triangles must have shape [N,3]")
+    dev = torch.device("cuda")
+    v, t = _ops.remove_components(torch.from_numpy(vertices).to(dev), torch.from_numpy(triangles).to(dev),
+                                  keep_n_largest_components, minimum_component_size)
+    return {"vertices": v.cpu().numpy(), "triangles": t.cpu().numpy()}
 
 
 class KDTree:

@@ -67,15 +67,56 @@ def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
     return nodes, leaves
 
 
-def dual_cells(device):
+def dual_cells(device, ctx=None):
     """dual_vertex_indices [D,8] (int64) of the octree built last on this context"""
-    ctx = context()
+    ctx = ctx or context()
     d = i64(0)
     ctx.call("asr_hip_dual_cells_count", ctypes.byref(d))
     out = torch.empty((d.value, 8), dtype=torch.int64, device=device)
     if d.value:
         ctx.call("asr_hip_dual_cells_fill", ptr(out))
     return out
+
+
+
+def contour(values, dual_vertex_indices, node_positions, threshold=1.0, ctx=None):
+    """asr::CreateTriangleMesh (cpp/lib/contouring.cpp:29-460) -> (vertices f32[M,3], triangles i32[T,3])"""
+    values = _dev(values, torch.float32)
+    duals = _dev(dual_vertex_indices, torch.int64)
+    pos = _dev(node_positions, torch.float32)
+    if values.dim() != 2 or values.shape[1] != 2:
+        raise ValueError("values must have shape [V,2]")
+    if duals.dim() != 2 or duals.shape[1] != 8:
+        raise ValueError("dual_vertex_indices must have shape [D,8]")
+    if pos.dim() != 2 or pos.shape[1] != 3 or pos.shape[0] != values.shape[0]:
+        raise ValueError("node_positions must have shape [V,3]")
+    ctx = ctx or context()
+    nv, nt = i64(0), i64(0)
+    ctx.call("asr_hip_contour_count", ptr(values), i64(values.shape[0]), ptr(duals), i64(duals.shape[0]),
+             ptr(pos), ctypes.c_float(threshold), ctypes.byref(nv), ctypes.byref(nt))
+    vertices = torch.empty((nv.value, 3), dtype=torch.float32, device=values.device)
+    triangles = torch.empty((nt.value, 3), dtype=torch.int32, device=values.device)
+    ctx.call("asr_hip_contour_fill", ptr(vertices), ptr(triangles))
+    return vertices, triangles
+
+
+def remove_components(vertices, triangles, keep_n, min_size=3, ctx=None):
+    """asr::RemoveConnectedComponents (cpp/lib/postprocess.cpp:141-176)"""
+    vertices = _dev(vertices, torch.float32)
+    triangles = _dev(triangles, torch.int32)
+    if vertices.dim() != 2 or vertices.shape[1] != 3:
+        raise ValueError("vertices must have shape [N,3]")
+    if triangles.dim() != 2 or triangles.shape[1] != 3:
+        raise ValueError("triangles must have shape [M,3]")
+    ctx = ctx or context()
+    nv, nt = i64(0), i64(0)
+    ctx.call("asr_hip_components_count", ptr(vertices), i64(vertices.shape[0]), ptr(triangles),
+             i64(triangles.shape[0]), i64(min(int(keep_n), 2**62)), i64(int(min_size)), ctypes.byref(nv),
+             ctypes.byref(nt))
+    v2 = torch.empty((nv.value, 3), dtype=torch.float32, device=vertices.device)
+    t2 = torch.empty((nt.value, 3), dtype=torch.int32, device=vertices.device)
+    ctx.call("asr_hip_components_fill", ptr(v2), ptr(t2))
+    return v2, t2
 
 
 def grid_neighbors(keys):
@@ -298,3 +339,17 @@ def decode_mlp(code, w1, b1, w2, b2, w3, voxel_sizes=None):
                    int(w1.shape[0]), ptr(w2), ptr(b2), int(w2.shape[0]), ptr(w3), ptr(sizes),
                    ptr(out))
     return out
+
+
+def density_inlier(counts, density_percentile_threshold):
+    """asr::ComputeInlierFromDensity (cpp/lib/preprocess.cpp:41-62) on host counts, literally
+    (see asr_density_inlier in include/asr_hip.h)"""
+    import numpy as np
+    counts = np.ascontiguousarray(counts, np.int64)
+    out = np.zeros(counts.shape[0], np.uint8)
+    rc = _lib.load().asr_density_inlier(counts.ctypes.data_as(ctypes.c_void_p), i64(counts.shape[0]),
+                                        ctypes.c_double(density_percentile_threshold),
+                                        out.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise AsrHipError("asr_density_inlier failed (%d)" % rc)
+    return out.astype(bool)

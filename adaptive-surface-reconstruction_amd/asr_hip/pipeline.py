@@ -145,6 +145,24 @@ class ImplicitPipeline:
             out = out.reshape(-1, cols)
         return out
 
+    def dual_cells(self):
+        """dual_vertex_indices [D,8] of the octree of the last forward/build (cpp/lib/asr.cpp:154)"""
+        from . import ops
+        self.ctx.set_stream(torch.cuda.current_stream())
+        return ops.dual_cells(self.device, ctx=self.ctx)
+
+    def mesh(self, contouring_value_threshold=1.0, keep_n_connected_components=2**63 - 1,
+             minimum_component_size=3, values=None):
+        """contouring + component filter on the last forward (cpp/lib/asr.cpp:338-346) ->
+        (vertices f32[M,3], triangles i32[T,3]) on the GPU"""
+        from . import ops
+        self.ctx.set_stream(torch.cuda.current_stream())
+        if values is None:
+            values = self.get("values")
+        duals = ops.dual_cells(self.device, ctx=self.ctx)
+        v, t = ops.contour(values, duals, self.get("voxel_centers0"), contouring_value_threshold, ctx=self.ctx)
+        return ops.remove_components(v, t, keep_n_connected_components, minimum_component_size, ctx=self.ctx)
+
     def stage_ms(self):
         ms = (ctypes.c_float * 6)()
         self.ctx.call("asr_hip_implicit_stage_ms", ms)

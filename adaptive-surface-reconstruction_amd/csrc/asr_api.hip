@@ -6,7 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
+
 #include "asr_common.h"
+#include "asr_uset.h"
 
 // rows are regrouped inside segments of this many consecutive rows (env ASR_ROW_SEGMENT overrides,
 // for experiments)
@@ -52,6 +55,7 @@ void asr_hip_context_destroy(asr_hip_context* ctx) {
     if (!ctx) return;
     (void)hipStreamSynchronize(ctx->stream);
     asr_geom_release(ctx);
+    asr_mesh_release(ctx);
     ctx->persist.release();
     ctx->scratch.release();
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -129,6 +133,48 @@ int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out, uint64_t* leav
     return ASR_HIP_OK;
 }
 
+int asr_hip_contour_count(asr_hip_context* ctx, const float* values, int64_t num_values, const int64_t* duals,
+                          int64_t num_duals, const float* positions, float threshold, int64_t* num_vertices,
+                          int64_t* num_triangles) {
+    if (!ctx) return ASR_HIP_EINVAL;
+    if (!num_vertices || !num_triangles || num_values < 0 || num_duals < 0 ||
+        (num_duals > 0 && (!values || !duals || !positions)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "contour_count: null argument");
+    return asr_mesh_contour_count(ctx, values, num_values, duals, num_duals, positions, threshold, num_vertices,
+                                  num_triangles);
+}
+int asr_hip_contour_fill(asr_hip_context* ctx, float* vertices, int32_t* triangles) {
+    if (!ctx) return ASR_HIP_EINVAL;
+    return asr_mesh_contour_fill(ctx, vertices, triangles);
+}
+int asr_hip_components_count(asr_hip_context* ctx, const float* vertices, int64_t nv, const int32_t* triangles,
+                             int64_t nt, int64_t keep_n, int64_t min_size, int64_t* nv_out, int64_t* nt_out) {
+    if (!ctx) return ASR_HIP_EINVAL;
+    if (!nv_out || !nt_out || nv < 0 || nt < 0 || (nv > 0 && !vertices) || (nt > 0 && !triangles))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "components_count: null argument");
+    return asr_mesh_components_count(ctx, vertices, nv, triangles, nt, keep_n, min_size, nv_out, nt_out);
+}
+int asr_hip_components_fill(asr_hip_context* ctx, float* vertices_out, int32_t* triangles_out) {
+    if (!ctx) return ASR_HIP_EINVAL;
+    return asr_mesh_components_fill(ctx, vertices_out, triangles_out);
+}
+int asr_density_inlier(const int64_t* counts, int64_t n, double density_percentile_threshold, uint8_t* inlier) {
+    if (n < 0 || (n > 0 && (!counts || !inlier))) return ASR_HIP_EINVAL;
+    if (n == 0) return ASR_HIP_OK;
+    std::vector<int> c((size_t)n);
+    for (int64_t i = 0; i < n; ++i) c[(size_t)i] = (int)counts[i];
+    size_t middle = (size_t)((density_percentile_threshold / 100) * (double)n);
+    middle = std::min<size_t>((size_t)n, std::max<size_t>(1, middle));
+    std::partial_sort(c.begin(), c.begin() + middle, c.end());
+    const int threshold = c[middle - 1];
+    for (int64_t i = 0; i < n; ++i) inlier[i] = c[(size_t)i] > threshold;
+    return ASR_HIP_OK;
+}
+int asr_hip_unordered_set_order(const uint32_t* xs, int n, uint32_t* out) {
+    if (!xs || !out || n < 0 || n > ASR_USET_CAP) return ASR_HIP_EINVAL;
+    asr_uset_order(xs, n, out);
+    return ASR_HIP_OK;
+}
 int asr_hip_dual_cells_count(asr_hip_context* ctx, int64_t* num_cells) {
     CTX_GUARD(ctx);
     if (!num_cells) ASR_FAIL(ctx, ASR_HIP_EINVAL, "dual_cells_count: null argument");

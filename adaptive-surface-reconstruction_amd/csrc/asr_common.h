@@ -108,6 +108,7 @@ struct asr_hip_context {
     int* d_flags = nullptr;  // small device scratch for counters (persistent)
     float* d_zeros = nullptr;  // 4 KB of zeros: target of masked-out loads
     void* radius_state = nullptr;  // RadiusState of asr_geom.hip (between _count and _fill)
+    void* mesh_state = nullptr;    // MeshState of asr_mesh.hip (between _count and _fill)
     std::map<std::string, std::pair<const void*, size_t>> named;  // asr_hip_implicit_get
 };
 
@@ -238,6 +239,15 @@ int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, co
                     i64 num_rows, const uint8_t* attr, int32_t* out_idx, i64* out_rs,
                     uint8_t* out_attr);
 void asr_geom_release(asr_hip_context* ctx);
+
+int asr_mesh_contour_count(asr_hip_context* ctx, const float* values, i64 num_values, const i64* duals,
+                           i64 num_duals, const float* positions, float threshold, i64* num_vertices,
+                           i64* num_triangles);
+int asr_mesh_contour_fill(asr_hip_context* ctx, float* vertices, int32_t* triangles);
+int asr_mesh_components_count(asr_hip_context* ctx, const float* vertices, i64 nv, const int32_t* triangles,
+                              i64 nt, i64 keep_n, i64 min_size, i64* nv_out, i64* nt_out);
+int asr_mesh_components_fill(asr_hip_context* ctx, float* vertices_out, int32_t* triangles_out);
+void asr_mesh_release(asr_hip_context* ctx);
 
 int asr_conv_agg_importance(asr_hip_context* ctx, const float* compat, const float* dist, i64 n,
                             float* out);

@@ -91,6 +91,38 @@ int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out_dev, uint64_t* 
 int asr_hip_dual_cells_count(asr_hip_context* ctx, int64_t* num_cells);
 int asr_hip_dual_cells_fill(asr_hip_context* ctx, int64_t* dual_vertex_indices_out_dev);
 
+/* ---- dual contouring ("next" row D.2): asr::CreateTriangleMesh (cpp/lib/contouring.cpp:29-460) ---- */
+/* values [V,2] (signed, unsigned), dual_vertex_indices [D,8] int64, node_positions [V,3]; all
+ * device pointers that must stay valid until the fill call.  count returns the mesh sizes, fill
+ * writes vertices f32[M,3] (one per active dual cell in dual order, then the fan centres in
+ * emission order) and triangles i32[T,3] in the reference's serial emission order, including the
+ * corner order it derives from libstdc++'s unordered_set iteration (see csrc/asr_uset.h). */
+int asr_hip_contour_count(asr_hip_context* ctx, const float* values_dev, int64_t num_values,
+                          const int64_t* dual_vertex_indices_dev, int64_t num_duals,
+                          const float* node_positions_dev, float value_threshold,
+                          int64_t* num_vertices, int64_t* num_triangles);
+int asr_hip_contour_fill(asr_hip_context* ctx, float* vertices_out_dev, int32_t* triangles_out_dev);
+
+/* ---- component filter ("next" row D.3): asr::RemoveConnectedComponents
+ * (cpp/lib/postprocess.cpp:141-176).  Keeps the keep_n largest components (size in vertices,
+ * ties -> the component found later first, like std::greater on (size, label)) that have at least
+ * min_size vertices; compacts vertices and re-indexes triangles, order preserving. */
+int asr_hip_components_count(asr_hip_context* ctx, const float* vertices_dev, int64_t num_vertices,
+                             const int32_t* triangles_dev, int64_t num_triangles, int64_t keep_n,
+                             int64_t min_size, int64_t* num_vertices_out, int64_t* num_triangles_out);
+int asr_hip_components_fill(asr_hip_context* ctx, float* vertices_out_dev, int32_t* triangles_out_dev);
+
+/* Host-only: asr::ComputeInlierFromDensity (cpp/lib/preprocess.cpp:41-62) on the neighbour counts of
+ * asr_hip_radius_neighbor_count (host array).  Reproduces the reference literally, including that
+ * it compares the counts AFTER std::partial_sort has permuted them in place (:53-60), so inlier[i]
+ * is not a function of point i's own count (quirk B.11 in DESIGN.md). */
+int asr_density_inlier(const int64_t* counts_host, int64_t n, double density_percentile_threshold,
+                       uint8_t* inlier_out_host);
+
+/* Host-only helper (no GPU): iteration order of a libstdc++ std::unordered_set<size_t> filled with
+ * xs[0..n) in that order, n <= 29 -- the rule the contouring kernel replays (csrc/asr_uset.h). */
+int asr_hip_unordered_set_order(const uint32_t* xs, int n, uint32_t* out);
+
 /* ---- a5: CreateLeafNeighborInformation (cpp/lib/grid.cpp:43-175) ---------------------- */
 /* keys: sorted unique voxel keys. count: fills row_splits[V+1] and returns the pair count;
  * fill: writes the CSR entries in ascending kernel-slot order. */

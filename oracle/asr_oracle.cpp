@@ -27,6 +27,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <array>
+#include <numeric>
 #include <unordered_set>
 #include <vector>
 
@@ -691,6 +693,280 @@ static void sparse_conv(const float* filters, const float* feat, i64 feat_ld, co
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// contouring.cpp:29-460 CreateTriangleMesh ("next" row D.2).  The order in which the duals around
+// an edge are emitted starts from the LAST element of a std::unordered_set<size_t> iteration
+// (contouring.cpp:250-256), i.e. it depends on libstdc++; this restatement uses the same container
+// in the same way, so with the image's libstdc++ it reproduces the reference's face order.
+// ---------------------------------------------------------------------------------
+namespace contour {
+static const int cube_edges[12][2] = {{0, 1}, {1, 3}, {3, 2}, {2, 0}, {4, 5}, {5, 7},
+                                      {7, 6}, {6, 4}, {0, 4}, {1, 5}, {3, 7}, {2, 6}};
+static const int cube_faces[6][4] = {{0, 1, 3, 2}, {4, 6, 7, 5}, {1, 5, 7, 3},
+                                     {2, 3, 7, 6}, {0, 2, 6, 4}, {0, 4, 5, 1}};
+static const int edge_subset[3] = {0, 1, 9};
+
+struct Small4 {  // smallset.h: sorted, duplicate free, capacity 4
+    size_t d[4];
+    int n = 0;
+    void insert(size_t v) {
+        int i = 0;
+        while (i < n && d[i] < v) ++i;
+        if (i < n && d[i] == v) return;
+        for (int j = n; j > i; --j) d[j] = d[j - 1];
+        d[i] = v;
+        ++n;
+    }
+    bool operator==(const Small4& o) const {
+        if (n != o.n) return false;
+        for (int i = 0; i < n; ++i)
+            if (d[i] != o.d[i]) return false;
+        return true;
+    }
+};
+
+struct Mesh {
+    std::vector<float> vertices;
+    std::vector<int32_t> triangles;
+    int error = 0;
+};
+
+static void create_triangle_mesh(Mesh& mesh, const float* values, size_t num_values,
+                                 const i64* dual_indices, size_t num_duals, const float* pos,
+                                 float thr) {
+    typedef std::array<size_t, 8> Dual;
+    auto dual_at = [&](size_t i) {
+        Dual d;
+        for (int k = 0; k < 8; ++k) d[k] = (size_t)dual_indices[i * 8 + k];
+        return d;
+    };
+    auto crossing = [&](size_t a, size_t b) {  // :81-111
+        float u1 = values[a * 2 + 1], u2 = values[b * 2 + 1];
+        if (u1 > thr && u2 > thr) return false;
+        float v1 = values[a * 2], v2 = values[b * 2];
+        return (v1 < 0 && v2 > 0) || (v1 > 0 && v2 < 0);
+    };
+    auto complex_test = [&](const Dual& d) {
+        for (int e = 0; e < 12; ++e)
+            if (crossing(d[cube_edges[e][0]], d[cube_edges[e][1]])) return true;
+        return false;
+    };
+    auto edge_test = [&](size_t a, size_t b) { return a != b && crossing(a, b); };
+    auto vertex_position = [&](const Dual& d, float* out) {  // :114-142
+        double p[3] = {0, 0, 0};
+        int count = 0;
+        for (int e = 0; e < 12; ++e) {
+            size_t a = d[cube_edges[e][0]], b = d[cube_edges[e][1]];
+            double v1 = values[a * 2 + 1], v2 = values[b * 2 + 1];
+            if (v1 > thr && v2 > thr) continue;
+            v1 = values[a * 2];
+            v2 = values[b * 2];
+            if ((v1 < 0 && v2 > 0) || (v1 > 0 && v2 < 0)) {
+                double t = -v1 / (v2 - v1);
+                if (!std::isfinite(t) || t < 0 || t > 1) t = 0.5;
+                for (int k = 0; k < 3; ++k) p[k] += (1 - t) * (double)pos[a * 3 + k] + t * (double)pos[b * 3 + k];
+                ++count;
+            }
+        }
+        for (int k = 0; k < 3; ++k) out[k] = (float)(p[k] / count);
+    };
+
+    std::vector<size_t> active;  // intersecting_duals_indices
+    std::vector<size_t> prefix(num_values, 0);
+    for (size_t i = 0; i < num_duals; ++i) {
+        Dual d = dual_at(i);
+        if (complex_test(d)) {
+            active.push_back(i);
+            std::unordered_set<size_t> tmp(d.begin(), d.end());
+            for (size_t v : tmp) prefix[v]++;
+        }
+    }
+    std::partial_sum(prefix.begin(), prefix.end(), prefix.begin());
+    std::vector<size_t> adj(num_values ? prefix.back() : 0), fill(num_values, 0);
+    auto adj_begin = [&](size_t v) { return v ? prefix[v - 1] : size_t(0); };
+    mesh.vertices.assign(active.size() * 3, 0.f);
+    for (size_t n = 0; n < active.size(); ++n) {
+        Dual d = dual_at(active[n]);
+        std::unordered_set<size_t> tmp(d.begin(), d.end());
+        for (size_t v : tmp) adj[adj_begin(v) + fill[v]++] = n;
+        vertex_position(d, &mesh.vertices[n * 3]);
+    }
+    auto duals_containing_edge = [&](size_t a, size_t b) {  // :202-213
+        std::unordered_set<size_t> set1(adj.begin() + adj_begin(a), adj.begin() + prefix[a]);
+        std::unordered_set<size_t> set2;
+        for (size_t i = adj_begin(b); i < prefix[b]; ++i)
+            if (set1.count(adj[i])) set2.insert(adj[i]);
+        return set2;
+    };
+    auto dual_has_face = [&](const Dual& d, const Small4& face) {
+        for (int i = 0; i < 6; ++i) {
+            Small4 f;
+            for (int j = 0; j < 4; ++j) f.insert(d[cube_faces[i][j]]);
+            if (f == face) return true;
+        }
+        return false;
+    };
+    auto face_with_oriented_edge = [&](const Dual& d, size_t e0, size_t e1) {
+        for (int fi = 0; fi < 6; ++fi)
+            for (int j = 0; j < 4; ++j)
+                if (d[cube_faces[fi][j]] == e0 && d[cube_faces[fi][(j + 1) % 4]] == e1) {
+                    Small4 f;
+                    for (int k = 0; k < 4; ++k) f.insert(d[cube_faces[fi][k]]);
+                    if (f.n >= 3) return f;
+                }
+        return Small4();
+    };
+    auto sort_duals = [&](const std::unordered_set<size_t>& idx_set, size_t e0, size_t e1) {  // :247-299
+        std::vector<size_t> idx_vec(idx_set.begin(), idx_set.end());
+        std::vector<size_t> sorted;
+        sorted.push_back(idx_vec.back());
+        idx_vec.pop_back();
+        const int N = (int)(idx_set.size() * idx_set.size());
+        bool reverse_again = false;
+        for (int i = 0; i < N && idx_vec.size(); ++i) {
+            Dual d1 = dual_at(active[sorted.back()]);
+            Small4 face = face_with_oriented_edge(d1, e0, e1);
+            size_t before = idx_vec.size();
+            for (auto it = idx_vec.begin(); it != idx_vec.end(); ++it) {
+                if (dual_has_face(dual_at(active[*it]), face)) {
+                    sorted.push_back(*it);
+                    idx_vec.erase(it);
+                    break;
+                }
+            }
+            if (before == idx_vec.size()) {
+                std::reverse(sorted.begin(), sorted.end());
+                std::swap(e0, e1);
+                reverse_again = !reverse_again;
+            }
+        }
+        if (reverse_again) std::reverse(sorted.begin(), sorted.end());
+        return sorted;
+    };
+
+    size_t num_vertices = active.size(), num_triangles = 0;
+    for (size_t n = 0; n < active.size(); ++n) {
+        Dual d = dual_at(active[n]);
+        for (int e = 0; e < 3; ++e) {
+            size_t a = d[cube_edges[edge_subset[e]][0]], b = d[cube_edges[edge_subset[e]][1]];
+            if (!edge_test(a, b)) continue;
+            int k = (int)duals_containing_edge(a, b).size();
+            if (k == 3)
+                num_triangles += 1;
+            else if (k == 4)
+                num_triangles += 2;
+            else if (k > 4) {
+                num_triangles += k;
+                num_vertices += 1;
+            }
+        }
+    }
+    mesh.vertices.resize(num_vertices * 3);
+    mesh.triangles.assign(num_triangles * 3, 0);
+    size_t ti = 0, extra = active.size();
+    for (size_t n = 0; n < active.size(); ++n) {
+        Dual d = dual_at(active[n]);
+        for (int e = 0; e < 3; ++e) {
+            size_t a = d[cube_edges[edge_subset[e]][0]], b = d[cube_edges[edge_subset[e]][1]];
+            if (!edge_test(a, b)) continue;
+            auto set = duals_containing_edge(a, b);
+            if (values[a * 2] > values[b * 2]) std::swap(a, b);
+            auto s = sort_duals(set, a, b);
+            if (s.size() != set.size()) {
+                mesh.error = 1;  // "this should not happen: cannot sort duals"
+                return;
+            }
+            int k = (int)s.size();
+            auto V = [&](int i, int c) { return mesh.vertices[s[i] * 3 + c]; };
+            auto sq = [&](int i, int j) {
+                float dx = V(i, 0) - V(j, 0), dy = V(i, 1) - V(j, 1), dz = V(i, 2) - V(j, 2);
+                return dx * dx + (dy * dy + dz * dz);  // Eigen's unrolled 3-vector sum: c0 + (c1 + c2)
+            };
+            int32_t* t = &mesh.triangles[ti * 3];
+            if (k == 3) {
+                t[0] = (int32_t)s[0]; t[1] = (int32_t)s[1]; t[2] = (int32_t)s[2];
+                ti += 1;
+            } else if (k == 4) {
+                if (sq(0, 2) > sq(1, 3)) {
+                    t[0] = (int32_t)s[0]; t[1] = (int32_t)s[1]; t[2] = (int32_t)s[3];
+                    t[3] = (int32_t)s[1]; t[4] = (int32_t)s[2]; t[5] = (int32_t)s[3];
+                } else {
+                    t[0] = (int32_t)s[0]; t[1] = (int32_t)s[1]; t[2] = (int32_t)s[2];
+                    t[3] = (int32_t)s[0]; t[4] = (int32_t)s[2]; t[5] = (int32_t)s[3];
+                }
+                ti += 2;
+            } else if (k > 4) {
+                float c[3] = {0, 0, 0};
+                for (int i = 0; i < k; ++i)
+                    for (int q = 0; q < 3; ++q) c[q] += V(i, q);
+                for (int q = 0; q < 3; ++q) mesh.vertices[extra * 3 + q] = c[q] / (float)k;
+                for (int i = 0; i < k; ++i) {
+                    t[i * 3 + 0] = (int32_t)s[i];
+                    t[i * 3 + 1] = (int32_t)s[(i + 1) % k];
+                    t[i * 3 + 2] = (int32_t)extra;
+                }
+                ++extra;
+                ti += k;
+            }
+        }
+    }
+}
+
+// postprocess.cpp:27-201 ("next" row D.3)
+static void remove_components(Mesh& m, i64 keep_n, i64 min_size) {
+    const size_t nv = m.vertices.size() / 3, nt = m.triangles.size() / 3;
+    std::vector<std::vector<i64>> vf(nv);
+    for (size_t f = 0; f < nt; ++f)
+        for (int k = 0; k < 3; ++k) vf[m.triangles[f * 3 + k]].push_back((i64)f);
+    std::vector<i64> comp(nv, -1), sizes;
+    std::vector<i64> todo;
+    i64 cur = 0;
+    for (size_t i = 0; i < nv; ++i) {
+        if (comp[i] != -1) continue;
+        todo.push_back((i64)i);
+        while (!todo.empty()) {
+            i64 v = todo.back();
+            todo.pop_back();
+            if (comp[v] != -1) continue;
+            comp[v] = cur;
+            for (i64 f : vf[v])
+                for (int k = 0; k < 3; ++k) {
+                    i64 w = m.triangles[f * 3 + k];
+                    if (comp[w] == -1) todo.push_back(w);
+                }
+        }
+        ++cur;
+    }
+    sizes.assign(cur, 0);
+    for (size_t i = 0; i < nv; ++i) ++sizes[comp[i]];
+    std::vector<std::pair<i64, i64>> order;
+    for (i64 c = 0; c < cur; ++c) order.push_back({sizes[c], c});
+    std::sort(order.begin(), order.end(), std::greater<>());
+    std::unordered_set<i64> keep;
+    for (i64 i = 0; i < std::min<i64>(cur, keep_n); ++i)
+        if (order[i].first >= min_size) keep.insert(order[i].second);
+    std::vector<size_t> pre(nv + 1, 0);
+    for (size_t i = 0; i < nv; ++i) {
+        bool k = keep.count(comp[i]) != 0;
+        pre[i + 1] = pre[i] + (k ? 1 : 0);
+        if (k)
+            for (int c = 0; c < 3; ++c) m.vertices[pre[i] * 3 + c] = m.vertices[i * 3 + c];
+    }
+    m.vertices.resize(pre[nv] * 3);
+    std::vector<int32_t> tri;
+    for (size_t f = 0; f < nt; ++f) {
+        int32_t a = m.triangles[f * 3], b = m.triangles[f * 3 + 1], c = m.triangles[f * 3 + 2];
+        if (pre[a + 1] > pre[a] && pre[b + 1] > pre[b] && pre[c + 1] > pre[c]) {
+            tri.push_back((int32_t)pre[a]);
+            tri.push_back((int32_t)pre[b]);
+            tri.push_back((int32_t)pre[c]);
+        }
+    }
+    m.triangles.swap(tri);
+}
+}  // namespace contour
+
 // ---------------------------------------------------------------------------------
 // C API
 // ---------------------------------------------------------------------------------
@@ -900,5 +1176,38 @@ void orc_decode(const float* code, i64 v, int c, const float* w1, const float* b
         }
         if (sizes) out[q * 2] *= sizes[q];
     }
+}
+// contouring + component filter; results are kept in a per-thread mesh until fetched
+static thread_local contour::Mesh g_mesh;
+int orc_create_triangle_mesh(const float* values, i64 num_values, const i64* duals, i64 num_duals,
+                             const float* positions, float threshold, i64* sizes) {
+    g_mesh = contour::Mesh();
+    contour::create_triangle_mesh(g_mesh, values, (size_t)num_values, duals, (size_t)num_duals, positions,
+                                  threshold);
+    sizes[0] = (i64)g_mesh.vertices.size() / 3;
+    sizes[1] = (i64)g_mesh.triangles.size() / 3;
+    return g_mesh.error;
+}
+void orc_set_mesh(const float* vertices, i64 nv, const int32_t* triangles, i64 nt) {
+    g_mesh = contour::Mesh();
+    g_mesh.vertices.assign(vertices, vertices + 3 * nv);
+    g_mesh.triangles.assign(triangles, triangles + 3 * nt);
+}
+void orc_remove_connected_components(i64 keep_n, i64 min_size, i64* sizes) {
+    contour::remove_components(g_mesh, keep_n, min_size);
+    sizes[0] = (i64)g_mesh.vertices.size() / 3;
+    sizes[1] = (i64)g_mesh.triangles.size() / 3;
+}
+void orc_get_mesh(float* vertices, int32_t* triangles) {
+    if (vertices) memcpy(vertices, g_mesh.vertices.data(), 4 * g_mesh.vertices.size());
+    if (triangles) memcpy(triangles, g_mesh.triangles.data(), 4 * g_mesh.triangles.size());
+}
+// iteration order of a std::unordered_set<size_t> filled in the given order (for checking the
+// device side emulation of libstdc++'s container)
+void orc_unordered_set_order(const u64* xs, int n, u64* out) {
+    std::unordered_set<size_t> s;
+    for (int i = 0; i < n; ++i) s.insert((size_t)xs[i]);
+    int k = 0;
+    for (size_t v : s) out[k++] = v;
 }
 }  // extern "C"

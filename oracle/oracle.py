@@ -294,3 +294,41 @@ def window_poly6(r_sqr):
     one = np.float32(1)
     t = one - r_sqr
     return np.clip(t * t * t, np.float32(0), one).astype(np.float32)
+
+
+# ---- "next" rows D.2 / D.3: dual contouring and component filter --------------------------------
+def create_triangle_mesh(values, dual_vertex_indices, node_positions, threshold=1.0):
+    """asr::CreateTriangleMesh (cpp/lib/contouring.cpp:29-460) -> (vertices f32[M,3], triangles i32[T,3])"""
+    values = _f32(values)
+    duals = np.ascontiguousarray(dual_vertex_indices, np.int64)
+    pos = _f32(node_positions)
+    sz = np.zeros(2, np.int64)
+    err = lib().orc_create_triangle_mesh(_p(values), i64(values.shape[0]), _p(duals), i64(duals.shape[0]),
+                                         _p(pos), ctypes.c_float(threshold), _p(sz))
+    if err:
+        raise RuntimeError("this should not happen: cannot sort duals")
+    v = np.zeros((int(sz[0]), 3), np.float32)
+    t = np.zeros((int(sz[1]), 3), np.int32)
+    lib().orc_get_mesh(_p(v), _p(t))
+    return v, t
+
+
+def remove_connected_components(vertices, triangles, keep_n_largest_components, minimum_component_size=3):
+    """asr::RemoveConnectedComponents (cpp/lib/postprocess.cpp:141-176)"""
+    v = _f32(vertices)
+    t = np.ascontiguousarray(triangles, np.int32)
+    lib().orc_set_mesh(_p(v), i64(v.shape[0]), _p(t), i64(t.shape[0]))
+    sz = np.zeros(2, np.int64)
+    lib().orc_remove_connected_components(i64(min(int(keep_n_largest_components), 2**62)),
+                                          i64(int(minimum_component_size)), _p(sz))
+    v2 = np.zeros((int(sz[0]), 3), np.float32)
+    t2 = np.zeros((int(sz[1]), 3), np.int32)
+    lib().orc_get_mesh(_p(v2), _p(t2))
+    return v2, t2
+
+
+def unordered_set_order(xs):
+    xs = np.ascontiguousarray(xs, np.uint64)
+    out = np.zeros(len(xs), np.uint64)
+    lib().orc_unordered_set_order(_p(xs), int(len(xs)), _p(out))
+    return out

@@ -146,3 +146,27 @@ def oracle_forward(points, normals, radii, bb_min, bb_max, weights, scale_sdf=Tr
     out = oracle_network(item, points, normals, weights, scale_sdf, timings)
     out.update(item)
     return out
+
+
+# ---- contouring test field ------------------------------------------------------------------------
+SPHERE_MESH_PIN = (1113, 2258, "ce9b39826aeff585")
+
+
+def sphere_field(n, seed=0, noise=0.0):
+    """analytic values on the adaptive grid of a sphere cloud: [signed distance to the unit sphere,
+    |sdf| / voxel size]; `noise` (in voxel sizes) roughens the field so that fans, quads and
+    boundary edges all occur"""
+    from asr_hip import synth
+    pts, _ = synth.sphere_cloud(n, seed)
+    rad = synth.knn_radii(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    o = O.Oracle()
+    o.build_octree(pts, rad, *bb)
+    g = o.create_grids(1)[0]
+    du = o.create_dual_vertex_indices().astype(np.int64)
+    c, vs = g["voxel_centers"], g["voxel_sizes"]
+    sd = (np.linalg.norm(c, axis=1) - 1.0).astype(np.float32)
+    if noise:
+        sd = sd + np.random.default_rng(seed + 7).normal(0, noise, sd.shape).astype(np.float32) * vs
+    values = np.stack([sd, np.abs(sd) / vs], 1).astype(np.float32)
+    return g, du, values

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity
 from asr_hip import _lib, synth
 from oracle import oracle as O
 
@@ -236,3 +237,74 @@ def test_error_behaviour(gpu):
     rc = ctx.lib.asr_hip_octree_build(ctx._h, None, None, None, ctypes.c_int64(3), ctypes.c_float(1), 21,
                                       None, None)
     assert rc == 1 and b"null" in ctx.lib.asr_hip_last_error(ctx._h)
+
+
+# ---- "next" rows D.2 / D.3: contouring and component filter ---------------------------------------
+def _gpu_mesh(values, du, centers, thr=1.0):
+    from asr_hip import ops
+    dev = torch.device("cuda:0")
+    v, t = ops.contour(torch.from_numpy(values).to(dev), torch.from_numpy(du).to(dev),
+                       torch.from_numpy(centers).to(dev), thr)
+    return v.cpu().numpy(), t.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,noise", [(5000, 1, 0.0), (5000, 1, 0.3), (20000, 0, 0.0), (30000, 3, 1.0)])
+def test_contour_bit_exact(n, seed, noise):
+    """vertices (float bits) and triangle corner order equal to the serial restatement"""
+    g, du, values = parity.sphere_field(n, seed=seed, noise=noise)
+    want_v, want_t = O.create_triangle_mesh(values, du, g["voxel_centers"], 1.0)
+    got_v, got_t = _gpu_mesh(values, du, g["voxel_centers"])
+    assert got_v.shape == want_v.shape and got_t.shape == want_t.shape
+    assert np.array_equal(got_v.view(np.uint32), want_v.view(np.uint32))
+    assert np.array_equal(got_t, want_t)
+
+
+@pytest.mark.gpu
+def test_contour_golden_pin_and_edge_cases():
+    import hashlib
+    g, du, values = parity.sphere_field(5000, seed=1, noise=0.3)
+    v, t = _gpu_mesh(values, du, g["voxel_centers"])
+    h = hashlib.sha256(v.tobytes() + t.tobytes()).hexdigest()
+    assert (v.shape[0], t.shape[0], h[:16]) == parity.SPHERE_MESH_PIN
+    far = values.copy()
+    far[:, 1] = 5.0
+    v0, t0 = _gpu_mesh(far, du, g["voxel_centers"])
+    assert v0.shape == (0, 3) and t0.shape == (0, 3)
+    v1, t1 = _gpu_mesh(values, du[:0], g["voxel_centers"])
+    assert v1.shape == (0, 3) and t1.shape == (0, 3)
+    # threshold gate partially active
+    want = O.create_triangle_mesh(values, du, g["voxel_centers"], 0.4)
+    got = _gpu_mesh(values, du, g["voxel_centers"], 0.4)
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)) and np.array_equal(got[1], want[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep_n,min_size", [(1, 3), (2, 3), (3, 1), (2**63 - 1, 3), (2**63 - 1, 10), (5, 40)])
+def test_remove_components_bit_exact(keep_n, min_size):
+    from asr_hip import ops
+    g, du, values = parity.sphere_field(20000, seed=2, noise=1.0)  # noisy field: many small components
+    v, t = O.create_triangle_mesh(values, du, g["voxel_centers"], 1.0)
+    want_v, want_t = O.remove_connected_components(v, t, keep_n, min_size)
+    dev = torch.device("cuda:0")
+    got_v, got_t = ops.remove_components(torch.from_numpy(v).to(dev), torch.from_numpy(t).to(dev), keep_n, min_size)
+    assert np.array_equal(got_v.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+    assert np.array_equal(got_t.cpu().numpy(), want_t)
+
+
+@pytest.mark.gpu
+def test_remove_components_small_cases():
+    import adaptivesurfacereconstruction as asr
+    v = np.arange(33, dtype=np.float32).reshape(11, 3)
+    t = np.array([[0, 1, 2], [3, 4, 5], [4, 5, 6], [7, 8, 9]], np.int32)
+    for keep_n, min_size in [(1, 3), (2, 3), (2**63 - 1, 3), (2**63 - 1, 4), (2**63 - 1, 1), (0, 1)]:
+        want = O.remove_connected_components(v, t, keep_n, min_size)
+        got = asr.remove_connected_components(v, t, keep_n, min_size)
+        assert np.array_equal(got["vertices"], want[0]) and np.array_equal(got["triangles"], want[1])
+        assert got["vertices"].dtype == np.float32 and got["triangles"].dtype == np.int32
+    got = asr.remove_connected_components(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), 1)
+    assert got["vertices"].shape == (0, 3) and got["triangles"].shape == (0, 3)
+    with pytest.raises(ValueError):
+        asr.remove_connected_components(np.zeros((4, 2), np.float32), t, 1)
+    with pytest.raises(RuntimeError):
+        asr.remove_connected_components(v[:5], t, 1)  # triangle index out of range

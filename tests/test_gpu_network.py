@@ -254,6 +254,54 @@ def test_whole_path_against_oracle_fresh_cloud(gpu):
     assert torch.equal(values, v2)
 
 
+def test_reconstruct_surface_end_to_end(gpu):
+    """module.cpp:291-346: pre-filter -> values -> contouring -> component filter.  The mesh is compared
+    bit for bit with the serial restatement run on the SAME values (north_star: indexing bit-exact given
+    identical values); the values themselves are covered by the 1e-5 tests above."""
+    import adaptivesurfacereconstruction as asr
+    from asr_hip.pipeline import ImplicitPipeline
+    p, q = synth.scan_cloud(6000, seed=31, device="cpu")
+    pts, nrm = p.numpy(), q.numpy()
+    weights = synth.make_weights(4, seed=31)
+    for given_radii in (False, True):
+        if given_radii:
+            rad_in = O.knn_radius(pts, 24)
+            counts = O.radius_count(pts, rad_in)
+            from asr_hip import ops
+            inl = ops.density_inlier(counts, 10.0)
+            out = asr.reconstruct_surface(pts, nrm, rad_in, weights=weights, keep_n_connected_components=4)
+            rad = rad_in
+        else:
+            rad = O.knn_radius(pts, 24)
+            d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2)
+            d2 = (d2[..., 0] + d2[..., 1]) + d2[..., 2]
+            kth = np.sort(d2, axis=1)[:, 23]
+            votes = ((d2 <= kth[:, None]) & (rad[None, :] < (rad * np.float32(0.5))[:, None])).sum(1)
+            inl = votes < 1
+            out = asr.reconstruct_surface(pts, nrm, weights=weights, keep_n_connected_components=4)
+        fp, fn, fr = pts[inl], nrm[inl], rad[inl]
+        bb = (fp.min(0), fp.max(0))
+        pipe = ImplicitPipeline(weights, device=gpu)
+        values = pipe.forward(_t(fp, gpu), _t(fn, gpu), _t(fr, gpu), *bb).cpu().numpy()
+        o = O.Oracle()
+        o.build_octree(fp, fr, *bb)
+        g0 = o.create_grids(1)[0]
+        du = o.create_dual_vertex_indices().astype(np.int64)
+        assert np.array_equal(pipe.dual_cells().cpu().numpy(), du)
+        v, t = O.create_triangle_mesh(values, du, g0["voxel_centers"], 1.0)
+        v, t = O.remove_connected_components(v, t, 4, 3)
+        assert out["vertices"].dtype == np.float32 and out["triangles"].dtype == np.int32
+        assert t.shape[0] > 100
+        assert np.array_equal(out["vertices"].view(np.uint32), v.view(np.uint32))
+        assert np.array_equal(out["triangles"], t)
+    with pytest.raises(RuntimeError):
+        asr.reconstruct_surface(pts[:0], nrm[:0], weights=weights)
+    with pytest.raises(ValueError):
+        asr.reconstruct_surface(pts, nrm[:10], weights=weights)
+    with pytest.raises(RuntimeError):
+        asr.reconstruct_surface(pts, nrm)  # no weights anywhere
+
+
 def test_pipeline_errors(gpu):
     from asr_hip.pipeline import ImplicitPipeline
     from asr_hip._lib import AsrHipError

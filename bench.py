@@ -111,6 +111,22 @@ def cpu_baseline(n_sample, seed):
                       (n_sample, dt, {k: round(v, 2) for k, v in timings.items()})}
 
 
+def mesh_stage(pipe, synth):
+    """Outside the timed region and not part of `value`: the stage after the path (dual cells, dual
+    contouring, component filter) on the analytic signed distance of the synthetic scene -- random
+    weights give no surface to contour."""
+    centers, vs = pipe.get("voxel_centers0"), pipe.get("voxel_sizes0")
+    sdf = synth._scene_sdf(centers)
+    field = torch.stack([sdf, sdf.abs() / vs], 1).contiguous()
+    pipe.mesh(values=field)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    v, t = pipe.mesh(values=field)
+    torch.cuda.synchronize()
+    return {"ms": round((time.perf_counter() - t0) * 1e3, 2), "vertices": int(v.shape[0]),
+            "triangles": int(t.shape[0]), "field": "analytic scene sdf on grid 0"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +189,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world, dev)
     assert values.shape[0] == pipe.sizes.num_voxels[0] and bool(torch.isfinite(values).all())
+    mesh_info = mesh_stage(pipe, synth) if rank == 0 else None
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -203,7 +220,8 @@ def main():
                        "agg_pairs": int(pipe.sizes.num_agg_pairs),
                        "parallelism": "one scan per GPU, no collective on the data path",
                        "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
-                       "untimed_knn24_radii_ms": round(t_knn * 1e3, 1)},
+                       "untimed_knn24_radii_ms": round(t_knn * 1e3, 1),
+                       "untimed_mesh_stage": mesh_info},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                          "traffic": tr[0] if tr else None,
@@ -215,6 +233,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # the other ranks wait for rank 0's cpu_baseline before tearing down
         dist.destroy_process_group()
 
 

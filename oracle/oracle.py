@@ -22,8 +22,9 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(_HERE, "libasr_oracle.so")
-        if not os.path.exists(path):
-            build()
+        src = os.path.join(_HERE, "asr_oracle.cpp")
+        if not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path) + 1:
+            build()  # never run with a library older than its source
         _LIB = ctypes.CDLL(path)
         _LIB.orc_create.restype = ctypes.c_void_p
         for name in ("orc_octree_build", "orc_num_nodes", "orc_leaf_neighbors", "orc_create_duals",

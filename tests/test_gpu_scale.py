@@ -42,6 +42,19 @@ def test_one_million_points_vs_oracle(gpu):
     assert np.abs(pipe.get("code").cpu().numpy() - ref["code"]).max() <= 2e-5 * scale
     vs = max(1.0, float(np.abs(ref["values"]).max()))
     assert np.abs(values.cpu().numpy() - ref["values"]).max() <= 1e-5 * vs
+    # contouring + component filter: bit exact vs the serial restatement on the same field
+    from oracle import oracle as O
+    centers = pipe.get("voxel_centers0")
+    sdf = synth._scene_sdf(centers)
+    field = torch.stack([sdf, sdf.abs() / pipe.get("voxel_sizes0")], 1).contiguous()
+    duals = pipe.dual_cells()
+    for fld, keep_n in ((field, 2**63 - 1), (values, 5)):
+        got_v, got_t = pipe.mesh(values=fld, keep_n_connected_components=keep_n)
+        want_v, want_t = O.create_triangle_mesh(fld.cpu().numpy(), duals.cpu().numpy(), centers.cpu().numpy(), 1.0)
+        want_v, want_t = O.remove_connected_components(want_v, want_t, keep_n, 3)
+        assert np.array_equal(got_v.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
+        assert np.array_equal(got_t.cpu().numpy(), want_t)
+    assert got_t.shape[0] > 0
 
 
 def test_ten_million_points_properties(gpu):
@@ -100,3 +113,24 @@ def test_ten_million_points_properties(gpu):
     # same input again on the same context: identical bits
     v2 = pipe.forward(pts, nrm, radii, bb[0], bb[1])
     assert torch.equal(values, v2)
+    # mesh stage on the analytic field of the scene: a closed oriented surface near the zero set
+    centers = pipe.get("voxel_centers0")
+    sdf = synth._scene_sdf(centers)
+    field = torch.stack([sdf, sdf.abs() / vs], 1).contiguous()
+    mv, mt = pipe.mesh(values=field)
+    assert mv.shape[0] > 500_000 and mt.shape[0] > 1_000_000
+    assert int(mt.min()) >= 0 and int(mt.max()) == mv.shape[0] - 1
+    tl = mt.long()
+    assert bool(((tl[:, 0] != tl[:, 1]) & (tl[:, 1] != tl[:, 2]) & (tl[:, 0] != tl[:, 2])).all())
+    # vertices lie within one finest-level voxel of the analytic surface
+    assert float(synth._scene_sdf(mv).abs().max()) < float(vs.max())
+    # almost every directed edge appears once (consistent orientation, contouring.cpp:357); the rest are
+    # the non-manifold spots the method leaves at level transitions
+    e = torch.cat([tl[:, [0, 1]], tl[:, [1, 2]], tl[:, [2, 0]]])
+    code = e[:, 0] * mv.shape[0] + e[:, 1]
+    uniq, cnt = torch.unique(code, return_counts=True)
+    assert float((cnt == 1).float().mean()) > 0.95
+    rev = e[:, 1] * mv.shape[0] + e[:, 0]
+    assert float(torch.isin(rev, uniq).float().mean()) > 0.9       # closed up to the scan's open boundary
+    mv2, mt2 = pipe.mesh(values=field)
+    assert torch.equal(mv, mv2) and torch.equal(mt, mt2)

@@ -5,6 +5,8 @@
 //   importance sums, a14 decoder MLP.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "asr_common.h"
 
 namespace {
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
     bmask &= (1ull << K) - 1;  // K <= 56
+    if (a.algo == 9) bmask = 0;        // measurement aid (ASR_SCONV_DRY=1): prologue + epilogue only
 
     f32x4 acc[NT];
 #pragma unroll
@@ -397,77 +400,87 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     // staging geometry: thread -> (panel row, float4 column) for SV float4 each
 
     // ---- software pipeline over (slot, panel) steps ------------------------------------------
-    unsigned long long todo = bmask;
-    int k_cur = todo ? __builtin_ctzll(todo) : -1;
-    int p_cur = 0;
-    float4 stage[SV];
-    float4 a_nxt[NJ];
+    // Prefetch distance is TWO steps, held in registers: at step i the weight panel and the feature
+    // gather of step i+2 are issued, the panel of step i+1 (loaded during step i-1) is written to
+    // the other LDS buffer after the MFMAs.  One step of MFMAs (0.4 us for the narrow layers) is
+    // shorter than an L2 / HBM round trip, two are not.  Slots alternate by step parity (the loop is
+    // unrolled by two) so that no in-flight register is ever moved, and every load is unconditional
+    // (finished sequences read the zero line): a guarded or moved load would turn the counted
+    // s_waitcnt vmcnt(n) into vmcnt(0).
+    // sequence state (wave uniform scalars): remaining slot mask, current slot (-1 = finished), panel
+#define ASR_SEQ_ADVANCE(todo, k, p)                          \
+    if ((k) >= 0 && ++(p) == npanel) {                       \
+        (p) = 0;                                             \
+        (todo) &= (todo)-1;                                  \
+        (k) = (todo) ? __builtin_ctzll(todo) : -1;           \
+    }
+    f32x4 stage0[SV], stage1[SV];  // separate objects (not stage[2][SV]): they must stay in registers
+    f32x4 a_q0[NJ], a_q1[NJ];
+    float imp_q0 = 1.f, imp_q1 = 1.f;
 
-    auto load_panel = [&](int k, int pnl) {
-        const float* Wk = a.filters + (i64)k * cin * cout;
+    auto load_panel = [&](const int qk, const int qp, f32x4 (&st)[SV]) __attribute__((always_inline)) {
+        const float* Wk = a.filters + (i64)(qk < 0 ? 0 : qk) * cin * cout;
 #pragma unroll
         for (int s = 0; s < SV; ++s) {
             int e = tid + s * NTHR;            // float4 index inside the panel
             int pr = e / (NCOL / 4);          // panel row
             int pc = (e % (NCOL / 4)) * 4;    // column
-            int ci = pnl * KC + pr, col = n0 + pc;
+            int ci = qp * KC + pr, col = n0 + pc;
             // cout % 4 == 0 and col % 4 == 0: a float4 is entirely inside or outside the row.
             // Out-of-range entries read a zero line instead of being masked after the load: a
             // select on the loaded value would force the vmcnt wait in front of the MFMAs.
-            bool ok = ci < cin && col < cout;
+            bool ok = qk >= 0 && ci < cin && col < cout;
             const float* src = ok ? Wk + (i64)ci * cout + col : zeros;
-            float4 v = *reinterpret_cast<const float4*>(src);
-            stage[s] = v;
+            st[s] = *reinterpret_cast<const f32x4*>(src);
         }
     };
-    auto store_panel = [&](int buf) {
+    auto store_panel = [&](int buf, const f32x4 (&st)[SV]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < SV; ++s) {
             int e = tid + s * NTHR;
             int pr = e / (NCOL / 4);
             int pc = (e % (NCOL / 4)) * 4;
-            *reinterpret_cast<float4*>(&s_B[buf][pr * BLD + pc]) = stage[s];
+            *reinterpret_cast<f32x4*>(&s_B[buf][pr * BLD + pc]) = st[s];
         }
     };
-    float imp_nxt = 1.f;
-    auto gather_a = [&](int k, int pnl) {
-        const int idx = s_nbr[lrow * NBR_LD + k];
+    auto gather_a = [&](const int qk, const int qp, f32x4 (&aq)[NJ], float& imp) __attribute__((always_inline)) {
+        const int idx = qk < 0 ? -1 : s_nbr[lrow * NBR_LD + qk];
         const bool valid = idx >= 0;
         const float* frow = a.inp_features + (i64)(valid ? idx : 0) * a.inp_ld;
-        if (IMP) imp_nxt = valid ? s_w[lrow * NBR_LD + k] : 0.f;
+        if (IMP) imp = valid ? s_w[lrow * NBR_LD + qk] : 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            int c = pnl * KC + 16 * j + 4 * g;
+            int c = qp * KC + 16 * j + 4 * g;
             const float* src = (valid && c < cin) ? frow + c : zeros;
-            a_nxt[j] = *reinterpret_cast<const float4*>(src);
+            aq[j] = *reinterpret_cast<const f32x4*>(src);
         }
     };
 
+    unsigned long long todo1 = bmask;  // the sequence position one step ahead of the current one
+    int k_cur = bmask ? __builtin_ctzll(bmask) : -1, p_cur = 0;
+    int k1 = k_cur, p1 = 0;
+    ASR_SEQ_ADVANCE(todo1, k1, p1)
     if (k_cur >= 0) {
-        load_panel(k_cur, 0);
-        gather_a(k_cur, 0);
-        store_panel(0);
+        load_panel(k_cur, p_cur, stage0);
+        gather_a(k_cur, p_cur, a_q0, imp_q0);
+        store_panel(0, stage0);
+        load_panel(k1, p1, stage1);
+        gather_a(k1, p1, a_q1, imp_q1);
     }
     __syncthreads();
     int buf = 0;
-    while (k_cur >= 0) {
-        // next step
-        int k_nxt = k_cur, p_nxt = p_cur + 1;
-        if (p_nxt == npanel) {
-            p_nxt = 0;
-            todo &= todo - 1;
-            k_nxt = todo ? __builtin_ctzll(todo) : -1;
-        }
-        float4 a_cur[NJ];
+    // one step: aq = gather of this step, st_next = panel of the next step (in flight), st_free free
+    auto step = [&](f32x4 (&aq)[NJ], float& imp, f32x4 (&st_free)[SV], f32x4 (&st_next)[SV]) __attribute__((always_inline)) {
+        int k2 = k1, p2 = p1;
+        ASR_SEQ_ADVANCE(todo1, k2, p2)   // todo1 now belongs to the position two steps ahead
+        f32x4 a_cur[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) a_cur[j] = a_nxt[j];
-        const float imp_cur = imp_nxt;
-        if (k_nxt >= 0) {
-            load_panel(k_nxt, p_nxt);   // global loads stay in flight during the MFMAs below
-            gather_a(k_nxt, p_nxt);
-        }
+        for (int j = 0; j < NJ; ++j) a_cur[j] = aq[j];
+        const float imp_cur = imp;
+        load_panel(k2, p2, st_free);    // two steps ahead; stays in flight across the barrier
+        gather_a(k2, p2, aq, imp);
         // a wave whose 16 rows lack slot k_cur skips the MFMAs (PMC: executing them
-        // unconditionally doubles the MFMA work, the block-level slot union is ~2x a wave's)
+        // unconditionally doubles the MFMA work)
         if ((wmask >> k_cur) & 1) {
             const float* sb = &s_B[buf][(4 * g) * BLD + ncol];
             float bv[2][NT];
@@ -489,12 +502,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[jt & 1][nb], acc[nb], 0, 0, 0);
             }
         }
-        if (k_nxt >= 0) store_panel(buf ^ 1);
+        store_panel(buf ^ 1, st_next);  // panel of the next step, loaded one step ago
         __syncthreads();
         buf ^= 1;
-        k_cur = k_nxt;
-        p_cur = p_nxt;
+        k_cur = k1;
+        p_cur = p1;
+        k1 = k2;
+        p1 = p2;
+    };
+    while (k_cur >= 0) {
+        step(a_q0, imp_q0, stage0, stage1);
+        if (k_cur < 0) break;
+        step(a_q1, imp_q1, stage1, stage0);
     }
+#undef ASR_SEQ_ADVANCE
 
     // epilogue: acc[nb][i] is C[row = 4*g + i][col = ncol] of the wave's 16 x 16 block.
     // All loads (bias, residual) are unconditional (absent -> zero line) and issued before the
@@ -719,13 +740,16 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     const float* zeros = nullptr;
     ASR_TRY(asr_ctx_zeros(ctx, &zeros));
     const bool imp = a.inp_importance || a.neighbors_importance;
+    static const bool dry = getenv("ASR_SCONV_DRY") && atoi(getenv("ASR_SCONV_DRY"));
+    if (dry) a.algo = 9;
     // widest column tile that fits cout, narrowed while the launch has too few blocks to fill
     // 256 CUs (coarse grids have only a few thousand rows; the gather is then repeated per
     // column chunk, which those levels can afford).  128-row blocks (8 waves) halve the weight
     // panel traffic per MFMA and are used whenever they still give enough blocks.
     int nt = a.cout > 128 ? 16 : a.cout > 64 ? 8 : a.cout > 32 ? 4 : a.cout > 16 ? 2 : 1;
     const i64 tiles64 = (a.num_out + 63) / 64;
-    while (nt > 2 && tiles64 * ((a.cout + nt * 16 - 1) / (nt * 16)) < 1024) nt >>= 1;
+    static const i64 min_blocks = getenv("ASR_SCONV_MIN_BLOCKS") ? atoll(getenv("ASR_SCONV_MIN_BLOCKS")) : 3072;
+    while (nt > 2 && tiles64 * ((a.cout + nt * 16 - 1) / (nt * 16)) < min_blocks) nt >>= 1;
     const i64 tiles128 = (a.num_out + 127) / 128;
     static const i64 wide_min = getenv("ASR_SCONV_WIDE_MIN") ? atoll(getenv("ASR_SCONV_WIDE_MIN")) : 2048;
     const bool wide = nt >= 2 && tiles128 * ((a.cout + nt * 16 - 1) / (nt * 16)) >= wide_min;

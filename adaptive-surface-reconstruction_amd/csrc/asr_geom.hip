@@ -6,6 +6,7 @@
 // (64-bit CAS), rocPRIM radix sort / scan for ordering, one thread per voxel / point / pair.
 // Compiled with -ffp-contract=off: the float expressions below must round exactly like the
 // reference's.
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <rocprim/rocprim.hpp>
@@ -483,19 +484,27 @@ __device__ inline float sqdist3(float ax, float ay, float az, float bx, float by
 // from 0 to tens of thousands (a coarse voxel near the surface sees every point within one voxel
 // size), so a thread-per-query loop is dominated by its longest row.
 // MODE 0: count, MODE 1: write (distance, index) keys in candidate order (sorted afterwards)
+// MODE 2: single pass.  Hits are collected in LDS; a row of at most RADIUS_LIGHT hits is ranked
+// inside the wave (rank = number of smaller keys, keys are unique) and written, sorted, to the
+// row's fixed slot tmp[q * RADIUS_LIGHT ..]; longer rows are only counted and appended to the
+// heavy list, which MODE 1 (row list + bases) and a segmented sort handle afterwards.
+constexpr int RADIUS_LIGHT = 64;
 template <int MODE>
 __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
                                                       const float* centers, const float* sizes,
                                                       i64 v, HashTab t, const int32_t* start,
                                                       const int32_t* end, i64* counts,
                                                       const i64* rs, u64* keys_out,
-                                                      int32_t* row_out) {
+                                                      int32_t* row_out, const int32_t* row_list,
+                                                      int32_t* heavy_out, int* heavy_cnt) {
     __shared__ int s_pref[4][28];
     __shared__ int s_beg[4][28];
+    __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 q = blockIdx.x * (i64)4 + wave;
-    if (MODE == 0 && q == v && lane == 0) counts[v] = 0;
-    if (q >= v) return;
+    const i64 qi = blockIdx.x * (i64)4 + wave;  // position in the row list (or the row itself)
+    if (MODE != 1 && qi == v && lane == 0) counts[v] = 0;
+    if (qi >= v) return;
+    const i64 q = row_list ? row_list[qi] : qi;
     const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
     const float r = sizes[q];
     const float r2 = r * r;
@@ -529,7 +538,7 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     const int total = __shfl(pre, 26, 64);
     __builtin_amdgcn_wave_barrier();
     i64 found = 0;
-    const i64 base = MODE == 1 ? rs[q] : 0;
+    const i64 base = MODE == 1 ? rs[qi] : 0;
     for (int i0 = 0; i0 < total; i0 += 64) {
         const int i = i0 + lane;
         bool hit = false;
@@ -554,11 +563,73 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
         if (MODE == 1 && hit) {
             const i64 o = base + found + __popcll(m & ((1ull << lane) - 1));
             keys_out[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
-            row_out[o] = (int32_t)q;
+            row_out[o] = (int32_t)qi;
+        }
+        if (MODE == 2 && hit) {
+            const i64 o = found + __popcll(m & ((1ull << lane) - 1));
+            if (o < RADIUS_LIGHT) s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
         }
         found += __popcll(m);
     }
-    if (MODE == 0 && lane == 0) counts[q] = found;
+    if (MODE != 1 && lane == 0) counts[q] = found;
+    if (MODE == 2) {
+        if (found > RADIUS_LIGHT) {
+            if (lane == 0) heavy_out[atomicAdd(heavy_cnt, 1)] = (int32_t)q;
+            return;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int h = (int)found;
+        const u64 mine = lane < h ? s_keys[wave][lane] : 0;
+        int rank = 0;
+        for (int j = 0; j < h; ++j) rank += s_keys[wave][j] < mine;  // LDS broadcast reads
+        if (lane < h) keys_out[q * RADIUS_LIGHT + rank] = mine;
+    }
+}
+// copies the light rows from their fixed slots to the CSR positions: 16 lanes per row
+__global__ void k_radius_place(const u64* tmp, const i64* rs, i64 v, const float* sizes, const float* radii,
+                               int32_t* idx, float* dist, float* compat) {
+    const i64 q = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (q >= v) return;
+    const i64 b = rs[q];
+    const int cnt = (int)(rs[q + 1] - b);
+    if (cnt > RADIUS_LIGHT) return;  // heavy row: written by k_radius_unpack_heavy
+    const float a = sizes[q];
+    for (int i = l; i < cnt; i += 16) {
+        const u64 k = tmp[q * RADIUS_LIGHT + i];
+        const int32_t id = (int32_t)(k & 0xffffffffu);
+        idx[b + i] = id;
+        dist[b + i] = __uint_as_float((unsigned)(k >> 32));
+        if (compat) {
+            float bb = 2 * radii[id];
+            float ratio = fminf(a, bb) / fmaxf(a, bb);
+            compat[b + i] = ratio * ratio;
+        }
+    }
+}
+__global__ void k_heavy_counts(const int32_t* heavy, i64 nh, const i64* rs, i64* cnt) {
+    i64 j = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (j > nh) return;
+    cnt[j] = j < nh ? rs[heavy[j] + 1] - rs[heavy[j]] : 0;
+}
+__global__ void k_radius_unpack_heavy(const u64* keys, const int32_t* hrow, i64 num_pairs, const int32_t* heavy,
+                                      const i64* hoff, const i64* rs, const float* sizes, const float* radii,
+                                      int32_t* idx, float* dist, float* compat) {
+    i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (p >= num_pairs) return;
+    const int j = hrow[p];
+    const i64 q = heavy[j];
+    const i64 o = rs[q] + (p - hoff[j]);
+    const u64 k = keys[p];
+    const int32_t id = (int32_t)(k & 0xffffffffu);
+    idx[o] = id;
+    dist[o] = __uint_as_float((unsigned)(k >> 32));
+    if (compat) {
+        float a = sizes[q];
+        float bb = 2 * radii[id];
+        float ratio = fminf(a, bb) / fmaxf(a, bb);
+        compat[o] = ratio * ratio;
+    }
 }
 // Exact k-th nearest neighbour distance, one wave per point (in Morton order).  Level by level,
 // finest first: lanes 0..26 look up the 3^3 cells around the point's cell; if they hold >= k points
@@ -690,23 +761,6 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
 }
 
 // rows are sorted by a segmented radix sort on (distance bits, index) keys; unpack + compat
-__global__ void k_radius_unpack(const u64* keys, const int32_t* rows, i64 num_pairs,
-                                const float* sizes, const float* radii, int32_t* idx, float* dist,
-                                float* compat) {
-    i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (p >= num_pairs) return;
-    const u64 k = keys[p];
-    const int32_t id = (int32_t)(k & 0xffffffffu);
-    idx[p] = id;
-    dist[p] = __uint_as_float((unsigned)(k >> 32));
-    if (compat) {
-        float a = sizes[rows[p]];
-        float bb = 2 * radii[id];
-        float ratio = fminf(a, bb) / fmaxf(a, bb);
-        compat[p] = ratio * ratio;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // a11: CSR inversion
 // ------------------------------------------------------------------------------------------
@@ -749,6 +803,34 @@ __global__ void k_row_masks(const uint8_t* kidx, const i64* rs, i64 v, u64* mask
     for (i64 p = rs[q]; p < rs[q + 1]; ++p) m |= u64(1) << (kidx[p] & 63);
     masks[q] = m;
     ids[q] = (int32_t)q;
+}
+// Longest-processing-time order of the 128-row chunks inside each segment: a block's cost is the
+// number of slots in the union of its rows' masks (one weight panel walk + barrier per slot), so
+// heavy tiles start first and the tail of a launch is made of light ones.
+__global__ void k_tile_cost(const int32_t* perm, const u64* masks, i64 v, int32_t* cost) {
+    const i64 tile = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;  // one wave per 64-row tile
+    const int lane = threadIdx.x & 63;
+    if (tile * 64 >= v) return;
+    const i64 r = tile * 64 + lane;
+    u64 m = r < v ? masks[perm[r]] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+    if (lane == 0) cost[tile] = __popcll(m);
+}
+__global__ void k_chunk_key(const int32_t* tile_cost, i64 v, i64 seg, int32_t* key, int32_t* ids) {
+    i64 c = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    i64 r0 = c * 128;
+    if (r0 >= v) return;
+    int cost = tile_cost[2 * c] + (r0 + 64 < v ? tile_cost[2 * c + 1] : 0);
+    if (r0 + 128 > v) cost = 0;  // the partial chunk stays last
+    key[c] = (int32_t)((r0 / seg) * 128 + (127 - cost));
+    ids[c] = (int32_t)c;
+}
+__global__ void k_chunk_apply(const int32_t* perm, const int32_t* order, i64 v, int32_t* out) {
+    i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (r >= v) return;
+    i64 src = (i64)order[r >> 7] * 128 + (r & 127);
+    out[r] = perm[src];
 }
 __global__ void k_segment_of(const int32_t* rows, i64 v, i64 seg, int32_t* out) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
@@ -1005,19 +1087,43 @@ int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs
     k_row_masks<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(kidx, rs, v, masks, ids);
     ASR_CHECK_LAUNCH(ctx);
     // order by (segment, mask) with two stable LSD radix sorts: by mask, then by segment id
-    if (seg >= v) {
-        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, perm_out, v, kbits)));
-        return ASR_HIP_OK;
+    static const bool lpt = !(getenv("ASR_ROW_LPT") && atoi(getenv("ASR_ROW_LPT")) == 0);
+    int32_t* perm_m = perm_out;  // (segment, mask) order; re-ordered by chunk cost below
+    if (lpt && v > 128) {
+        perm_m = arena_alloc<int32_t>(ctx->scratch, v);
+        if (!perm_m) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     }
-    int32_t* ids_m = arena_alloc<int32_t>(ctx->scratch, v);
-    int32_t* segk = arena_alloc<int32_t>(ctx->scratch, v);
-    int32_t* segk_s = arena_alloc<int32_t>(ctx->scratch, v);
-    if (!ids_m || !segk || !segk_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, ids_m, v, kbits)));
-    k_segment_of<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(ids_m, v, seg, segk);
-    ASR_CHECK_LAUNCH(ctx);
-    ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, segk, segk_s, ids_m, perm_out, v,
-                                          bits_for((v + seg - 1) / seg + 1))));
+    if (seg >= v) {
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, perm_m, v, kbits)));
+    } else {
+        int32_t* ids_m = arena_alloc<int32_t>(ctx->scratch, v);
+        int32_t* segk = arena_alloc<int32_t>(ctx->scratch, v);
+        int32_t* segk_s = arena_alloc<int32_t>(ctx->scratch, v);
+        if (!ids_m || !segk || !segk_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, masks, masks_s, ids, ids_m, v, kbits)));
+        k_segment_of<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(ids_m, v, seg, segk);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, segk, segk_s, ids_m, perm_m, v,
+                                              bits_for((v + seg - 1) / seg + 1))));
+    }
+    if (perm_m != perm_out) {
+        const i64 nc = (v + 127) / 128;
+        int32_t* ckey = arena_alloc<int32_t>(ctx->scratch, nc);
+        int32_t* ckey_s = arena_alloc<int32_t>(ctx->scratch, nc);
+        int32_t* cid = arena_alloc<int32_t>(ctx->scratch, nc);
+        int32_t* cid_s = arena_alloc<int32_t>(ctx->scratch, nc);
+        if (!ckey || !ckey_s || !cid || !cid_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        int32_t* tcost = arena_alloc<int32_t>(ctx->scratch, 2 * nc);
+        if (!tcost) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_tile_cost<<<grid_for(((v + 63) / 64) * 64, BLK), BLK, 0, ctx->stream>>>(perm_m, masks, v, tcost);
+        ASR_CHECK_LAUNCH(ctx);
+        k_chunk_key<<<grid_for(nc, BLK), BLK, 0, ctx->stream>>>(tcost, v, seg, ckey, cid);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, ckey, ckey_s, cid, cid_s, nc,
+                                              7 + bits_for((v + seg - 1) / seg + 1))));
+        k_chunk_apply<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(perm_m, cid_s, v, perm_out);
+        ASR_CHECK_LAUNCH(ctx);
+    }
     return ASR_HIP_OK;
 }
 
@@ -1071,6 +1177,9 @@ struct RadiusState {
     int32_t* start = nullptr;
     int32_t* end = nullptr;
     i64 n = 0, v = 0;
+    u64* tmp = nullptr;        // [v][RADIUS_LIGHT] sorted keys of the light rows
+    int32_t* heavy = nullptr;  // rows with more than RADIUS_LIGHT hits
+    i64 num_heavy = 0;
 };
 static RadiusState& rstate(asr_hip_context* ctx) {
     if (!ctx->radius_state) ctx->radius_state = new RadiusState();
@@ -1156,15 +1265,20 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     ASR_TRY(query_level_range(ctx, frame, sizes, v, &lmin, &lmax));
     ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st));
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
-    if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_radius_query<0><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(
-            *frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, counts, nullptr, nullptr,
-            nullptr);
+    st.tmp = arena_alloc<u64>(ctx->scratch, (size_t)v * RADIUS_LIGHT);
+    st.heavy = arena_alloc<int32_t>(ctx->scratch, v);
+    if (!counts || !st.tmp || !st.heavy) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 10, 0, sizeof(int), ctx->stream));
+    // one pass: counts, the sorted light rows (fixed slots) and the list of heavy rows
+    k_radius_query<2><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(
+            *frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, counts, nullptr, st.tmp,
+            nullptr, nullptr, st.heavy, ctx->d_flags + 10);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
     ASR_TRY(read_i64(ctx, rs + v, num_pairs));
     ASR_TRY(read_flags(ctx, host));
     if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search cell table overflow");
+    st.num_heavy = host[10];
     st.valid = true;
     return ASR_HIP_OK;
 }
@@ -1183,7 +1297,8 @@ int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame*
     i64* counts = arena_alloc<i64>(ctx->scratch, n + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     k_radius_query<0><<<grid_for(n + 1, 4), BLK, 0, ctx->stream>>>(
-            *frame, st.sorted, pts, radii, n, st.tab, st.start, st.end, counts, nullptr, nullptr, nullptr);
+            *frame, st.sorted, pts, radii, n, st.tab, st.start, st.end, counts, nullptr, nullptr, nullptr, nullptr,
+            nullptr, nullptr);
     ASR_CHECK_LAUNCH(ctx);
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, counts, n * sizeof(i64), hipMemcpyDeviceToDevice,
                                       ctx->stream));
@@ -1224,31 +1339,41 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
     if (!st.valid || st.n != n || st.v != v)
         ASR_FAIL(ctx, ASR_HIP_EINVAL,
                  "asr_hip_multi_radius_search_fill must follow the matching _count call");
-    i64 num_pairs = 0;
-    ASR_TRY(read_i64(ctx, rs + v, &num_pairs));
-    if (num_pairs > 0) {
-        if (num_pairs >= (i64(1) << 32)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many aggregation pairs");
-        u64* k_u = arena_alloc<u64>(ctx->scratch, num_pairs);
-        u64* k_s = arena_alloc<u64>(ctx->scratch, num_pairs);
-        int32_t* t_row = arena_alloc<int32_t>(ctx->scratch, num_pairs);
-        if (!k_u || !k_s || !t_row) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_radius_query<1><<<grid_for(v, 4), BLK, 0, ctx->stream>>>(
-                st.frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, nullptr, rs, k_u,
-                t_row);
+    // light rows: already sorted in their fixed slots, copy them to the CSR positions
+    k_radius_place<<<grid_for(v * 16, BLK), BLK, 0, ctx->stream>>>(st.tmp, rs, v, sizes, radii, idx, dist, compat);
+    ASR_CHECK_LAUNCH(ctx);
+    const i64 nh = st.num_heavy;
+    if (nh > 0) {
+        // heavy rows (> RADIUS_LIGHT hits): gather keys per row, segmented sort by (squared distance,
+        // index) -- distances are >= 0 so their float bits order like unsigned integers
+        i64* hcnt = arena_alloc<i64>(ctx->scratch, nh + 1);
+        i64* hoff = arena_alloc<i64>(ctx->scratch, nh + 1);
+        if (!hcnt || !hoff) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_heavy_counts<<<grid_for(nh + 1, BLK), BLK, 0, ctx->stream>>>(st.heavy, nh, rs, hcnt);
         ASR_CHECK_LAUNCH(ctx);
-        // order every row by (squared distance, index): distances are >= 0 so their float bits
-        // order like unsigned integers
+        ASR_TRY(scan_counts(ctx, ctx->scratch, hcnt, hoff, nh + 1));
+        i64 hp = 0;
+        ASR_TRY(read_i64(ctx, hoff + nh, &hp));
+        if (hp >= (i64(1) << 32)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many aggregation pairs");
+        u64* k_u = arena_alloc<u64>(ctx->scratch, hp);
+        u64* k_s = arena_alloc<u64>(ctx->scratch, hp);
+        int32_t* t_row = arena_alloc<int32_t>(ctx->scratch, hp);
+        if (!k_u || !k_s || !t_row) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_radius_query<1><<<grid_for(nh, 4), BLK, 0, ctx->stream>>>(
+                st.frame, st.sorted, centers, sizes, nh, st.tab, st.start, st.end, nullptr, hoff, k_u,
+                t_row, st.heavy, nullptr, nullptr);
+        ASR_CHECK_LAUNCH(ctx);
         size_t tb = 0;
-        ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, k_u, k_s,
-                                                              (unsigned int)num_pairs, (unsigned int)v,
-                                                              rs, rs + 1, 0, 64, ctx->stream));
+        ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, k_u, k_s, (unsigned int)hp,
+                                                              (unsigned int)nh, hoff, hoff + 1, 0, 64,
+                                                              ctx->stream));
         void* tmp = ctx->scratch.alloc(tb ? tb : 256);
         if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(tmp, tb, k_u, k_s,
-                                                              (unsigned int)num_pairs, (unsigned int)v,
-                                                              rs, rs + 1, 0, 64, ctx->stream));
-        k_radius_unpack<<<grid_for(num_pairs, BLK), BLK, 0, ctx->stream>>>(k_s, t_row, num_pairs, sizes,
-                                                                          radii, idx, dist, compat);
+        ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(tmp, tb, k_u, k_s, (unsigned int)hp,
+                                                              (unsigned int)nh, hoff, hoff + 1, 0, 64,
+                                                              ctx->stream));
+        k_radius_unpack_heavy<<<grid_for(hp, BLK), BLK, 0, ctx->stream>>>(k_s, t_row, hp, st.heavy, hoff, rs, sizes,
+                                                                        radii, idx, dist, compat);
         ASR_CHECK_LAUNCH(ctx);
     }
     st.valid = false;

@@ -9,7 +9,7 @@ namespace asr_prim {
 
 static inline int ensure_flags(asr_hip_context* ctx) {
     if (!ctx->d_flags) {
-        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_flags, 64 * sizeof(int)));
+        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_flags, 256 * sizeof(int)));
     }
     return ASR_HIP_OK;
 }

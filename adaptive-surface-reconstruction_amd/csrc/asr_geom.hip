@@ -483,31 +483,22 @@ __device__ inline float sqdist3(float ax, float ay, float az, float bx, float by
 // then walked 64 at a time (flattened through a prefix of the cell counts).  Row lengths range
 // from 0 to tens of thousands (a coarse voxel near the surface sees every point within one voxel
 // size), so a thread-per-query loop is dominated by its longest row.
-// MODE 0: count, MODE 1: write (distance, index) keys in candidate order (sorted afterwards)
-// MODE 2: single pass.  Hits are collected in LDS; a row of at most RADIUS_LIGHT hits is ranked
-// inside the wave (rank = number of smaller keys, keys are unique) and written, sorted, to the
-// row's fixed slot tmp[q * RADIUS_LIGHT ..]; longer rows are only counted and appended to the
-// heavy list, which MODE 1 (row list + bases) and a segmented sort handle afterwards.
-constexpr int RADIUS_LIGHT = 64;
-template <int MODE>
-__global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
-                                                      const float* centers, const float* sizes,
-                                                      i64 v, HashTab t, const int32_t* start,
-                                                      const int32_t* end, i64* counts,
-                                                      const i64* rs, u64* keys_out,
-                                                      int32_t* row_out, const int32_t* row_list,
-                                                      int32_t* heavy_out, int* heavy_cnt) {
-    __shared__ int s_pref[4][28];
-    __shared__ int s_beg[4][28];
-    __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 qi = blockIdx.x * (i64)4 + wave;  // position in the row list (or the row itself)
-    if (MODE != 1 && qi == v && lane == 0) counts[v] = 0;
-    if (qi >= v) return;
-    const i64 q = row_list ? row_list[qi] : qi;
-    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
-    const float r = sizes[q];
-    const float r2 = r * r;
+// MODE 0: count only (KDTree::ComputeRadiusNeighbors).
+// MODE 2: single pass of the aggregation search.  Hits are collected in LDS; a row of at most
+// RADIUS_LIGHT hits is ranked inside the wave (rank = number of smaller keys, keys are unique) and
+// written, sorted, to the row's fixed slot tmp[q * RADIUS_LIGHT ..].  Rows with more hits, and rows
+// whose 27 cells hold more than RADIUS_GIANT candidates (a coarse voxel next to a dense region: up
+// to 10^5 candidates, which one wave would walk for milliseconds), go to the heavy list and are
+// processed by k_radius_heavy with RADIUS_SPLIT blocks per row.
+constexpr int RADIUS_LIGHT = 128;
+constexpr int RADIUS_GIANT = 4096;
+constexpr int RADIUS_SPLIT = 64;
+
+// lanes 0..26 look up the 3^3 cells around the query; returns the candidate total, fills the
+// per-wave prefix / begin tables
+__device__ inline int radius_cells(const asr_octree_frame& f, const HashTab& t, const int32_t* start,
+                                   const int32_t* end, float cx, float cy, float cz, float r, int lane,
+                                   int* s_pref, int* s_beg) {
     const int lev = query_level(f, r);
     int x, y, z;
     frame_coord(f, cx, cy, cz, lev, x, y, z);
@@ -523,77 +514,165 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
             }
         }
     }
-    // inclusive prefix of n over lanes 0..26
-    int pre = n;
+    int pre = n;  // inclusive prefix of n over lanes 0..26
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
         int up = __shfl_up(pre, o, 64);
         if (lane >= o) pre += up;
     }
     if (lane < 27) {
-        s_pref[wave][lane + 1] = pre;
-        s_beg[wave][lane] = b;
+        s_pref[lane + 1] = pre;
+        s_beg[lane] = b;
     }
-    if (lane == 0) s_pref[wave][0] = 0;
+    if (lane == 0) s_pref[0] = 0;
     const int total = __shfl(pre, 26, 64);
     __builtin_amdgcn_wave_barrier();
+    return total;
+}
+// candidate i of the concatenated cell ranges
+__device__ inline float4 radius_candidate(const float4* sorted, const int* s_pref, const int* s_beg, int i) {
+    int lo = 0, hi = 27;  // cell c with pref[c] <= i < pref[c+1]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (s_pref[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return sorted[s_beg[lo] + (i - s_pref[lo])];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
+                                                      const float* centers, const float* sizes,
+                                                      i64 v, HashTab t, const int32_t* start,
+                                                      const int32_t* end, i64* counts, u64* tmp,
+                                                      int32_t* heavy_out, int* heavy_cnt,
+                                                      uint8_t* is_heavy) {
+    __shared__ int s_pref[4][28];
+    __shared__ int s_beg[4][28];
+    __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 q = blockIdx.x * (i64)4 + wave;
+    if (q == v && lane == 0) counts[v] = 0;
+    if (q >= v) return;
+    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
+    const float r = sizes[q];
+    const float r2 = r * r;
+    const int total = radius_cells(f, t, start, end, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
     i64 found = 0;
-    const i64 base = MODE == 1 ? rs[qi] : 0;
-    for (int i0 = 0; i0 < total; i0 += 64) {
+    bool heavy = MODE == 2 && total > RADIUS_GIANT;
+    for (int i0 = 0; i0 < total && !heavy; i0 += 64) {
         const int i = i0 + lane;
         bool hit = false;
         float d = 0.f;
         int id = 0;
         if (i < total) {
-            // cell c with pref[c] <= i < pref[c+1]
-            int lo = 0, hi = 27;
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (s_pref[wave][mid] <= i)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const float4 pt = sorted[s_beg[wave][lo] + (i - s_pref[wave][lo])];
+            const float4 pt = radius_candidate(sorted, s_pref[wave], s_beg[wave], i);
             d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
             hit = d < r2;
             id = __float_as_int(pt.w);
         }
         const unsigned long long m = __ballot(hit);
-        if (MODE == 1 && hit) {
-            const i64 o = base + found + __popcll(m & ((1ull << lane) - 1));
-            keys_out[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
-            row_out[o] = (int32_t)qi;
-        }
         if (MODE == 2 && hit) {
             const i64 o = found + __popcll(m & ((1ull << lane) - 1));
             if (o < RADIUS_LIGHT) s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
         }
         found += __popcll(m);
+        if (MODE == 2 && found > RADIUS_LIGHT) heavy = true;
     }
-    if (MODE != 1 && lane == 0) counts[q] = found;
-    if (MODE == 2) {
-        if (found > RADIUS_LIGHT) {
-            if (lane == 0) heavy_out[atomicAdd(heavy_cnt, 1)] = (int32_t)q;
-            return;
+    if (MODE == 0) {
+        if (lane == 0) counts[q] = found;
+        return;
+    }
+    if (heavy) {  // counted and written by k_radius_heavy
+        if (lane == 0) {
+            counts[q] = 0;
+            is_heavy[q] = 1;
+            heavy_out[atomicAdd(heavy_cnt, 1)] = (int32_t)q;
         }
-        __builtin_amdgcn_wave_barrier();
-        const int h = (int)found;
-        const u64 mine = lane < h ? s_keys[wave][lane] : 0;
-        int rank = 0;
-        for (int j = 0; j < h; ++j) rank += s_keys[wave][j] < mine;  // LDS broadcast reads
-        if (lane < h) keys_out[q * RADIUS_LIGHT + rank] = mine;
+        return;
     }
+    if (lane == 0) {
+        counts[q] = found;
+        is_heavy[q] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int h = (int)found;
+    u64 mine[RADIUS_LIGHT / 64];
+    int rank[RADIUS_LIGHT / 64];
+#pragma unroll
+    for (int u = 0; u < RADIUS_LIGHT / 64; ++u) {
+        mine[u] = lane + 64 * u < h ? s_keys[wave][lane + 64 * u] : 0;
+        rank[u] = 0;
+    }
+    for (int j = 0; j < h; ++j) {  // LDS broadcast reads
+        const u64 kj = s_keys[wave][j];
+#pragma unroll
+        for (int u = 0; u < RADIUS_LIGHT / 64; ++u) rank[u] += kj < mine[u];
+    }
+#pragma unroll
+    for (int u = 0; u < RADIUS_LIGHT / 64; ++u)
+        if (lane + 64 * u < h) tmp[q * RADIUS_LIGHT + rank[u]] = mine[u];
+}
+
+// Heavy rows: RADIUS_SPLIT blocks per row, each block walks 1/RADIUS_SPLIT of the candidates.
+// FILL = false: accumulates the hit count into counts[q]; FILL = true: writes the (distance, index)
+// keys at hoff[j] + cursor (any order: the rows are sorted by a segmented sort afterwards).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const float4* sorted, const float* centers,
+                                                      const float* sizes, const int32_t* heavy, HashTab t,
+                                                      const int32_t* start, const int32_t* end, i64* counts,
+                                                      const i64* hoff, int* cursor, u64* keys_out, int32_t* row_out) {
+    __shared__ int s_pref[4][28];
+    __shared__ int s_beg[4][28];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x;
+    const i64 q = heavy[j];
+    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
+    const float r = sizes[q];
+    const float r2 = r * r;
+    const int total = radius_cells(f, t, start, end, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
+    int per = (total + RADIUS_SPLIT - 1) / RADIUS_SPLIT;
+    per = (per + 255) & ~255;  // whole 4-wave rounds
+    const int lo = blockIdx.y * per;
+    const int hi = min(total, lo + per);
+    unsigned long long found = 0;
+    for (int i0 = lo + wave * 64; i0 < hi; i0 += 256) {
+        const int i = i0 + lane;
+        bool hit = false;
+        float d = 0.f;
+        int id = 0;
+        if (i < hi) {
+            const float4 pt = radius_candidate(sorted, s_pref[wave], s_beg[wave], i);
+            d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+            hit = d < r2;
+            id = __float_as_int(pt.w);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (FILL && m) {
+            int o0 = 0;
+            if (lane == 0) o0 = atomicAdd(&cursor[j], __popcll(m));
+            o0 = __shfl(o0, 0, 64);
+            if (hit) {
+                const i64 o = hoff[j] + o0 + __popcll(m & ((1ull << lane) - 1));
+                keys_out[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+                row_out[o] = j;
+            }
+        }
+        found += __popcll(m);
+    }
+    if (!FILL && lane == 0 && found) atomicAdd((unsigned long long*)&counts[q], found);
 }
 // copies the light rows from their fixed slots to the CSR positions: 16 lanes per row
-__global__ void k_radius_place(const u64* tmp, const i64* rs, i64 v, const float* sizes, const float* radii,
-                               int32_t* idx, float* dist, float* compat) {
+__global__ void k_radius_place(const u64* tmp, const i64* rs, const uint8_t* is_heavy, i64 v, const float* sizes,
+                               const float* radii, int32_t* idx, float* dist, float* compat) {
     const i64 q = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 4;
     const int l = threadIdx.x & 15;
     if (q >= v) return;
     const i64 b = rs[q];
     const int cnt = (int)(rs[q + 1] - b);
-    if (cnt > RADIUS_LIGHT) return;  // heavy row: written by k_radius_unpack_heavy
+    if (is_heavy[q]) return;  // written by k_radius_unpack_heavy
     const float a = sizes[q];
     for (int i = l; i < cnt; i += 16) {
         const u64 k = tmp[q * RADIUS_LIGHT + i];
@@ -1178,7 +1257,8 @@ struct RadiusState {
     int32_t* end = nullptr;
     i64 n = 0, v = 0;
     u64* tmp = nullptr;        // [v][RADIUS_LIGHT] sorted keys of the light rows
-    int32_t* heavy = nullptr;  // rows with more than RADIUS_LIGHT hits
+    int32_t* heavy = nullptr;  // rows with more than RADIUS_LIGHT hits or RADIUS_GIANT candidates
+    uint8_t* is_heavy = nullptr;
     i64 num_heavy = 0;
 };
 static RadiusState& rstate(asr_hip_context* ctx) {
@@ -1267,18 +1347,25 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     st.tmp = arena_alloc<u64>(ctx->scratch, (size_t)v * RADIUS_LIGHT);
     st.heavy = arena_alloc<int32_t>(ctx->scratch, v);
-    if (!counts || !st.tmp || !st.heavy) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    st.is_heavy = arena_alloc<uint8_t>(ctx->scratch, v);
+    if (!counts || !st.tmp || !st.heavy || !st.is_heavy) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 10, 0, sizeof(int), ctx->stream));
     // one pass: counts, the sorted light rows (fixed slots) and the list of heavy rows
-    k_radius_query<2><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(
-            *frame, st.sorted, centers, sizes, v, st.tab, st.start, st.end, counts, nullptr, st.tmp,
-            nullptr, nullptr, st.heavy, ctx->d_flags + 10);
+    k_radius_query<2><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.tab,
+                                                                    st.start, st.end, counts, st.tmp, st.heavy,
+                                                                    ctx->d_flags + 10, st.is_heavy);
     ASR_CHECK_LAUNCH(ctx);
-    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
-    ASR_TRY(read_i64(ctx, rs + v, num_pairs));
     ASR_TRY(read_flags(ctx, host));
     if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search cell table overflow");
     st.num_heavy = host[10];
+    if (st.num_heavy > 0) {
+        k_radius_heavy<false><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
+                *frame, st.sorted, centers, sizes, st.heavy, st.tab, st.start, st.end, counts, nullptr, nullptr,
+                nullptr, nullptr);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
+    ASR_TRY(read_i64(ctx, rs + v, num_pairs));
     st.valid = true;
     return ASR_HIP_OK;
 }
@@ -1297,8 +1384,7 @@ int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame*
     i64* counts = arena_alloc<i64>(ctx->scratch, n + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     k_radius_query<0><<<grid_for(n + 1, 4), BLK, 0, ctx->stream>>>(
-            *frame, st.sorted, pts, radii, n, st.tab, st.start, st.end, counts, nullptr, nullptr, nullptr, nullptr,
-            nullptr, nullptr);
+            *frame, st.sorted, pts, radii, n, st.tab, st.start, st.end, counts, nullptr, nullptr, nullptr, nullptr);
     ASR_CHECK_LAUNCH(ctx);
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, counts, n * sizeof(i64), hipMemcpyDeviceToDevice,
                                       ctx->stream));
@@ -1340,7 +1426,8 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         ASR_FAIL(ctx, ASR_HIP_EINVAL,
                  "asr_hip_multi_radius_search_fill must follow the matching _count call");
     // light rows: already sorted in their fixed slots, copy them to the CSR positions
-    k_radius_place<<<grid_for(v * 16, BLK), BLK, 0, ctx->stream>>>(st.tmp, rs, v, sizes, radii, idx, dist, compat);
+    k_radius_place<<<grid_for(v * 16, BLK), BLK, 0, ctx->stream>>>(st.tmp, rs, st.is_heavy, v, sizes, radii, idx, dist,
+                                                                   compat);
     ASR_CHECK_LAUNCH(ctx);
     const i64 nh = st.num_heavy;
     if (nh > 0) {
@@ -1359,9 +1446,12 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         u64* k_s = arena_alloc<u64>(ctx->scratch, hp);
         int32_t* t_row = arena_alloc<int32_t>(ctx->scratch, hp);
         if (!k_u || !k_s || !t_row) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_radius_query<1><<<grid_for(nh, 4), BLK, 0, ctx->stream>>>(
-                st.frame, st.sorted, centers, sizes, nh, st.tab, st.start, st.end, nullptr, hoff, k_u,
-                t_row, st.heavy, nullptr, nullptr);
+        int* cursor = arena_alloc<int>(ctx->scratch, nh);
+        if (!cursor) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(cursor, 0, (size_t)nh * sizeof(int), ctx->stream));
+        k_radius_heavy<true><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
+                st.frame, st.sorted, centers, sizes, st.heavy, st.tab, st.start, st.end, nullptr, hoff, cursor, k_u,
+                t_row);
         ASR_CHECK_LAUNCH(ctx);
         size_t tb = 0;
         ASR_HIP_CHECK(ctx, rocprim::segmented_radix_sort_keys(nullptr, tb, k_u, k_s, (unsigned int)hp,

@@ -53,6 +53,9 @@ class SparseConvArgs(ctypes.Structure):
         ("out_importance", ctypes.c_void_p),
         ("algo", ctypes.c_int),
         ("row_perm", ctypes.c_void_p),
+        ("filters_b", ctypes.c_void_p),
+        ("bias_b", ctypes.c_void_p),
+        ("cout_b", ctypes.c_int),
     ]
 
 

@@ -243,8 +243,10 @@ def continuous_conv(filters, out_positions, extents, inp_positions, inp_features
 def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
                 neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False,
                 residual=None, out=None, return_importance=False, algo=0,
-                neighbors_importance=None, row_perm=None):
-    """SpecialSparseConv.forward (models/common_torch.py:95-148) in one launch."""
+                neighbors_importance=None, row_perm=None, filters_b=None, bias_b=None):
+    """SpecialSparseConv.forward (models/common_torch.py:95-148) in one launch.  filters_b / bias_b:
+    optional second filter bank (conv1a + conv1b of a SparseConvBlock in one pass): output columns
+    [cout, cout + cout_b); importance, normalize and the returned importance sum then belong to bank b."""
     filters = _dev(filters, torch.float32)
     K, cin, cout = filters.shape
     inp_features = _dev(inp_features, torch.float32)
@@ -258,8 +260,13 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     nimp = _dev(neighbors_importance, torch.float32) if neighbors_importance is not None else None
     b = _dev(bias, torch.float32) if bias is not None else None
     res = _dev(residual, torch.float32) if residual is not None else None
+    fb = _dev(filters_b, torch.float32) if filters_b is not None else None
+    bb = _dev(bias_b, torch.float32) if bias_b is not None else None
+    if fb is not None and (fb.dim() != 3 or fb.shape[0] != K or fb.shape[1] != cin):
+        raise RuntimeError("sparse_conv: second filter bank does not match the first")
     if out is None:
-        out = torch.empty((v, cout), dtype=torch.float32, device=filters.device)
+        out = torch.empty((v, cout + (fb.shape[2] if fb is not None else 0)), dtype=torch.float32,
+                          device=filters.device)
     oimp = torch.empty(v, dtype=torch.float32, device=filters.device) if return_importance else None
     a = _lib.SparseConvArgs()
     a.filters = filters.data_ptr()
@@ -286,6 +293,9 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     a.algo = int(algo)
     perm = _dev(row_perm, torch.int32) if row_perm is not None else None
     a.row_perm = perm.data_ptr() if perm is not None else None
+    a.filters_b = fb.data_ptr() if fb is not None else None
+    a.bias_b = bb.data_ptr() if bb is not None else None
+    a.cout_b = fb.shape[2] if fb is not None else 0
     context().call("asr_hip_sparse_conv_f32", ctypes.byref(a))
     if return_importance:
         return out, oimp

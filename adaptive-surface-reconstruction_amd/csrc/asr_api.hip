@@ -424,6 +424,54 @@ struct Net {
         a.row_perm = perm;
         return asr_conv_sparse(ctx, &a);
     }
+    // conv1a + conv1b of a block in one launch (second filter bank of asr_sparse_conv_args): same
+    // gather, one extra column tile.  Falls back to two launches for widths the fused kernel does not take.
+    int conv_ab(const std::string& name, int K, Feat in, const int32_t* nidx, const uint8_t* nk, const i64* rs,
+                const int32_t* perm, i64 num_out, i64 num_inp, const float* imp, float* out, i64 out_ld, int ca,
+                int cb, float* out_imp) {
+        const asr_weight *ka, *ba, *kb, *bb;
+        ASR_TRY(get(name + ".conv1a.kernel", 3, &ka));
+        ASR_TRY(get(name + ".conv1a.bias", 1, &ba));
+        ASR_TRY(get(name + ".conv1b.kernel", 3, &kb));
+        ASR_TRY(get(name + ".conv1b.bias", 1, &bb));
+        const bool fused = ca % 16 == 8 && cb == 8 && in.c % 4 == 0 && in.ld % 4 == 0 && ka->shape[0] == K &&
+                           kb->shape[0] == K && ka->shape[1] == in.c && kb->shape[1] == in.c &&
+                           ka->shape[2] == ca && kb->shape[2] == cb && ba->shape[0] == ca && bb->shape[0] == cb &&
+                           (uintptr_t)kb->data % 16 == 0 && (uintptr_t)ka->data % 16 == 0 &&
+                           (uintptr_t)in.p % 16 == 0;
+        if (!fused) {
+            ASR_TRY(conv(name + ".conv1a", K, in, nidx, nk, rs, perm, num_out, num_inp, nullptr, 0, out, out_ld, ca,
+                         nullptr, nullptr, 0));
+            return conv(name + ".conv1b", K, in, nidx, nk, rs, perm, num_out, num_inp, imp, 1, out + ca, out_ld, cb,
+                        out_imp, nullptr, 0);
+        }
+        asr_sparse_conv_args a;
+        memset(&a, 0, sizeof(a));
+        a.filters = ka->data;
+        a.filters_b = kb->data;
+        a.inp_features = in.p;
+        a.inp_ld = in.ld;
+        a.inp_importance = imp;
+        a.neighbors_index = nidx;
+        a.neighbors_kernel_index = nk;
+        a.neighbors_row_splits = rs;
+        a.num_out = num_out;
+        a.num_inp = num_inp;
+        a.kernel_size = K;
+        a.cin = in.c;
+        a.cout = ca;
+        a.cout_b = cb;
+        a.normalize = 1;
+        a.bias = ba->data;
+        a.bias_b = bb->data;
+        a.relu = 1;
+        a.out = out;
+        a.out_ld = out_ld;
+        a.out_importance = out_imp;
+        a.row_perm = perm;
+        a.algo = 2;
+        return asr_conv_sparse(ctx, &a);
+    }
     int cout_of(const std::string& prefix, int* c) {
         const asr_weight* k;
         ASR_TRY(get(prefix + ".kernel", 3, &k));
@@ -447,10 +495,7 @@ struct Net {
             if (ca + cb != C) ASR_FAIL(c, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != block width", name.c_str());
             float* oi = arena_alloc<float>(c->scratch, g.v);
             if (!oi) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
-            ASR_TRY(conv(name + ".conv1a", 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C,
-                         ca, nullptr, nullptr, 0));
-            ASR_TRY(conv(name + ".conv1b", 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, imp, 1, t1 + ca,
-                         C, cb, oi, nullptr, 0));
+            ASR_TRY(conv_ab(name, 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, imp, t1, C, ca, cb, oi));
             *out_imp = oi;
         } else {
             ASR_TRY(conv(name + ".conv1", 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C,
@@ -474,10 +519,8 @@ struct Net {
         if (ca + cb != out.c) ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != width", name.c_str());
         float* oi = arena_alloc<float>(ctx->scratch, coarse.v);
         if (!oi) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(conv(name + ".conv1a", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, fine.perm_down, coarse.v,
-                     fine.v, nullptr, 0, out.p, out.ld, ca, nullptr, nullptr, 0));
-        ASR_TRY(conv(name + ".conv1b", 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, fine.perm_down, coarse.v,
-                     fine.v, imp, 1, out.p + ca, out.ld, cb, oi, nullptr, 0));
+        ASR_TRY(conv_ab(name, 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, fine.perm_down, coarse.v, fine.v,
+                        imp, out.p, out.ld, ca, cb, oi));
         *out_imp = oi;
         return ASR_HIP_OK;
     }

@@ -316,7 +316,11 @@ __global__ void k_sconv_scalar(asr_sparse_conv_args a) {
 // ------------------------------------------------------------------------------------------
 constexpr int NBR_LD = 57;  // odd stride: conflict-free column reads
 
-template <int NT, int KC, bool IMP, int WAVES>
+// DUAL (with IMP): two filter banks in one pass (SparseConvBlock conv1a + conv1b): columns
+// [0, cout) are the plain convolution, columns [cout, cout + cout_b) are weighted by the neighbour
+// importance and normalised.  cout % 16 == 8 and cout_b == 8, so bank b is the upper half of the last
+// column tile; that tile gets a second accumulator fed with the importance-scaled A operand.
+template <int NT, int KC, bool IMP, int WAVES, bool DUAL = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) void k_sconv_mfma(asr_sparse_conv_args a,
                                                     const float* __restrict__ zeros) {
     constexpr int TM = WAVES * 16;   // rows per block: more rows share one staged weight panel
@@ -324,8 +328,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     constexpr int NCOL = NT * 16;
     constexpr int BLD = NCOL + 4;            // (4g+t)*BLD mod 32 separates the two 16-lane halves
     constexpr int NJ = KC / 16;              // float4 gathers per lane per panel
-    constexpr int SV = KC * NCOL / 4 / NTHR;  // float4 staged per thread per panel
-    static_assert(KC * NCOL / 4 % NTHR == 0, "panel must split evenly over the block");
+    constexpr int PV = KC * NCOL / 4;               // float4 per panel
+    constexpr int SV = (PV + NTHR - 1) / NTHR;      // float4 staged per thread per panel
+    constexpr bool SV_EXACT = PV % NTHR == 0;       // else the last threads stage nothing
     __shared__ int s_nbr[TM * NBR_LD];
     __shared__ float s_w[IMP ? TM * NBR_LD : 1];
     __shared__ float s_norm[TM];
@@ -341,35 +346,50 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     const i64 row0 = tile * TM;
     const int n0 = blockIdx.y * NCOL;
     const int K = a.kernel_size;
-    const int cin = a.cin, cout = a.cout;
+    const int cin = a.cin;
+    const int ca = a.cout;                              // bank a width
+    const int cout = a.cout + (DUAL ? a.cout_b : 0);    // all output columns of this launch
+    const bool has_b = DUAL && blockIdx.y == gridDim.y - 1;  // this block holds the bank-b half tile
 
     for (int i = tid; i < TM * NBR_LD; i += NTHR) s_nbr[i] = -1;
     __syncthreads();
-    if (tid < TM) {
-        i64 q = row0 + tid;
+    {
+        // slot table: TPR = 4 threads walk one CSR row (entries p, p+4, ...) -- the row walk is a chain
+        // of dependent global loads and sits in front of every tile
+        constexpr int TPR = NTHR / TM;
+        const int prow = tid / TPR, pj = tid % TPR;
+        i64 q = row0 + prow;
         if (q < a.num_out && a.row_perm) q = a.row_perm[q];
         unsigned long long m = 0;
         float norm = 0.f;
         if (q < a.num_out) {
-            for (i64 p = a.neighbors_row_splits[q]; p < a.neighbors_row_splits[q + 1]; ++p) {
+            const i64 pe = a.neighbors_row_splits[q + 1];
+            for (i64 p = a.neighbors_row_splits[q] + pj; p < pe; p += TPR) {
                 int k = a.neighbors_kernel_index[p];
                 int32_t i = a.neighbors_index[p];
                 if (k >= K) continue;  // malformed input: slot outside the filter
-                s_nbr[tid * NBR_LD + k] = i;
+                s_nbr[prow * NBR_LD + k] = i;
                 m |= 1ull << k;
                 float w = 1.f;
                 if (IMP) {
                     w = a.neighbors_importance ? a.neighbors_importance[p] : a.inp_importance[i];
-                    s_w[tid * NBR_LD + k] = w;
+                    s_w[prow * NBR_LD + k] = w;
                 }
                 norm += w;
             }
         } else {
             q = -1;
         }
-        s_row[tid] = (int)q;
-        s_mask[tid] = m;
-        s_norm[tid] = norm;
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {  // the TPR lanes of a row are adjacent
+            m |= __shfl_xor(m, o, 64);
+            norm += __shfl_xor(norm, o, 64);
+        }
+        if (pj == 0) {
+            s_row[prow] = (int)q;
+            s_mask[prow] = m;
+            s_norm[prow] = norm;
+        }
     }
     __syncthreads();
 
@@ -394,6 +414,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_b = {0.f, 0.f, 0.f, 0.f};
 
     const int ncol = lane & 15;
     const int npanel = (cin + KC - 1) / KC;
@@ -419,7 +440,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     float imp_q0 = 1.f, imp_q1 = 1.f;
 
     auto load_panel = [&](const int qk, const int qp, f32x4 (&st)[SV]) __attribute__((always_inline)) {
-        const float* Wk = a.filters + (i64)(qk < 0 ? 0 : qk) * cin * cout;
+        const float* Wk = a.filters + (i64)(qk < 0 ? 0 : qk) * cin * ca;
+        const float* Wkb = DUAL ? a.filters_b + (i64)(qk < 0 ? 0 : qk) * cin * a.cout_b : nullptr;
 #pragma unroll
         for (int s = 0; s < SV; ++s) {
             int e = tid + s * NTHR;            // float4 index inside the panel
@@ -429,8 +451,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
             // cout % 4 == 0 and col % 4 == 0: a float4 is entirely inside or outside the row.
             // Out-of-range entries read a zero line instead of being masked after the load: a
             // select on the loaded value would force the vmcnt wait in front of the MFMAs.
-            bool ok = qk >= 0 && ci < cin && col < cout;
-            const float* src = ok ? Wk + (i64)ci * cout + col : zeros;
+            bool ok = qk >= 0 && ci < cin && col < cout && (SV_EXACT || e < PV);
+            const float* src = ok ? Wk + (i64)ci * ca + col : zeros;
+            if (DUAL && ok && col >= ca) src = Wkb + (i64)ci * a.cout_b + (col - ca);
             st[s] = *reinterpret_cast<const f32x4*>(src);
         }
     };
@@ -440,7 +463,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
             int e = tid + s * NTHR;
             int pr = e / (NCOL / 4);
             int pc = (e % (NCOL / 4)) * 4;
-            *reinterpret_cast<f32x4*>(&s_B[buf][pr * BLD + pc]) = st[s];
+            if (SV_EXACT || e < PV) *reinterpret_cast<f32x4*>(&s_B[buf][pr * BLD + pc]) = st[s];
         }
     };
     auto gather_a = [&](const int qk, const int qp, f32x4 (&aq)[NJ], float& imp) __attribute__((always_inline)) {
@@ -496,10 +519,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
                         bv[(jt + 1) & 1][nb] = sb[(16 * j1 + t1) * BLD + nb * 16];
                 }
                 float av = t == 0 ? a_cur[j].x : t == 1 ? a_cur[j].y : t == 2 ? a_cur[j].z : a_cur[j].w;
-                if (IMP) av *= imp_cur;
+                if (IMP && !DUAL) av *= imp_cur;
 #pragma unroll
                 for (int nb = 0; nb < NT; ++nb)
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[jt & 1][nb], acc[nb], 0, 0, 0);
+                if (DUAL && has_b)
+                    acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(av * imp_cur, bv[jt & 1][NT - 1], acc_b, 0, 0, 0);
             }
         }
         store_panel(buf ^ 1, st_next);  // panel of the next step, loaded one step ago
@@ -524,7 +549,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) {
         const int col = n0 + nb * 16 + ncol;
-        const float* bp = (a.bias && col < cout) ? a.bias + col : zeros;
+        const float* bp = (a.bias && col < ca) ? a.bias + col : zeros;
+        if (DUAL && a.bias_b && col >= ca && col < cout) bp = a.bias_b + (col - ca);
         bv[nb] = *bp;
     }
 #pragma unroll
@@ -545,7 +571,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
         for (int nb = 0; nb < NT; ++nb) {
             const int col = n0 + nb * 16 + ncol;
             float v = acc[nb][i];
-            v = do_norm ? v / norm : v;
+            if (DUAL) {  // bank b: importance weighted + normalised; bank a: plain
+                const bool colb = col >= ca;
+                if (nb == NT - 1 && has_b && colb) v = acc_b[i];
+                v = (colb && do_norm) ? v / norm : v;
+            } else {
+                v = do_norm ? v / norm : v;
+            }
             v += bv[nb];
             if (a.relu) v = fmaxf(v, 0.f);
             v += res[nb];
@@ -720,7 +752,8 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     if (a.kernel_size < 1 || a.kernel_size > 56)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: kernel_size must be 1..56");
     if (a.cin < 1 || a.cout < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: bad channel count");
-    if (a.inp_ld < a.cin || a.out_ld < a.cout)
+    if (a.filters_b && a.cout_b < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: bad channel count");
+    if (a.inp_ld < a.cin || a.out_ld < a.cout + (a.filters_b ? a.cout_b : 0))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: row stride smaller than channel count");
     bool mfma_ok = (a.cin % 4 == 0) && (a.cout % 4 == 0) && (a.inp_ld % 4 == 0) &&
                    ((uintptr_t)a.filters % 16 == 0) &&
@@ -729,6 +762,8 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     if (algo == 0) algo = mfma_ok ? 2 : 1;
     if (algo == 2 && !mfma_ok)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: MFMA path needs cin %% 4 == 0 and 16 B rows");
+    if (a.filters_b && algo != 2)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: the second filter bank needs the MFMA path");
     if (algo == 1) {
         i64 total = a.num_out * a.cout;
         k_sconv_scalar<<<grid_for(total, 256), 256, 0, ctx->stream>>>(a);
@@ -740,23 +775,30 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     const float* zeros = nullptr;
     ASR_TRY(asr_ctx_zeros(ctx, &zeros));
     const bool imp = a.inp_importance || a.neighbors_importance;
+    const bool dual = a.filters_b != nullptr;
+    const int ctot = a.cout + (dual ? a.cout_b : 0);
+    if (dual && (!imp || a.cout % 16 != 8 || a.cout_b != 8 || a.residual || (uintptr_t)a.filters_b % 16 != 0))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: second filter bank needs importance, cout %% 16 == 8, cout_b == 8");
     static const bool dry = getenv("ASR_SCONV_DRY") && atoi(getenv("ASR_SCONV_DRY"));
     if (dry) a.algo = 9;
     // widest column tile that fits cout, narrowed while the launch has too few blocks to fill
     // 256 CUs (coarse grids have only a few thousand rows; the gather is then repeated per
     // column chunk, which those levels can afford).  128-row blocks (8 waves) halve the weight
     // panel traffic per MFMA and are used whenever they still give enough blocks.
-    int nt = a.cout > 128 ? 16 : a.cout > 64 ? 8 : a.cout > 32 ? 4 : a.cout > 16 ? 2 : 1;
+    int nt = ctot > 128 ? 16 : ctot > 64 ? 8 : ctot > 32 ? 4 : ctot > 16 ? 2 : 1;
     const i64 tiles64 = (a.num_out + 63) / 64;
     static const i64 min_blocks = getenv("ASR_SCONV_MIN_BLOCKS") ? atoll(getenv("ASR_SCONV_MIN_BLOCKS")) : 3072;
-    while (nt > 2 && tiles64 * ((a.cout + nt * 16 - 1) / (nt * 16)) < min_blocks) nt >>= 1;
+    while (nt > 2 && tiles64 * ((ctot + nt * 16 - 1) / (nt * 16)) < min_blocks) nt >>= 1;
+    while (dual && ctot % (nt * 16) != 0) nt >>= 1;  // bank b must be the last tile of the last column chunk
     const i64 tiles128 = (a.num_out + 127) / 128;
     static const i64 wide_min = getenv("ASR_SCONV_WIDE_MIN") ? atoll(getenv("ASR_SCONV_WIDE_MIN")) : 2048;
-    const bool wide = nt >= 2 && tiles128 * ((a.cout + nt * 16 - 1) / (nt * 16)) >= wide_min;
+    const bool wide = nt >= 2 && tiles128 * ((ctot + nt * 16 - 1) / (nt * 16)) >= wide_min;
 #define ASR_LAUNCH_SCONV(NT_, KC_, W_)                                                           \
     {                                                                                            \
-        dim3 grid((unsigned)((a.num_out + W_ * 16 - 1) / (W_ * 16)), (a.cout + NT_ * 16 - 1) / (NT_ * 16)); \
-        if (imp)                                                                                 \
+        dim3 grid((unsigned)((a.num_out + W_ * 16 - 1) / (W_ * 16)), (ctot + NT_ * 16 - 1) / (NT_ * 16)); \
+        if (dual)                                                                                \
+            k_sconv_mfma<NT_, KC_, true, W_, true><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(a, zeros); \
+        else if (imp)                                                                            \
             k_sconv_mfma<NT_, KC_, true, W_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(a, zeros);   \
         else                                                                                     \
             k_sconv_mfma<NT_, KC_, false, W_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(a, zeros);  \
@@ -766,12 +808,18 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
         ASR_LAUNCH_SCONV(NT_, KC_, 8)  \
     else                               \
         ASR_LAUNCH_SCONV(NT_, KC_, 4)
+    // KC: deeper panels (8/32, 4/64) measured neutral; 2 and 1 column tiles take 32-deep panels when
+    // cin <= 32 so that no zero-padded k step is executed (decblock0: 0.97 -> 0.6 ms per layer)
     switch (nt) {
         case 16: ASR_LAUNCH_SCONV_W(16, 16) break;
         case 8: ASR_LAUNCH_SCONV_W(8, 16) break;
         case 4: ASR_LAUNCH_SCONV_W(4, 32) break;
-        case 2: ASR_LAUNCH_SCONV_W(2, 64) break;
-        default: ASR_LAUNCH_SCONV(1, 64, 4) break;
+        case 2:
+            if (a.cin <= 32) ASR_LAUNCH_SCONV_W(2, 32) else ASR_LAUNCH_SCONV_W(2, 64)  // no zero-padded k steps
+            break;
+        default:
+            if (a.cin <= 32) ASR_LAUNCH_SCONV(1, 32, 4) else ASR_LAUNCH_SCONV(1, 64, 4)
+            break;
     }
 #undef ASR_LAUNCH_SCONV_W
 #undef ASR_LAUNCH_SCONV

@@ -220,6 +220,13 @@ typedef struct asr_sparse_conv_args {
     const int32_t* row_perm;           /* dev [num_out] or NULL: order in which the MFMA kernel
                                           tiles the output rows (asr_hip_row_groups); results
                                           do not depend on it                                */
+    /* optional second filter bank, same gather, same launch (SparseConvBlock conv1a + conv1b,
+     * models/v0/net_definitions_torch.py:262-281): output columns [cout, cout + cout_b).  With
+     * filters_b != NULL the importance arrays, `normalize` and `out_importance` belong to bank b
+     * only and bank a is the plain convolution.  MFMA path: cout % 16 == 8, cout_b == 8. */
+    const float* filters_b;            /* dev [K, cin, cout_b] or NULL                       */
+    const float* bias_b;               /* dev [cout_b] or NULL                               */
+    int cout_b;
 } asr_sparse_conv_args;
 int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* args);
 

@@ -140,6 +140,39 @@ def test_sparse_conv_k55(geo, gpu, algo, cin, cout):
     _close(out.cpu().numpy(), O.sparse_conv(W, f, idx, kidx, pimp, rs, False))
 
 
+@pytest.mark.parametrize("cin,ca", [(32, 56), (16, 8), (64, 120), (128, 248)])
+def test_sparse_conv_two_banks_equals_two_launches(geo, gpu, cin, ca):
+    """conv1a + conv1b fused (second filter bank): same bits as the two separate launches, and both
+    against the oracle"""
+    from asr_hip import ops
+    pts, nrm, rad, bb, item = geo
+    rng = np.random.default_rng(5)
+    L = 1
+    idx, kidx, rs = item["neighbors_index%d" % L], item["neighbors_kernel_index%d" % L], item["neighbors_row_splits%d" % L]
+    v = len(rs) - 1
+    f = rng.normal(size=(v, cin)).astype(np.float32)
+    Wa = (rng.normal(size=(55, cin, ca)) * 0.1).astype(np.float32)
+    Wb = (rng.normal(size=(55, cin, 8)) * 0.1).astype(np.float32)
+    ba, bb_ = rng.normal(size=ca).astype(np.float32), rng.normal(size=8).astype(np.float32)
+    imp = rng.uniform(0.05, 1.0, size=v).astype(np.float32)
+    perm = ops.row_groups(_t(kidx, gpu), _t(rs, gpu))
+    common = (_t(idx, gpu), _t(kidx, gpu), _t(rs, gpu))
+    out, oimp = ops.sparse_conv(_t(Wa, gpu), _t(f, gpu), *common, inp_importance=_t(imp, gpu), normalize=True,
+                                bias=_t(ba, gpu), relu=True, return_importance=True, algo=2, row_perm=perm,
+                                filters_b=_t(Wb, gpu), bias_b=_t(bb_, gpu))
+    assert out.shape == (v, ca + 8)
+    oa = ops.sparse_conv(_t(Wa, gpu), _t(f, gpu), *common, bias=_t(ba, gpu), relu=True, algo=2, row_perm=perm)
+    ob, oimp2 = ops.sparse_conv(_t(Wb, gpu), _t(f, gpu), *common, inp_importance=_t(imp, gpu), normalize=True,
+                                bias=_t(bb_, gpu), relu=True, return_importance=True, algo=2, row_perm=perm)
+    assert torch.equal(out[:, :ca], oa) and torch.equal(out[:, ca:], ob) and torch.equal(oimp, oimp2)
+    ones = np.ones(len(idx), np.float32)
+    _close(out[:, :ca].cpu().numpy(), np.maximum(O.sparse_conv(Wa, f, idx, kidx, ones, rs, False) + ba, 0))
+    _close(out[:, ca:].cpu().numpy(), np.maximum(O.sparse_conv(Wb, f, idx, kidx, imp[idx.astype(np.int64)], rs, True) + bb_, 0))
+    with pytest.raises(RuntimeError):  # widths the fused kernel does not take
+        ops.sparse_conv(_t(np.zeros((55, cin, 16), np.float32), gpu), _t(f, gpu), *common,
+                        inp_importance=_t(imp, gpu), algo=2, filters_b=_t(Wb, gpu))
+
+
 def test_sparse_conv_strided_io_residual_and_k9(geo, gpu):
     from asr_hip import ops
     pts, nrm, rad, bb, item = geo

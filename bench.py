@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=int(os.environ.get("ASR_BENCH_POINTS", 10_000_000)))
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("ASR_BENCH_CPU_SAMPLE", 400_000)))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("ASR_BENCH_CPU_SAMPLE", 1_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl")
     args = ap.parse_args()

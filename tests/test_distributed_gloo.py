@@ -67,5 +67,5 @@ def test_conv_flop_model_matches_survey():
         num_pairs = [3404263, 1012372, 273790, 67041, 16237]
 
     flops, launches = bench.conv_flops(S, synth.unet5_param_shapes(1))
-    assert launches == 53
+    assert launches == 44  # 53 convs; conv1a + conv1b of the 9 blocks share a launch
     assert abs(flops / 1e9 - 926) < 1.0

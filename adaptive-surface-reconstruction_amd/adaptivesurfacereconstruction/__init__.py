@@ -139,11 +139,12 @@ def create_triangle_mesh(values, dual_vertex_indices, node_positions, contouring
 def _load_weights(weights):
     """state dict of the network (names of UNet5.state_dict()).  The reference loads the TorchScript
     file <resource dir>/model.pt (cpp/lib/asr.cpp:138-139); here: a dict, an .npz, or a torch file
-    holding a state dict, by argument or as $ASR_RESOURCE_DIR/model_weights.{npz,pt}."""
+    holding a state dict or a TorchScript module, by argument or as
+    $ASR_RESOURCE_DIR/{model_weights.npz, model_weights.pt, model.pt}."""
     import os
     if weights is None:
         base = os.environ.get("ASR_RESOURCE_DIR", "")
-        for cand in ("model_weights.npz", "model_weights.pt"):
+        for cand in ("model_weights.npz", "model_weights.pt", "model.pt"):
             if base and os.path.exists(os.path.join(base, cand)):
                 weights = os.path.join(base, cand)
                 break
@@ -154,8 +155,11 @@ def _load_weights(weights):
         if weights.endswith(".npz"):
             with np.load(weights) as z:
                 return {k: z[k] for k in z.files}
-        sd = torch.load(weights, map_location="cpu")
-        return sd.state_dict() if hasattr(sd, "state_dict") else sd
+        try:  # the reference ships a TorchScript archive (model.pt, cpp/lib/asr.cpp:138-139)
+            sd = torch.jit.load(weights, map_location="cpu")
+        except Exception:
+            sd = torch.load(weights, map_location="cpu")
+        return dict(sd.state_dict()) if hasattr(sd, "state_dict") else sd
     return weights
 
 

@@ -230,7 +230,7 @@ def main():
                          "kernel": "k_sconv_mfma (%d launches/step, %.3f ms avg, %.1f algorithmic "
                                    "GFLOP/step)" % (launches, stage_ms["unet"] / launches, flops / 1e9)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)
         print(json.dumps(out))
     if world > 1:

@@ -287,11 +287,23 @@ __global__ void k_neighbors_count(const u64* keys, i64 v, HashTab t, i64* counts
     asr_key_coord(key, x, y, z, lev);
     u64 m = 0;
     int n = 1;
-#pragma unroll 6
-    for (int c = 0; c < 36; ++c) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
         int slot;
-        int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
-        if (idx >= 0) {
+        if (neighbor_candidate(t, key, x, y, z, lev, c, slot) >= 0) {
+            m |= u64(1) << c;
+            ++n;
+        }
+    }
+    // The voxels of a grid are disjoint cells: where the same-level neighbour across a face exists,
+    // neither its four children nor its parent can, so those five probes are skipped (36 -> ~13 probes
+    // per voxel on a scan; the resulting mask is the same).
+#pragma unroll 6
+    for (int c = 6; c < 36; ++c) {
+        const int face = c < 30 ? (c - 6) >> 2 : c - 30;
+        if ((m >> face) & 1) continue;
+        int slot;
+        if (neighbor_candidate(t, key, x, y, z, lev, c, slot) >= 0) {
             m |= u64(1) << c;
             ++n;
         }

@@ -84,17 +84,23 @@ __device__ inline i64 tab_find_slot(const HashTab& t, u64 key) {
     return -1;
 }
 
-// append with ONE atomic per wave (ballot + popcount); must be reached by every lane of the wave
-__device__ inline int wave_append(bool pred, int* counter) {
+// append with ONE atomic per 256-thread block; must be reached by every thread of the block (4 waves).
+// Same-address atomics retire at ~88 / us: one per wave is 0.5 ms for 2.6 M voxels.
+__device__ inline int block_append(bool pred, int* counter) {
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
     const unsigned long long m = __ballot(pred);
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        if (lane == leader) base = atomicAdd(counter, __popcll(m));
-        base = __shfl(base, leader, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        s_base = total ? atomicAdd(counter, total) : 0;
     }
-    return base + __popcll(m & ((1ull << lane) - 1));
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w) off += s_cnt[w];
+    return off + __popcll(m & ((1ull << lane) - 1));
 }
 
 u64 next_pow2(u64 x) {
@@ -220,7 +226,7 @@ __global__ void k_collect_leaves(HashTab t, const u64* nodes, i64 n, u64* leaves
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     u64 k = i < n ? nodes[i] : 0;
     bool leaf = k != 0 && !((__clzll((long long)k) > 1) && tab_contains(t, k << 3));
-    int pl = wave_append(leaf, &cnt[4]);
+    int pl = block_append(leaf, &cnt[4]);
     if (leaf) leaves[pl] = k;
 }
 
@@ -353,12 +359,12 @@ __device__ inline int coarsen_state(const u64* keys, i64 v, i64 i) {
 __global__ void k_coarsen_count(const u64* keys, i64 v, int* cnt) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     bool keep = i < v && coarsen_state(keys, v, i) != 2;
-    (void)wave_append(keep, &cnt[5]);
+    (void)block_append(keep, &cnt[5]);
 }
 __global__ void k_coarsen_emit(const u64* keys, i64 v, u64* out_keys, int32_t* out_src, int* cnt) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     int st = i < v ? coarsen_state(keys, v, i) : 2;
-    int pos = wave_append(st != 2, &cnt[5]);
+    int pos = block_append(st != 2, &cnt[5]);
     if (st == 2) return;
     out_keys[pos] = st == 1 ? keys[i] >> 3 : keys[i];
     out_src[pos] = (int32_t)i;

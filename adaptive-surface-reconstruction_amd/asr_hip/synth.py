@@ -214,7 +214,7 @@ def scan_cloud(n, seed=0, device="cpu", density_variance=1.0, num_cameras=50):
         e = torch.eye(3, device=dev) * eps
         grad = torch.stack([_scene_sdf(p + e[i]) - _scene_sdf(p - e[i]) for i in range(3)], 1)
         nn_ = grad / grad.norm(dim=1, keepdim=True).clamp(min=1e-9)
-        u = torch.rand(p.shape[0], generator=g, device=dev) - 0.5
+        u = (torch.rand(p.shape[0], generator=g, device=dev) - 0.5).clamp(-0.4999999, 0.4999999)  # log1p(-1) = -inf
         lap = -torch.sign(u) * torch.log1p(-2 * u.abs())
         p = p + dirs_k * (0.001 * t * lap)[:, None]
         pts.append(p)

@@ -190,6 +190,10 @@ __global__ void k_octree_insert_points(asr_octree_frame f, const float* pts, con
                                        int* cnt, u64* list, int list_cap) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (!(isfinite(pts[3 * i]) && isfinite(pts[3 * i + 1]) && isfinite(pts[3 * i + 2]) && isfinite(radii[i]))) {
+        cnt[11] = 1;  // rejected by the host: the reference has undefined behaviour on such input
+        return;
+    }
     u64 key = point_key(f, pts, radii, i, radius_scale, max_depth);
     if (key == 0) return;  // the reference inserts key 0 here and then hits UB
     insert_with_ancestors(t, key, cnt, list, list_cap);
@@ -415,9 +419,10 @@ __global__ void k_voxel_info(asr_octree_frame f, const u64* keys, i64 v, float* 
 // a query of radius r looks at the 3^3 cells of the deepest level whose cell size is >= r.
 // ------------------------------------------------------------------------------------------
 __global__ void k_point_codes(asr_octree_frame f, const float* pts, i64 n, u64* codes,
-                              int32_t* ids) {
+                              int32_t* ids, int* cnt) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (!(isfinite(pts[3 * i]) && isfinite(pts[3 * i + 1]) && isfinite(pts[3 * i + 2]))) cnt[11] = 1;
     int x, y, z;
     frame_coord(f, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], ASR_MAX_LEVEL, x, y, z);
     const int lim = (1 << ASR_MAX_LEVEL) - 1;
@@ -765,6 +770,7 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
     const float4 me = sorted[s];
     const int kk = (int)(n < k ? n : k);
     u32 kth_bits = 0;
+    u32 bound_bits = 0x7f800000u;  // upper bound of the answer (+inf until a level has been evaluated)
     int total = 0;
     for (int lev = lfine; lev >= 0; --lev) {
         int x, y, z;
@@ -812,23 +818,69 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
             return sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z);
         };
         const int need = total < kk ? total : kk;  // lev == 0 with fewer than k points overall
-        u32 lo_bits = 0;
-        if (total <= 64 * CMAX) {
-            float d[CMAX];
+        // Selection of the need-th smallest squared distance: one pass over the candidates that keeps a
+        // pool of 8 values per lane.  Only values <= bound enter, where bound is an upper bound of the
+        // answer: the result of the finer level (k-th among a subset of these candidates) and, once a
+        // lane's slots are full, the need-th smallest of the pool itself.  (The previous version ran a
+        // 31-pass bit search over ALL candidates of every level it tried: an isolated point whose
+        // 3^3 block is a coarse cell next to a dense region walked 10^6 candidates 31 times.)
+        u32 pool[CMAX];
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) {
-                const int i = c * 64 + lane;
-                d[c] = i < total ? cand(i) : __uint_as_float(0x7f800000u);
-            }
-            // largest bit pattern t with #{d < t} < need  ==  the need-th smallest value
+        for (int c = 0; c < CMAX; ++c) pool[c] = 0x7f800000u;
+        int nl = 0;  // used slots of this lane
+        bool overflow = false;
+        // need-th smallest of the pool = largest bit pattern t with #{pool < t} < need
+        auto select = [&]() {
+            u32 lo_bits = 0;
             for (int bit = 30; bit >= 0; --bit) {
                 const u32 trial = lo_bits | (1u << bit);
                 int c_lt = 0;
 #pragma unroll
-                for (int c = 0; c < CMAX; ++c) c_lt += __popcll(__ballot(__float_as_uint(d[c]) < trial));
+                for (int c = 0; c < CMAX; ++c) c_lt += __popcll(__ballot(pool[c] < trial));
                 if (c_lt < need) lo_bits = trial;
             }
-        } else {
+            return lo_bits;
+        };
+        for (int i0 = 0; i0 < total && !overflow; i0 += 64) {
+            const int i = i0 + lane;
+            const u32 db = i < total ? __float_as_uint(cand(i)) : 0x7f800001u;
+            if (__ballot(db <= bound_bits && nl == CMAX)) {
+                // a lane is full: tighten the bound to the pool's need-th smallest and drop the rest
+                int have = 0;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) have += __popcll(__ballot(pool[c] != 0x7f800000u));
+                if (have >= need) {
+                    const u32 nb = select();
+                    if (nb < bound_bits) bound_bits = nb;
+                }
+                u32 keep[CMAX];
+                int m = 0;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) keep[c] = 0x7f800000u;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    const bool k2 = pool[c] <= bound_bits && pool[c] != 0x7f800000u;
+#pragma unroll
+                    for (int e = 0; e < CMAX; ++e)
+                        if (k2 && e == m) keep[e] = pool[c];
+                    m += k2;
+                }
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) pool[c] = keep[c];
+                nl = m;
+                if (__ballot(db <= bound_bits && nl == CMAX)) overflow = true;  // > 8 ties on one lane
+            }
+            if (!overflow && db <= bound_bits) {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c == nl) pool[c] = db;
+                ++nl;
+            }
+        }
+        u32 lo_bits = 0;
+        if (!overflow) {
+            lo_bits = select();
+        } else {  // pathological (hundreds of equal distances): bit search over the stream
             for (int bit = 30; bit >= 0; --bit) {
                 const u32 trial = lo_bits | (1u << bit);
                 int c_lt = 0;
@@ -840,6 +892,7 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
                 if (c_lt < need) lo_bits = trial;
             }
         }
+        bound_bits = lo_bits;  // k-th among a subset of the next (coarser) level's candidates
         kth_bits = lo_bits;
         const float cs = f.voxel_size[lev];
         if (lev == 0 || __uint_as_float(kth_bits) <= cs * cs) {
@@ -1084,6 +1137,7 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
             ASR_CHECK_LAUNCH(ctx);
         }
         ASR_TRY(read_flags(ctx, host));
+        if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree: points / radii contain non-finite values");
         bool overflow = host[1] != 0 || (u64)host[0] * 2 > cap;
         int lo = 0, hi = host[0];
         while (!overflow && hi > lo) {
@@ -1319,14 +1373,14 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     st.sorted = arena_alloc<float4>(ctx->scratch, n + 1);
     if (!codes_u || !codes || !ids_u || !ids || !st.sorted)
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
     if (n > 0) {
-        k_point_codes<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, n, codes_u, ids_u);
+        k_point_codes<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, n, codes_u, ids_u, ctx->d_flags);
         ASR_CHECK_LAUNCH(ctx);
         ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes_u, codes, ids_u, ids, n, 63)));
         k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted);
         ASR_CHECK_LAUNCH(ctx);
     }
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
     HashTab dummy{nullptr, nullptr, 0};
     if (n > 0) {
         k_cell_bounds<true><<<std::min<unsigned>(grid_for(n + 1, BLK), 4096u), BLK, 0, ctx->stream>>>(
@@ -1334,6 +1388,7 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
         ASR_CHECK_LAUNCH(ctx);
     }
     ASR_TRY(read_flags(ctx, host));
+    if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "points contain non-finite values");
     u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * (i64)host[8]));
     ASR_TRY(make_table(ctx, ctx->scratch, cap, false, st.tab));
     st.start = arena_alloc<int32_t>(ctx->scratch, cap);

@@ -308,3 +308,16 @@ def test_remove_components_small_cases():
         asr.remove_connected_components(np.zeros((4, 2), np.float32), t, 1)
     with pytest.raises(RuntimeError):
         asr.remove_connected_components(v[:5], t, 1)  # triangle index out of range
+
+
+def test_non_finite_points_are_rejected(gpu):
+    """the reference has undefined behaviour for inf / nan coordinates; here: a clean error (and no
+    multi-minute neighbour search)"""
+    import adaptivesurfacereconstruction as asr
+    pts, nrm, rad, bb = _cloud("sphere", 3000, 9)
+    bad = pts.copy()
+    bad[17, 1] = np.inf
+    with pytest.raises(RuntimeError):
+        asr.create_octree(bad, rad, bb[0], bb[1])
+    with pytest.raises(RuntimeError):
+        asr.KDTree(np.where(np.isfinite(bad), bad, np.float32(np.nan))).compute_k_radius(8)

@@ -369,11 +369,21 @@ __global__ void k_uf_roots(int* parent, i64 n, i64* is_root) {
 // after k_uf_roots all paths are short; flatten and count members per component label
 __global__ void k_comp_sizes(int* parent, i64 n, const i64* label_of_root, int32_t* comp, int* sizes) {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) return;  // (exited lanes are inactive below: readfirstlane / ballot see active lanes only)
     const int r = uf_find(parent, (int)i);
     const int c = (int)label_of_root[r];
     comp[i] = c;
-    atomicAdd(&sizes[c], 1);
+    // one atomic per distinct label in the wave (a mesh is mostly one component: 10^6 atomics on one
+    // address would take 12 ms)
+    bool todo = true;
+    while (todo) {
+        const int lead = __builtin_amdgcn_readfirstlane(c);
+        const unsigned long long same = __ballot(c == lead);
+        if (c == lead) {
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&sizes[lead], __popcll(same));
+            todo = false;
+        }
+    }
 }
 __global__ void k_comp_keys(const int* sizes, i64 nc, u64* keys) {
     i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -14,6 +14,8 @@ t = time.perf_counter()
 tree = asr.KDTree(pts); t = T("KDTree", t)
 r = _ops.knn_radius(tree._frame, tree._points, 24); t = T("knn radius", t)
 _, inl = _ops.knn_radius(tree._frame, tree._points, 24, r, 0.5, 1, want_inlier=True); t = T("inlier", t)
+cnt = _ops.radius_neighbor_count(tree._frame, tree._points, r); t = T("radius neighbour count", t)
+dens = _ops.density_inlier(cnt.cpu().numpy(), 10.0); t = T("density inlier (host) %d" % dens.sum(), t)
 radii = r.cpu().numpy(); inlier = inl.cpu().numpy().astype(bool)
 pts, nrm, radii = pts[inlier], nrm[inlier], radii[inlier]; t = T("filter (%d left)" % len(pts), t)
 dev = torch.device("cuda")

@@ -301,7 +301,7 @@ __global__ void k_sconv_scalar(asr_sparse_conv_args a) {
 // ------------------------------------------------------------------------------------------
 // a12 MFMA kernel (v2).
 // Block = 256 threads = 4 waves; tile = 64 output rows (16 per wave) x NCOL = NT*16 output
-// columns (blockIdx.y selects the column chunk).  Rows come from an optional permutation that
+// columns (several column chunks per row tile share an XCD, see the block index mapping).  Rows come from an optional permutation that
 // groups rows with equal kernel-slot signatures (asr_geom_row_groups): ~8 of 55 slots are
 // occupied per voxel and without regrouping a 16-row MFMA tile touches ~23 distinct slots.
 // A dense slot table nbr[64][55] is built in LDS from the CSR rows.  The block walks the slots
@@ -342,14 +342,25 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     const int wave = tid >> 6, lane = tid & 63;
     // (an XCD-contiguous tile order was measured and is slower: tiles are sorted by slot mask, so a
     // contiguous range per XCD is unbalanced -- 59 -> 70 ms for the 10 M U-Net)
-    const i64 tile = blockIdx.x;
+    // 1-D grid.  With several column chunks per row tile the chunks of one tile get consecutive slots
+    // on ONE XCD (workgroups go round-robin over the 8 XCDs: id % 8), so that the repeated feature
+    // gathers of chunks 1.. hit that XCD's L2 instead of HBM: id = ((tile / 8) * nY + y) * 8 + tile % 8.
+    const int nY = (a.cout + (DUAL ? a.cout_b : 0) + NCOL - 1) / NCOL;
+    i64 tile = blockIdx.x;
+    int ychunk = 0;
+    if (nY > 1) {
+        const i64 r8 = blockIdx.x >> 3;
+        ychunk = (int)(r8 % nY);
+        tile = (r8 / nY) * 8 + (blockIdx.x & 7);
+    }
     const i64 row0 = tile * TM;
-    const int n0 = blockIdx.y * NCOL;
+    if (row0 >= a.num_out) return;  // grid padding (whole block, before any barrier)
+    const int n0 = ychunk * NCOL;
     const int K = a.kernel_size;
     const int cin = a.cin;
     const int ca = a.cout;                              // bank a width
     const int cout = a.cout + (DUAL ? a.cout_b : 0);    // all output columns of this launch
-    const bool has_b = DUAL && blockIdx.y == gridDim.y - 1;  // this block holds the bank-b half tile
+    const bool has_b = DUAL && ychunk == nY - 1;  // this block holds the bank-b half tile
 
     for (int i = tid; i < TM * NBR_LD; i += NTHR) s_nbr[i] = -1;
     __syncthreads();
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
             if (rowok && col < cout) a.out[q * a.out_ld + col] = v;
         }
     }
-    if (a.out_importance && blockIdx.y == 0 && tid < TM && s_row[tid] >= 0)
+    if (a.out_importance && ychunk == 0 && tid < TM && s_row[tid] >= 0)
         a.out_importance[s_row[tid]] = s_norm[tid];
 }
 
@@ -795,7 +806,9 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     const bool wide = nt >= 2 && tiles128 * ((ctot + nt * 16 - 1) / (nt * 16)) >= wide_min;
 #define ASR_LAUNCH_SCONV(NT_, KC_, W_)                                                           \
     {                                                                                            \
-        dim3 grid((unsigned)((a.num_out + W_ * 16 - 1) / (W_ * 16)), (ctot + NT_ * 16 - 1) / (NT_ * 16)); \
+        const i64 tiles_ = (a.num_out + W_ * 16 - 1) / (W_ * 16);                                \
+        const i64 ny_ = (ctot + NT_ * 16 - 1) / (NT_ * 16);                                      \
+        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));                   \
         if (dual)                                                                                \
             k_sconv_mfma<NT_, KC_, true, W_, true><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(a, zeros); \
         else if (imp)                                                                            \

@@ -27,8 +27,14 @@ for l in (3, 2, 1, 0):
 pairs = [19838807, 4537981, 1179462, 329893, 89914]
 vox = [2572109, 600041, 160994, 45823, 12566]
 tot = [0.0] * len(files)
+fused = len(files[0]) == 44  # conv1a + conv1b share a launch since the second filter bank
+if fused:
+    keep = [i for i, n in enumerate(seq) if not n.endswith('conv1b')]
+    seq, lev = [seq[i] for i in keep], [lev[i] for i in keep]
 for i, n in enumerate(seq):
     k, ci, co = shapes['sparseconv_' + n + '.kernel']
+    if fused and n.endswith('conv1a'):
+        co += 8
     L = lev[i]
     P = pairs[L] if k == 55 else (vox[L - 1] if 'down' in n else vox[L])
     fl = 2.0 * P * ci * co

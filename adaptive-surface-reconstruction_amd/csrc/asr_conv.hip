@@ -798,7 +798,7 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     // panel traffic per MFMA and are used whenever they still give enough blocks.
     int nt = ctot > 128 ? 16 : ctot > 64 ? 8 : ctot > 32 ? 4 : ctot > 16 ? 2 : 1;
     const i64 tiles64 = (a.num_out + 63) / 64;
-    static const i64 min_blocks = getenv("ASR_SCONV_MIN_BLOCKS") ? atoll(getenv("ASR_SCONV_MIN_BLOCKS")) : 3072;
+    static const i64 min_blocks = getenv("ASR_SCONV_MIN_BLOCKS") ? atoll(getenv("ASR_SCONV_MIN_BLOCKS")) : 2816;  // 11 blocks per CU
     while (nt > 2 && tiles64 * ((ctot + nt * 16 - 1) / (nt * 16)) < min_blocks) nt >>= 1;
     while (dual && ctot % (nt * 16) != 0) nt >>= 1;  // bank b must be the last tile of the last column chunk
     const i64 tiles128 = (a.num_out + 127) / 128;

@@ -17,7 +17,7 @@ static i64 asr_row_group_segment() {
     static i64 v = [] {
         const char* e = getenv("ASR_ROW_SEGMENT");
         i64 x = e ? atoll(e) : 0;
-        return x > 0 ? x : (i64)131072;
+        return x > 0 ? x : (i64)524288;
     }();
     return v;
 }

@@ -520,6 +520,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
             float bv[2][NT];
 #pragma unroll
             for (int nb = 0; nb < NT; ++nb) bv[0][nb] = sb[nb * 16];
+            __builtin_amdgcn_s_setprio(1);  // a wave with MFMAs to issue wins over the ones issuing loads (1 %)
 #pragma unroll
             for (int jt = 0; jt < NJ * 4; ++jt) {
                 const int j = jt >> 2, t = jt & 3;
@@ -537,6 +538,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
                 if (DUAL && has_b)
                     acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(av * imp_cur, bv[jt & 1][NT - 1], acc_b, 0, 0, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         store_panel(buf ^ 1, st_next);  // panel of the next step, loaded one step ago
         __syncthreads();

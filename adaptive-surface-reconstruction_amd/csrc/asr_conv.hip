@@ -477,15 +477,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
             if (SV_EXACT || e < PV) *reinterpret_cast<f32x4*>(&s_B[buf][pr * BLD + pc]) = st[s];
         }
     };
+    // The neighbour of (row, slot) is looked up in the LDS slot table once per SLOT, not once per panel:
+    // that ds_read sits at the head of every step's dependency chain (ds_read -> address -> global load)
+    // right after the barrier, when no wave of the block has MFMAs to issue.
+    int cache_k = -2;
+    const float* cache_row = zeros;
+    bool cache_valid = false;
+    float cache_imp = 0.f;
     auto gather_a = [&](const int qk, const int qp, f32x4 (&aq)[NJ], float& imp) __attribute__((always_inline)) {
-        const int idx = qk < 0 ? -1 : s_nbr[lrow * NBR_LD + qk];
-        const bool valid = idx >= 0;
-        const float* frow = a.inp_features + (i64)(valid ? idx : 0) * a.inp_ld;
-        if (IMP) imp = valid ? s_w[lrow * NBR_LD + qk] : 0.f;
+        if (qk != cache_k) {  // wave uniform
+            cache_k = qk;
+            const int idx = qk < 0 ? -1 : s_nbr[lrow * NBR_LD + qk];
+            cache_valid = idx >= 0;
+            cache_row = a.inp_features + (i64)(cache_valid ? idx : 0) * a.inp_ld;
+            if (IMP) cache_imp = (cache_valid && qk >= 0) ? s_w[lrow * NBR_LD + qk] : 0.f;
+        }
+        if (IMP) imp = cache_imp;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             int c = qp * KC + 16 * j + 4 * g;
-            const float* src = (valid && c < cin) ? frow + c : zeros;
+            const float* src = (cache_valid && c < cin) ? cache_row + c : zeros;
             aq[j] = *reinterpret_cast<const f32x4*>(src);
         }
     };
@@ -511,6 +522,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
 #pragma unroll
         for (int j = 0; j < NJ; ++j) a_cur[j] = aq[j];
         const float imp_cur = imp;
+        // panel of the NEXT step (loaded one step ago) goes to the other LDS buffer right away: that
+        // buffer was released by the barrier that ended the previous step, and the ds_write + its wait
+        // no longer sit between the last MFMA and the barrier
+        store_panel(buf ^ 1, st_next);
         load_panel(k2, p2, st_free);    // two steps ahead; stays in flight across the barrier
         gather_a(k2, p2, aq, imp);
         // a wave whose 16 rows lack slot k_cur skips the MFMAs (PMC: executing them
@@ -540,7 +555,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
             }
             __builtin_amdgcn_s_setprio(0);
         }
-        store_panel(buf ^ 1, st_next);  // panel of the next step, loaded one step ago
         __syncthreads();
         buf ^= 1;
         k_cur = k1;

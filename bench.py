@@ -58,7 +58,7 @@ def conv_flops(sizes, shapes):
 
 def rank_seed(rank):
     """one scan per rank: the path shards by scan, no data moves between ranks"""
-    return 1000 + rank
+    return int(os.environ.get("ASR_BENCH_SEED_BASE", 1000)) + rank
 
 
 def max_over_ranks(dt, world, device):

@@ -134,3 +134,36 @@ def test_ten_million_points_properties(gpu):
     assert float(torch.isin(rev, uniq).float().mean()) > 0.9       # closed up to the scan's open boundary
     mv2, mt2 = pipe.mesh(values=field)
     assert torch.equal(mv, mv2) and torch.equal(mt, mt2)
+
+
+def test_config_c2_single_scale_cconv_one_million_uniform_points(gpu):
+    """BASELINE config 2: single-scale continuous conv on 1 M uniform-density points, fp32.  Octree,
+    neighbour search and the conv run on the GPU; the search result is compared bit for bit and the
+    conv within 1e-5 with the oracle on the same arrays."""
+    from asr_hip import _lib, ops
+    from oracle import oracle as O
+    rng = np.random.default_rng(42)
+    n = 1_000_000
+    pts = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    rad = np.full(n, 0.02, np.float32)  # uniform density -> one octree level
+    feats = rng.normal(size=(n, 4)).astype(np.float32)
+    bb_min, bb_max = np.full(3, -1.05, np.float32), np.full(3, 1.05, np.float32)
+    frame = _lib.frame_init(bb_min, bb_max)
+    d = lambda a: torch.from_numpy(a).to(gpu)  # noqa: E731
+    nodes, leaves = ops.octree_build(frame, d(pts), d(rad), 1.0, 21)
+    centers, sizes = ops.voxel_info(frame, leaves)
+    assert torch.unique(sizes).numel() <= 2  # one point scale (empty sibling cells stay one level coarser)
+    idx, dist, rs, compat = ops.multi_radius_search(frame, d(pts), d(rad), centers, sizes)
+    o = O.Oracle()
+    o.build_octree(pts, rad, bb_min, bb_max)
+    g0 = o.create_grids(1)[0]
+    assert np.array_equal(leaves.cpu().numpy().view(np.uint64), g0["voxel_keys"])
+    ridx, rdist, rrs, rcompat = o.radius_search(pts, rad, g0["voxel_centers"], g0["voxel_sizes"])
+    assert np.array_equal(rs.cpu().numpy(), rrs) and np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy(), rdist)
+    W = (rng.standard_normal((4, 4, 4, 4, 32)) * 0.5).astype(np.float32)
+    imp = (rcompat * O.window_poly6(rdist)).astype(np.float32)
+    out = ops.continuous_conv(d(W), centers, sizes, d(pts), d(feats), idx, d(imp), rs, True)
+    ref = O.continuous_conv(W, g0["voxel_centers"], g0["voxel_sizes"], pts, feats, ridx, imp, rrs, True)
+    err = np.abs(out.cpu().numpy() - ref)
+    assert err.max() <= 1e-5 * max(1.0, float(np.abs(ref).max())), err.max()

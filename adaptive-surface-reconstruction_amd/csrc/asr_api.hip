@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include <algorithm>
+#include <thread>
 
 #include "asr_common.h"
 #include "asr_uset.h"
@@ -47,13 +48,12 @@ int asr_hip_context_create(asr_hip_context** out, void* stream) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ASR_HIP_ENODEV;
     asr_hip_context* ctx = new asr_hip_context();
     ctx->stream = (hipStream_t)stream;
+    (void)hipGetDevice(&ctx->device);
     memset(&ctx->sizes, 0, sizeof(ctx->sizes));
     *out = ctx;
     return ASR_HIP_OK;
 }
-void asr_hip_context_destroy(asr_hip_context* ctx) {
-    if (!ctx) return;
-    (void)hipStreamSynchronize(ctx->stream);
+static void release_members(asr_hip_context* ctx) {
     asr_geom_release(ctx);
     asr_mesh_release(ctx);
     ctx->persist.release();
@@ -62,6 +62,18 @@ void asr_hip_context_destroy(asr_hip_context* ctx) {
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->ev_ok)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+}
+void asr_hip_context_destroy(asr_hip_context* ctx) {
+    if (!ctx) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux) {
+        (void)hipStreamSynchronize(ctx->aux->stream);
+        release_members(ctx->aux);
+        if (ctx->aux_stream_owned) (void)hipStreamDestroy(ctx->aux->stream);
+        if (ctx->aux_ev) (void)hipEventDestroy(ctx->aux_ev);
+        delete ctx->aux;
+    }
+    release_members(ctx);
     delete ctx;
 }
 void asr_hip_context_set_stream(asr_hip_context* ctx, void* stream) {
@@ -69,7 +81,10 @@ void asr_hip_context_set_stream(asr_hip_context* ctx, void* stream) {
 }
 const char* asr_hip_last_error(const asr_hip_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 size_t asr_hip_context_reserved_bytes(const asr_hip_context* ctx) {
-    return ctx ? ctx->persist.reserved() + ctx->scratch.reserved() : 0;
+    if (!ctx) return 0;
+    size_t t = ctx->persist.reserved() + ctx->scratch.reserved();
+    if (ctx->aux) t += ctx->aux->persist.reserved() + ctx->aux->scratch.reserved();
+    return t;
 }
 
 // cpp/lib/octree.cpp:20-42 (float / double operation order is part of the contract, A.7)
@@ -551,15 +566,84 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (ctx->num_leaves == 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "no point inside the bounding box");
 
+    // level-0 voxel centres / sizes first: the aggregation search only needs those
+    {
+        GridDev& g0 = ctx->grids[0];
+        g0 = GridDev();
+        g0.v = ctx->num_leaves;
+        g0.keys = ctx->leaves;
+        g0.centers = arena_alloc<float>(ctx->persist, 3 * g0.v);
+        g0.sizes = arena_alloc<float>(ctx->persist, g0.v);
+        if (!g0.centers || !g0.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g0.keys, g0.v, g0.centers, g0.sizes));
+    }
+
+    // Aggregation neighbours (cpp/lib/asr.cpp:266-273) on the auxiliary context: its own stream, arenas,
+    // counters and host thread, overlapped with the grid hierarchy below.  Both are chains of
+    // latency-bound kernels with host round trips for the data-dependent sizes; neither fills the GPU.
+    static const bool overlap = !(getenv("ASR_OVERLAP") && atoi(getenv("ASR_OVERLAP")) == 0);
+    asr_hip_context* sc = ctx;  // context the search runs on
+    if (overlap) {
+        if (!ctx->aux) {
+            ctx->aux = new asr_hip_context();
+            ctx->aux->device = ctx->device;
+            memset(&ctx->aux->sizes, 0, sizeof(ctx->aux->sizes));
+            // lowest priority: the search's large grids must not starve the small kernels of the chain
+            // on the caller's stream
+            int prio_least = 0, prio_greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+            ASR_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->aux->stream, hipStreamNonBlocking, prio_least));
+            ctx->aux_stream_owned = true;
+            ASR_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
+        }
+        sc = ctx->aux;
+        sc->persist.reset();
+        sc->scratch.reset();
+        sc->err.clear();
+        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));      // inputs + level-0 info are ready
+        ASR_HIP_CHECK(ctx, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
+    }
+    i64 agg_pairs = 0;
+    auto search = [&]() -> int {
+        if (sc != ctx) {
+            if (hipSetDevice(ctx->device) != hipSuccess) {
+                sc->err = "hipSetDevice failed in the search thread";
+                return ASR_HIP_EHIP;
+            }
+        } else {
+            ctx->scratch.reset();
+        }
+        GridDev& g0 = ctx->grids[0];
+        ctx->agg_rs = arena_alloc<i64>(sc->persist, g0.v + 1);
+        if (!ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
+                                      &agg_pairs));
+        ctx->agg_idx = arena_alloc<int32_t>(sc->persist, agg_pairs);
+        ctx->agg_dist = arena_alloc<float>(sc->persist, agg_pairs);
+        ctx->agg_compat = arena_alloc<float>(sc->persist, agg_pairs);
+        if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat)
+            ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_radius_fill(sc, points, radii, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs, ctx->agg_idx,
+                                     ctx->agg_dist, ctx->agg_compat));
+        if (sc != ctx) ASR_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
+        return ASR_HIP_OK;
+    };
+    int search_rc = ASR_HIP_OK;
+    std::thread worker;
+    if (overlap) worker = std::thread([&] { search_rc = search(); });
+    struct Joiner {  // the grid code below returns early on errors: never leave the thread running
+        std::thread& t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{worker};
+
     // grids (cpp/lib/grid.cpp:245-314)
     for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
         GridDev& g = ctx->grids[i];
-        g = GridDev();
+        if (i > 0) g = GridDev();
         ctx->scratch.reset();
-        if (i == 0) {
-            g.v = ctx->num_leaves;
-            g.keys = ctx->leaves;
-        } else {
+        if (i > 0) {
             GridDev& prev = ctx->grids[i - 1];
             ASR_TRY(asr_geom_coarsen_count(ctx, prev.keys, prev.v, &g.v));
             g.keys = arena_alloc<u64>(ctx->persist, g.v);
@@ -593,10 +677,12 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             name_it(ctx, "down_neighbors_kernel_index" + s, prev.down_kidx, prev.v);
             name_it(ctx, "down_neighbors_row_splits" + s, prev.down_rs, 8 * (g.v + 1));
         }
-        g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
-        g.sizes = arena_alloc<float>(ctx->persist, g.v);
-        if (!g.centers || !g.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
+        if (i > 0) {
+            g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
+            g.sizes = arena_alloc<float>(ctx->persist, g.v);
+            if (!g.centers || !g.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
+        }
         ASR_TRY(asr_geom_neighbors_build(ctx, ctx->persist, g.keys, g.v, &g.nrs, &g.nidx, &g.nkidx,
                                          &g.p));
         g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
@@ -614,26 +700,20 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
-    // aggregation neighbours (cpp/lib/asr.cpp:266-273)
+    if (overlap)
+        worker.join();
+    else
+        search_rc = search();
+    if (search_rc != ASR_HIP_OK) {
+        if (sc != ctx) ctx->err = sc->err;
+        return search_rc;
+    }
     {
-        ctx->scratch.reset();
         GridDev& g0 = ctx->grids[0];
-        ctx->agg_rs = arena_alloc<i64>(ctx->persist, g0.v + 1);
-        if (!ctx->agg_rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        i64 P = 0;
-        ASR_TRY(asr_geom_radius_count(ctx, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v,
-                                      ctx->agg_rs, &P));
-        ctx->agg_idx = arena_alloc<int32_t>(ctx->persist, P);
-        ctx->agg_dist = arena_alloc<float>(ctx->persist, P);
-        ctx->agg_compat = arena_alloc<float>(ctx->persist, P);
-        if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat)
-            ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_radius_fill(ctx, points, radii, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
-                                     ctx->agg_idx, ctx->agg_dist, ctx->agg_compat));
-        ctx->sizes.num_agg_pairs = P;
-        name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * P);
-        name_it(ctx, "aggregation_neighbors_dist", ctx->agg_dist, 4 * P);
-        name_it(ctx, "aggregation_scale_compat", ctx->agg_compat, 4 * P);
+        ctx->sizes.num_agg_pairs = agg_pairs;
+        name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * agg_pairs);
+        name_it(ctx, "aggregation_neighbors_dist", ctx->agg_dist, 4 * agg_pairs);
+        name_it(ctx, "aggregation_scale_compat", ctx->agg_compat, 4 * agg_pairs);
         name_it(ctx, "aggregation_row_splits", ctx->agg_rs, 8 * (g0.v + 1));
     }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));

@@ -110,6 +110,11 @@ struct asr_hip_context {
     void* radius_state = nullptr;  // RadiusState of asr_geom.hip (between _count and _fill)
     void* mesh_state = nullptr;    // MeshState of asr_mesh.hip (between _count and _fill)
     std::map<std::string, std::pair<const void*, size_t>> named;  // asr_hip_implicit_get
+    int device = 0;                 // HIP device of this context (helper threads must select it)
+    asr_hip_context* aux = nullptr;  // second stream + arenas: the aggregation search runs there, overlapped
+                                    // with the grid hierarchy build (asr_api.hip implicit_build)
+    bool aux_stream_owned = false;
+    hipEvent_t aux_ev = nullptr;
 };
 
 #define ASR_FAIL(ctx, code, ...)                         \

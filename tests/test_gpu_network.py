@@ -400,3 +400,41 @@ def test_open3d_facade_ops_on_gpu(geo, gpu):
     _close(y.cpu().numpy(), np.maximum(ref + conv.bias.detach().cpu().numpy(), 0))
     with pytest.raises(NotImplementedError):  # no CPU kernel in the product facade
         ml3d.ops.reduce_subarrays_sum(torch.zeros(3), torch.tensor([0, 3]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 65, 300])
+def test_whole_path_tiny_clouds(gpu, n):
+    """degenerate sizes: a handful of points still gives the oracle's grids and values (single voxel
+    levels, rows shorter than a wave, empty coarse grids' neighbours)"""
+    from asr_hip.pipeline import ImplicitPipeline
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    rad = rng.uniform(0.02, 0.1, size=n).astype(np.float32)
+    bb = (np.full(3, -0.6, np.float32), np.full(3, 0.6, np.float32))
+    weights = synth.make_weights(4, seed=3)
+    pipe = ImplicitPipeline(weights, device=gpu)
+    try:
+        ref = parity.oracle_forward(pts, nrm, rad, bb[0], bb[1], weights)
+    except IndexError:
+        # SURVEY B.2: the per-pair importance array is indexed with voxel indices; with fewer aggregation
+        # pairs than voxels the reference indexes out of bounds -- the library reports that as an error
+        with pytest.raises(RuntimeError):
+            pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
+        return
+    values = pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
+    for i in range(5):
+        assert np.array_equal(pipe.get("voxel_keys%d" % i).cpu().numpy().view(np.uint64), ref["voxel_keys%d" % i])
+        assert np.array_equal(pipe.get("neighbors_index%d" % i).cpu().numpy(), ref["neighbors_index%d" % i])
+    assert np.array_equal(pipe.get("aggregation_neighbors_index").cpu().numpy(), ref["aggregation_neighbors_index"])
+    _close(values.cpu().numpy(), ref["values"])
+    v, t = pipe.mesh()
+    duals = pipe.dual_cells().cpu().numpy()
+    o = O.Oracle()
+    o.build_octree(pts, rad, bb[0], bb[1])
+    o.create_grids(1)
+    assert np.array_equal(duals, o.create_dual_vertex_indices().astype(np.int64))
+    wv, wt = O.create_triangle_mesh(values.cpu().numpy(), duals, pipe.get("voxel_centers0").cpu().numpy(), 1.0)
+    wv, wt = O.remove_connected_components(wv, wt, 2**63 - 1, 3)
+    assert np.array_equal(v.cpu().numpy().view(np.uint32), wv.view(np.uint32)) and np.array_equal(t.cpu().numpy(), wt)

@@ -421,6 +421,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
     bmask &= (1ull << K) - 1;  // K <= 56
     if (a.algo == 9) bmask = 0;        // measurement aid (ASR_SCONV_DRY=1): prologue + epilogue only
+    if (a.algo == 8) wmask = bmask;    // measurement aid (ASR_SCONV_DRY=2): no wave-level slot skip
 
     f32x4 acc[NT];
 #pragma unroll
@@ -806,8 +807,8 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     const int ctot = a.cout + (dual ? a.cout_b : 0);
     if (dual && (!imp || a.cout % 16 != 8 || a.cout_b != 8 || a.residual || (uintptr_t)a.filters_b % 16 != 0))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: second filter bank needs importance, cout %% 16 == 8, cout_b == 8");
-    static const bool dry = getenv("ASR_SCONV_DRY") && atoi(getenv("ASR_SCONV_DRY"));
-    if (dry) a.algo = 9;
+    static const int dry = getenv("ASR_SCONV_DRY") ? atoi(getenv("ASR_SCONV_DRY")) : 0;
+    if (dry) a.algo = dry == 2 ? 8 : 9;
     // widest column tile that fits cout, narrowed while the launch has too few blocks to fill
     // 256 CUs (coarse grids have only a few thousand rows; the gather is then repeated per
     // column chunk, which those levels can afford).  128-row blocks (8 waves) halve the weight

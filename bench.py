@@ -171,8 +171,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (ASR_BENCH_FORCE_DEVICE: run several ranks on one GPU with --backend gloo, to exercise the
+    # multi-process logic on a single-GPU box)
+    dev_index = int(os.environ.get("ASR_BENCH_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world,

@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--points", type=int, default=int(os.environ.get("ASR_BENCH_POINTS", 10_000_000)))
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("ASR_BENCH_CPU_SAMPLE", 1_000_000)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-context run (profiling)")
     ap.add_argument("--backend", default="nccl")
     args = ap.parse_args()
 
@@ -220,7 +221,7 @@ def main():
     assert values.shape[0] == pipe.sizes.num_voxels[0] and bool(torch.isfinite(values).all())
     mesh_info = mesh_stage(pipe, synth) if rank == 0 else None
     pipelined = None
-    if world == 1:
+    if world == 1 and not args.no_pipelined:
         pipelined = pipelined_rate(pipe, weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(4, 2 * args.steps))
 
     if rank == 0:

@@ -56,6 +56,8 @@ class SparseConvArgs(ctypes.Structure):
         ("filters_b", ctypes.c_void_p),
         ("bias_b", ctypes.c_void_p),
         ("cout_b", ctypes.c_int),
+        ("force_nt", ctypes.c_int),
+        ("force_waves", ctypes.c_int),
     ]
 
 
@@ -92,7 +94,8 @@ class ImplicitSizes(ctypes.Structure):
 EXPORTS = [
     "asr_hip_context_create", "asr_hip_context_destroy", "asr_hip_context_set_stream",
     "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes",
-    "asr_hip_struct_size",
+    "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_set_option", "asr_hip_context_get_option",
+    "asr_hip_sparse_conv_variant_counts",
     "asr_octree_frame_init", "asr_hip_point_keys", "asr_hip_octree_build", "asr_hip_octree_get", "asr_hip_dual_cells_count", "asr_hip_dual_cells_fill",
     "asr_hip_contour_count", "asr_hip_contour_fill", "asr_hip_components_count", "asr_hip_components_fill",
     "asr_hip_unordered_set_order", "asr_density_inlier",
@@ -166,6 +169,30 @@ class Context:
 
     def call(self, name, *args):
         self.check(getattr(self.lib, name)(self._h, *args))
+
+    def set_option(self, name, value):
+        """per-context tunable (include/asr_hip.h asr_hip_context_set_option)"""
+        self.call("asr_hip_context_set_option", name.encode(), ctypes.c_int64(int(value)))
+
+    def get_option(self, name):
+        v = ctypes.c_int64(0)
+        self.call("asr_hip_context_get_option", name.encode(), ctypes.byref(v))
+        return v.value
+
+    @property
+    def device_index(self):
+        return int(self.lib.asr_hip_context_device(self._h))
+
+    def sconv_variant_counts(self, reset=False):
+        """{(NT, KC, IMP, WAVES, DUAL): launches} of k_sconv_mfma since the last reset"""
+        buf = ctypes.create_string_buffer(4096)
+        self.call("asr_hip_sparse_conv_variant_counts", buf, ctypes.c_size_t(4096), int(bool(reset)))
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                k, c = item.split(":")
+                out[tuple(int(x) for x in k.split(","))] = int(c)
+        return out
 
     def reserved_bytes(self):
         return int(self.lib.asr_hip_context_reserved_bytes(self._h))

@@ -13,16 +13,23 @@ import torch
 from . import _lib
 from ._lib import AsrHipError, Context, ptr
 
-_ctx = None
+_ctx = {}  # device index -> Context
 
 
-def context():
-    """process-wide context on torch's current stream"""
-    global _ctx
-    if _ctx is None:
-        _ctx = Context()
-    _ctx.set_stream(torch.cuda.current_stream())
-    return _ctx
+def context(device=None):
+    """the process-wide context of `device` (default: torch's current device), on torch's current
+    stream of that device.  One context per GPU: a context is bound to the device it was created on."""
+    if device is None:
+        index = torch.cuda.current_device()
+    else:
+        device = torch.device(device)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+    ctx = _ctx.get(index)
+    if ctx is None:
+        with torch.cuda.device(index):
+            ctx = _ctx[index] = Context()
+    ctx.set_stream(torch.cuda.current_stream(index))
+    return ctx
 
 
 def _dev(t, dtype):
@@ -35,6 +42,19 @@ def _dev(t, dtype):
     return t.contiguous()
 
 
+def _same_device(*tensors):
+    """all tensors of one call must live on one GPU; returns that device"""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise AsrHipError("tensors on different devices (%s and %s) in one call" % (dev, t.device))
+    return dev
+
+
 i64 = ctypes.c_int64
 
 
@@ -43,7 +63,7 @@ def point_keys(frame, points, radii, radius_scale=1.0, max_depth=21):
     radii = _dev(radii, torch.float32)
     n = points.shape[0]
     keys = torch.empty(n, dtype=torch.int64, device=points.device)
-    context().call("asr_hip_point_keys", ctypes.byref(frame), ptr(points), ptr(radii), i64(n),
+    context(_same_device(points, radii)).call("asr_hip_point_keys", ctypes.byref(frame), ptr(points), ptr(radii), i64(n),
                    ctypes.c_float(radius_scale), int(max_depth), ptr(keys))
     return keys  # uint64 bit pattern in an int64 tensor
 
@@ -57,7 +77,7 @@ def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
     if radii.ndim != 1 or radii.shape[0] != points.shape[0]:
         raise ValueError("radii must have shape [N]")
     nn, nl = i64(0), i64(0)
-    ctx = context()
+    ctx = context(_same_device(points, radii))
     ctx.call("asr_hip_octree_build", ctypes.byref(frame), ptr(points), ptr(radii),
              i64(points.shape[0]), ctypes.c_float(radius_scale), int(max_depth), ctypes.byref(nn),
              ctypes.byref(nl))
@@ -69,7 +89,7 @@ def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
 
 def dual_cells(device, ctx=None):
     """dual_vertex_indices [D,8] (int64) of the octree built last on this context"""
-    ctx = ctx or context()
+    ctx = ctx or context(device)
     d = i64(0)
     ctx.call("asr_hip_dual_cells_count", ctypes.byref(d))
     out = torch.empty((d.value, 8), dtype=torch.int64, device=device)
@@ -90,7 +110,7 @@ def contour(values, dual_vertex_indices, node_positions, threshold=1.0, ctx=None
         raise ValueError("dual_vertex_indices must have shape [D,8]")
     if pos.dim() != 2 or pos.shape[1] != 3 or pos.shape[0] != values.shape[0]:
         raise ValueError("node_positions must have shape [V,3]")
-    ctx = ctx or context()
+    ctx = ctx or context(_same_device(values, duals, pos))
     nv, nt = i64(0), i64(0)
     ctx.call("asr_hip_contour_count", ptr(values), i64(values.shape[0]), ptr(duals), i64(duals.shape[0]),
              ptr(pos), ctypes.c_float(threshold), ctypes.byref(nv), ctypes.byref(nt))
@@ -108,7 +128,7 @@ def remove_components(vertices, triangles, keep_n, min_size=3, ctx=None):
         raise ValueError("vertices must have shape [N,3]")
     if triangles.dim() != 2 or triangles.shape[1] != 3:
         raise ValueError("triangles must have shape [M,3]")
-    ctx = ctx or context()
+    ctx = ctx or context(_same_device(vertices, triangles))
     nv, nt = i64(0), i64(0)
     ctx.call("asr_hip_components_count", ptr(vertices), i64(vertices.shape[0]), ptr(triangles),
              i64(triangles.shape[0]), i64(min(int(keep_n), 2**62)), i64(int(min_size)), ctypes.byref(nv),
@@ -124,7 +144,7 @@ def grid_neighbors(keys):
     v = keys.shape[0]
     rs = torch.empty(v + 1, dtype=torch.int64, device=keys.device)
     p = i64(0)
-    ctx = context()
+    ctx = context(_same_device(keys))
     ctx.call("asr_hip_grid_neighbors_count", ptr(keys), i64(v), ptr(rs), ctypes.byref(p))
     idx = torch.empty(p.value, dtype=torch.int32, device=keys.device)
     kidx = torch.empty(p.value, dtype=torch.uint8, device=keys.device)
@@ -136,7 +156,7 @@ def grid_coarsen(keys):
     keys = _dev(keys, torch.int64)
     v = keys.shape[0]
     vo = i64(0)
-    ctx = context()
+    ctx = context(_same_device(keys))
     ctx.call("asr_hip_grid_coarsen_count", ptr(keys), i64(v), ctypes.byref(vo))
     out_keys = torch.empty(vo.value, dtype=torch.int64, device=keys.device)
     up_idx = torch.empty(v, dtype=torch.int32, device=keys.device)
@@ -152,7 +172,7 @@ def voxel_info(frame, keys):
     v = keys.shape[0]
     centers = torch.empty((v, 3), dtype=torch.float32, device=keys.device)
     sizes = torch.empty(v, dtype=torch.float32, device=keys.device)
-    context().call("asr_hip_voxel_info", ctypes.byref(frame), ptr(keys), i64(v), ptr(centers),
+    context(_same_device(keys)).call("asr_hip_voxel_info", ctypes.byref(frame), ptr(keys), i64(v), ptr(centers),
                    ptr(sizes))
     return centers, sizes
 
@@ -166,7 +186,7 @@ def multi_radius_search(frame, points, radii, centers, sizes):
     n, v = points.shape[0], sizes.shape[0]
     rs = torch.empty(v + 1, dtype=torch.int64, device=points.device)
     p = i64(0)
-    ctx = context()
+    ctx = context(_same_device(points, radii, centers, sizes))
     ctx.call("asr_hip_multi_radius_search_count", ctypes.byref(frame), ptr(points), i64(n),
              ptr(centers), ptr(sizes), i64(v), ptr(rs), ctypes.byref(p))
     idx = torch.empty(p.value, dtype=torch.int32, device=points.device)
@@ -185,7 +205,7 @@ def knn_radius(frame, points, k, radii=None, radius_fraction=0.5, outlier_thresh
     out = torch.empty(n, dtype=torch.float32, device=points.device)
     rin = _dev(radii, torch.float32) if radii is not None else None
     inl = torch.empty(n, dtype=torch.uint8, device=points.device) if want_inlier else None
-    context().call("asr_hip_knn_radius", ctypes.byref(frame), ptr(points), i64(n), int(k), ptr(rin),
+    context(_same_device(points, rin)).call("asr_hip_knn_radius", ctypes.byref(frame), ptr(points), i64(n), int(k), ptr(rin),
                    ctypes.c_float(radius_fraction), int(outlier_threshold), ptr(out), ptr(inl))
     return (out, inl.bool()) if want_inlier else out
 
@@ -195,7 +215,7 @@ def radius_neighbor_count(frame, points, radii):
     points = _dev(points, torch.float32)
     radii = _dev(radii, torch.float32)
     out = torch.empty(points.shape[0], dtype=torch.int64, device=points.device)
-    context().call("asr_hip_radius_neighbor_count", ctypes.byref(frame), ptr(points), ptr(radii),
+    context(_same_device(points, radii)).call("asr_hip_radius_neighbor_count", ctypes.byref(frame), ptr(points), ptr(radii),
                    i64(points.shape[0]), ptr(out))
     return out
 
@@ -204,7 +224,7 @@ def aggregation_importance(compat, dist):
     compat = _dev(compat, torch.float32)
     dist = _dev(dist, torch.float32)
     out = torch.empty_like(compat)
-    context().call("asr_hip_aggregation_importance", ptr(compat), ptr(dist), i64(compat.shape[0]),
+    context(_same_device(compat, dist)).call("asr_hip_aggregation_importance", ptr(compat), ptr(dist), i64(compat.shape[0]),
                    ptr(out))
     return out
 
@@ -234,7 +254,8 @@ def continuous_conv(filters, out_positions, extents, inp_positions, inp_features
         nimp = _dev(neighbors_importance, torch.float32)
     b = _dev(bias, torch.float32) if bias is not None else None
     out = torch.empty((v, cout), dtype=torch.float32, device=filters.device)
-    context().call("asr_hip_continuous_conv_f32", ptr(filters), ptr(out_positions), ptr(extents),
+    dev = _same_device(filters, out_positions, extents, inp_positions, inp_features, nidx, rs, nimp, b)
+    context(dev).call("asr_hip_continuous_conv_f32", ptr(filters), ptr(out_positions), ptr(extents),
                    ptr(inp_positions), ptr(inp_features), ptr(nidx), ptr(nimp), ptr(rs), i64(v),
                    int(cin), int(cout), int(bool(normalize)), ptr(b), int(bool(relu)), ptr(out))
     return out
@@ -243,7 +264,8 @@ def continuous_conv(filters, out_positions, extents, inp_positions, inp_features
 def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
                 neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False,
                 residual=None, out=None, return_importance=False, algo=0,
-                neighbors_importance=None, row_perm=None, filters_b=None, bias_b=None):
+                neighbors_importance=None, row_perm=None, filters_b=None, bias_b=None, force_nt=0,
+                force_waves=0):
     """SpecialSparseConv.forward (models/common_torch.py:95-148) in one launch.  filters_b / bias_b:
     optional second filter bank (conv1a + conv1b of a SparseConvBlock in one pass): output columns
     [cout, cout + cout_b); importance, normalize and the returned importance sum then belong to bank b."""
@@ -296,7 +318,10 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     a.filters_b = fb.data_ptr() if fb is not None else None
     a.bias_b = bb.data_ptr() if bb is not None else None
     a.cout_b = fb.shape[2] if fb is not None else 0
-    context().call("asr_hip_sparse_conv_f32", ctypes.byref(a))
+    a.force_nt = int(force_nt)
+    a.force_waves = int(force_waves)
+    dev = _same_device(filters, inp_features, nidx, nk, rs, imp, nimp, b, res, fb, bb, out, perm)
+    context(dev).call("asr_hip_sparse_conv_f32", ctypes.byref(a))
     if return_importance:
         return out, oimp
     return out
@@ -308,7 +333,7 @@ def row_groups(neighbors_kernel_index, neighbors_row_splits, segment_rows=0):
     rs = _dev(neighbors_row_splits, torch.int64)
     v = rs.shape[0] - 1
     perm = torch.empty(v, dtype=torch.int32, device=rs.device)
-    context().call("asr_hip_row_groups", ptr(nk), ptr(rs), i64(v), i64(segment_rows), ptr(perm))
+    context(_same_device(nk, rs)).call("asr_hip_row_groups", ptr(nk), ptr(rs), i64(v), i64(segment_rows), ptr(perm))
     return perm
 
 
@@ -323,7 +348,7 @@ def invert_neighbors_list(num_points, inp_neighbors_index, inp_neighbors_row_spl
     out_idx = torch.empty(p, dtype=torch.int32, device=idx.device)
     out_rs = torch.empty(num_points + 1, dtype=torch.int64, device=idx.device)
     out_attr = torch.empty(p if attr is not None else 0, dtype=torch.uint8, device=idx.device)
-    context().call("asr_hip_invert_neighbors_list", i64(num_points), ptr(idx), ptr(rs),
+    context(_same_device(idx, rs, attr)).call("asr_hip_invert_neighbors_list", i64(num_points), ptr(idx), ptr(rs),
                    i64(rs.shape[0] - 1), ptr(attr), ptr(out_idx), ptr(out_rs),
                    ptr(out_attr) if attr is not None else ctypes.c_void_p(0))
     return out_idx, out_rs, out_attr
@@ -334,7 +359,7 @@ def reduce_subarrays_sum(values, row_splits, gather_index=None):
     rs = _dev(row_splits, torch.int64)
     g = _dev(gather_index, torch.int32) if gather_index is not None else None
     out = torch.empty(rs.shape[0] - 1, dtype=torch.float32, device=values.device)
-    context().call("asr_hip_reduce_subarrays_sum", ptr(values), ptr(g), ptr(rs),
+    context(_same_device(values, rs, g)).call("asr_hip_reduce_subarrays_sum", ptr(values), ptr(g), ptr(rs),
                    i64(rs.shape[0] - 1), ptr(out))
     return out
 
@@ -345,7 +370,8 @@ def decode_mlp(code, w1, b1, w2, b2, w3, voxel_sizes=None):
     sizes = _dev(voxel_sizes, torch.float32) if voxel_sizes is not None else None
     v, c = code.shape
     out = torch.empty((v, 2), dtype=torch.float32, device=code.device)
-    context().call("asr_hip_decode_mlp", ptr(code), i64(v), int(c), ptr(w1), ptr(b1),
+    dev = _same_device(code, w1, b1, w2, b2, w3, sizes)
+    context(dev).call("asr_hip_decode_mlp", ptr(code), i64(v), int(c), ptr(w1), ptr(b1),
                    int(w1.shape[0]), ptr(w2), ptr(b2), int(w2.shape[0]), ptr(w3), ptr(sizes),
                    ptr(out))
     return out

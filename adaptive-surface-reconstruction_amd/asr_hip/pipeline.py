@@ -42,15 +42,20 @@ _ARRAY_TYPES = {
 class ImplicitPipeline:
     """weights: dict state_dict-name -> tensor (names of SURVEY A.6 / UNet5.state_dict())."""
 
-    STAGES = ("octree", "grids", "aggregation_search", "continuous_conv", "unet", "decode")
+    # grids and aggregation_search overlap (two streams) unless option "overlap" is 0; geometry_wall /
+    # network_wall are the wall times of the two halves
+    STAGES = ("octree", "grids", "aggregation_search", "continuous_conv", "unet", "decode",
+              "geometry_wall", "network_wall")
 
     def __init__(self, weights, device="cuda:0", point_radius_scale=1.0, octree_max_depth=21,
                  scale_sdf=True):
         if not torch.cuda.is_available():
             raise AsrHipError("no GPU visible: the MI355X path cannot run (no CPU fallback)")
         self.device = torch.device(device)
-        torch.cuda.set_device(self.device)
-        self.ctx = Context()
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(self.device):  # the context binds to the device current at creation
+            self.ctx = Context()
         self.point_radius_scale = float(point_radius_scale)
         self.octree_max_depth = int(octree_max_depth)
         self.scale_sdf = bool(scale_sdf)
@@ -80,12 +85,17 @@ class ImplicitPipeline:
         p.scale_sdf = int(self.scale_sdf)
         return p
 
-    @staticmethod
-    def _check(points, normals, radii):
+    def _stream(self):
+        """torch's current stream ON THE PIPELINE'S DEVICE (not on whatever device is current)"""
+        self.ctx.set_stream(torch.cuda.current_stream(self.device))
+
+    def _check(self, points, normals, radii):
         for t in (points, normals, radii):
             if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and
                     t.is_contiguous()):
                 raise AsrHipError("inputs must be contiguous float32 GPU tensors")
+            if t.device != self.device:
+                raise AsrHipError("input on %s but the pipeline lives on %s" % (t.device, self.device))
         if points.ndim != 2 or points.shape[1] != 3:
             raise ValueError("points must have shape [num_points,3]")
         if normals.shape != points.shape:
@@ -99,7 +109,7 @@ class ImplicitPipeline:
         """Enqueues the whole path on torch's current stream; returns values[V0,2] (a view into
         the context arena, valid until the next forward)."""
         self._check(points, normals, radii)
-        self.ctx.set_stream(torch.cuda.current_stream())
+        self._stream()
         p = self._params(bb_min, bb_max)
         sizes = ImplicitSizes()
         self.ctx.call("asr_hip_implicit_forward", ptr(points), ptr(normals), ptr(radii),
@@ -110,7 +120,8 @@ class ImplicitPipeline:
 
     def build(self, points, radii, bb_min, bb_max):
         """geometry half only (octree, grids, aggregation neighbours)"""
-        self.ctx.set_stream(torch.cuda.current_stream())
+        self._check(points, points, radii)
+        self._stream()
         p = self._params(bb_min, bb_max)
         sizes = ImplicitSizes()
         self.ctx.call("asr_hip_implicit_build", ptr(points), ptr(radii),
@@ -120,7 +131,8 @@ class ImplicitPipeline:
 
     def network(self, points, normals, bb_min, bb_max):
         """network half on the structures of the last build()"""
-        self.ctx.set_stream(torch.cuda.current_stream())
+        self._check(points, normals, points[:, 0].contiguous())
+        self._stream()
         p = self._params(bb_min, bb_max)
         self.ctx.call("asr_hip_implicit_network", ptr(points), ptr(normals),
                       ctypes.c_int64(points.shape[0]), self._table, len(self._weights),
@@ -148,7 +160,7 @@ class ImplicitPipeline:
     def dual_cells(self):
         """dual_vertex_indices [D,8] of the octree of the last forward/build (cpp/lib/asr.cpp:154)"""
         from . import ops
-        self.ctx.set_stream(torch.cuda.current_stream())
+        self._stream()
         return ops.dual_cells(self.device, ctx=self.ctx)
 
     def mesh(self, contouring_value_threshold=1.0, keep_n_connected_components=2**63 - 1,
@@ -156,7 +168,7 @@ class ImplicitPipeline:
         """contouring + component filter on the last forward (cpp/lib/asr.cpp:338-346) ->
         (vertices f32[M,3], triangles i32[T,3]) on the GPU"""
         from . import ops
-        self.ctx.set_stream(torch.cuda.current_stream())
+        self._stream()
         if values is None:
             values = self.get("values")
         duals = ops.dual_cells(self.device, ctx=self.ctx)
@@ -164,6 +176,6 @@ class ImplicitPipeline:
         return ops.remove_components(v, t, keep_n_connected_components, minimum_component_size, ctx=self.ctx)
 
     def stage_ms(self):
-        ms = (ctypes.c_float * 6)()
+        ms = (ctypes.c_float * 8)()
         self.ctx.call("asr_hip_implicit_stage_ms", ms)
         return dict(zip(self.STAGES, [float(x) for x in ms]))

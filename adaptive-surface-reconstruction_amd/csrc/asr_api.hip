@@ -12,20 +12,33 @@
 #include "asr_common.h"
 #include "asr_uset.h"
 
-// rows are regrouped inside segments of this many consecutive rows (env ASR_ROW_SEGMENT overrides,
-// for experiments)
-static i64 asr_row_group_segment() {
-    static i64 v = [] {
-        const char* e = getenv("ASR_ROW_SEGMENT");
-        i64 x = e ? atoll(e) : 0;
-        return x > 0 ? x : (i64)524288;
-    }();
-    return v;
-}
-#define ASR_ROW_GROUP_SEGMENT asr_row_group_segment()
-#define CTX_GUARD(ctx)                      \
-    if (!(ctx)) return ASR_HIP_EINVAL;      \
-    (ctx)->err.clear();
+// rows are regrouped inside segments of this many consecutive rows (option "row_segment")
+#define ASR_ROW_GROUP_SEGMENT (ctx->opt.row_segment > 0 ? ctx->opt.row_segment : (i64)524288)
+// every entry point selects the context's device on the calling thread: a context is bound to the
+// device that was current when it was created, whatever the caller's current device is now
+#define CTX_GUARD(ctx)                                                  \
+    if (!(ctx)) return ASR_HIP_EINVAL;                                  \
+    (ctx)->err.clear();                                                 \
+    if (hipSetDevice((ctx)->device) != hipSuccess) {                    \
+        (ctx)->err = "hipSetDevice failed for the context's device";   \
+        return ASR_HIP_EHIP;                                            \
+    }
+
+namespace {
+struct OptEntry {
+    const char* name;
+    const char* env;
+    i64 AsrOptions::*field;
+};
+const OptEntry k_options[] = {
+        {"sconv_min_blocks", "ASR_SCONV_MIN_BLOCKS", &AsrOptions::sconv_min_blocks},
+        {"sconv_wide_min", "ASR_SCONV_WIDE_MIN", &AsrOptions::sconv_wide_min},
+        {"sconv_dry", "ASR_SCONV_DRY", &AsrOptions::sconv_dry},
+        {"row_segment", "ASR_ROW_SEGMENT", &AsrOptions::row_segment},
+        {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
+        {"overlap", "ASR_OVERLAP", &AsrOptions::overlap},
+};
+}  // namespace
 
 extern "C" {
 
@@ -50,7 +63,40 @@ int asr_hip_context_create(asr_hip_context** out, void* stream) {
     ctx->stream = (hipStream_t)stream;
     (void)hipGetDevice(&ctx->device);
     memset(&ctx->sizes, 0, sizeof(ctx->sizes));
+    for (const OptEntry& o : k_options)  // experiment defaults from the environment, per context
+        if (const char* e = getenv(o.env)) ctx->opt.*(o.field) = atoll(e);
     *out = ctx;
+    return ASR_HIP_OK;
+}
+int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return ASR_HIP_EINVAL;
+    for (const OptEntry& o : k_options)
+        if (!strcmp(name, o.name)) {
+            ctx->opt.*(o.field) = value;
+            if (ctx->aux) ctx->aux->opt.*(o.field) = value;
+            return ASR_HIP_OK;
+        }
+    ASR_FAIL(ctx, ASR_HIP_EINVAL, "unknown option '%s'", name);
+}
+int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value) {
+    if (!ctx || !name || !value) return ASR_HIP_EINVAL;
+    for (const OptEntry& o : k_options)
+        if (!strcmp(name, o.name)) {
+            *value = ctx->opt.*(o.field);
+            return ASR_HIP_OK;
+        }
+    ASR_FAIL(ctx, ASR_HIP_EINVAL, "unknown option '%s'", name);
+}
+int asr_hip_context_device(const asr_hip_context* ctx) { return ctx ? ctx->device : -1; }
+int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t cap, int reset) {
+    if (!ctx || (!buf && cap)) return ASR_HIP_EINVAL;
+    std::string s;
+    for (auto& kv : ctx->sconv_launches) s += kv.first + ":" + std::to_string(kv.second) + ";";
+    if (buf && cap) {
+        if (s.size() + 1 > cap) ASR_FAIL(ctx, ASR_HIP_EINVAL, "variant_counts: buffer too small (%zu needed)", s.size() + 1);
+        memcpy(buf, s.c_str(), s.size() + 1);
+    }
+    if (reset) ctx->sconv_launches.clear();
     return ASR_HIP_OK;
 }
 static void release_members(asr_hip_context* ctx) {
@@ -71,6 +117,8 @@ void asr_hip_context_destroy(asr_hip_context* ctx) {
         release_members(ctx->aux);
         if (ctx->aux_stream_owned) (void)hipStreamDestroy(ctx->aux->stream);
         if (ctx->aux_ev) (void)hipEventDestroy(ctx->aux_ev);
+        if (ctx->aux_t0) (void)hipEventDestroy(ctx->aux_t0);
+        if (ctx->aux_t1) (void)hipEventDestroy(ctx->aux_t1);
         delete ctx->aux;
     }
     release_members(ctx);
@@ -151,7 +199,7 @@ int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out, uint64_t* leav
 int asr_hip_contour_count(asr_hip_context* ctx, const float* values, int64_t num_values, const int64_t* duals,
                           int64_t num_duals, const float* positions, float threshold, int64_t* num_vertices,
                           int64_t* num_triangles) {
-    if (!ctx) return ASR_HIP_EINVAL;
+    CTX_GUARD(ctx);
     if (!num_vertices || !num_triangles || num_values < 0 || num_duals < 0 ||
         (num_duals > 0 && (!values || !duals || !positions)))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "contour_count: null argument");
@@ -159,18 +207,18 @@ int asr_hip_contour_count(asr_hip_context* ctx, const float* values, int64_t num
                                   num_triangles);
 }
 int asr_hip_contour_fill(asr_hip_context* ctx, float* vertices, int32_t* triangles) {
-    if (!ctx) return ASR_HIP_EINVAL;
+    CTX_GUARD(ctx);
     return asr_mesh_contour_fill(ctx, vertices, triangles);
 }
 int asr_hip_components_count(asr_hip_context* ctx, const float* vertices, int64_t nv, const int32_t* triangles,
                              int64_t nt, int64_t keep_n, int64_t min_size, int64_t* nv_out, int64_t* nt_out) {
-    if (!ctx) return ASR_HIP_EINVAL;
+    CTX_GUARD(ctx);
     if (!nv_out || !nt_out || nv < 0 || nt < 0 || (nv > 0 && !vertices) || (nt > 0 && !triangles))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "components_count: null argument");
     return asr_mesh_components_count(ctx, vertices, nv, triangles, nt, keep_n, min_size, nv_out, nt_out);
 }
 int asr_hip_components_fill(asr_hip_context* ctx, float* vertices_out, int32_t* triangles_out) {
-    if (!ctx) return ASR_HIP_EINVAL;
+    CTX_GUARD(ctx);
     return asr_mesh_components_fill(ctx, vertices_out, triangles_out);
 }
 int asr_density_inlier(const int64_t* counts, int64_t n, double density_percentile_threshold, uint8_t* inlier) {
@@ -351,11 +399,13 @@ int asr_hip_decode_mlp(asr_hip_context* ctx, const float* code, int64_t v, int c
 // ==========================================================================================
 namespace {
 
-__global__ void k_make_feats(const float* normals, i64 n, float* feats) {
-    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // cpp/lib/asr.cpp:168-176: feats = [nx, ny, nz, 1]
-    reinterpret_cast<float4*>(feats)[i] =
+// cpp/lib/asr.cpp:168-176: feats = [nx, ny, nz, 1], written in Morton order (sorted[s].w = original index of
+// the point at position s) so that the continuous conv reads a voxel's neighbours from adjacent rows
+__global__ void k_make_feats(const float* normals, const float4* sorted, i64 n, float* feats) {
+    i64 s = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const i64 i = __float_as_int(sorted[s].w);
+    reinterpret_cast<float4*>(feats)[s] =
             make_float4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 1.f);
 }
 
@@ -581,7 +631,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     // Aggregation neighbours (cpp/lib/asr.cpp:266-273) on the auxiliary context: its own stream, arenas,
     // counters and host thread, overlapped with the grid hierarchy below.  Both are chains of
     // latency-bound kernels with host round trips for the data-dependent sizes; neither fills the GPU.
-    static const bool overlap = !(getenv("ASR_OVERLAP") && atoi(getenv("ASR_OVERLAP")) == 0);
+    const bool overlap = ctx->opt.overlap != 0;
     asr_hip_context* sc = ctx;  // context the search runs on
     if (overlap) {
         if (!ctx->aux) {
@@ -595,6 +645,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             ASR_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->aux->stream, hipStreamNonBlocking, prio_least));
             ctx->aux_stream_owned = true;
             ASR_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
+            ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t0));
+            ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t1));
+            ctx->aux->opt = ctx->opt;
         }
         sc = ctx->aux;
         sc->persist.reset();
@@ -602,7 +655,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         sc->err.clear();
         ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));      // inputs + level-0 info are ready
         ASR_HIP_CHECK(ctx, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
+        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_t0, sc->stream));  // the search is timed on ITS stream
     }
+    ctx->search_overlapped = overlap;
     i64 agg_pairs = 0;
     auto search = [&]() -> int {
         if (sc != ctx) {
@@ -617,15 +672,19 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         ctx->agg_rs = arena_alloc<i64>(sc->persist, g0.v + 1);
         if (!ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
-                                      &agg_pairs));
+                                      &agg_pairs, &sc->persist));
         ctx->agg_idx = arena_alloc<int32_t>(sc->persist, agg_pairs);
         ctx->agg_dist = arena_alloc<float>(sc->persist, agg_pairs);
         ctx->agg_compat = arena_alloc<float>(sc->persist, agg_pairs);
-        if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat)
+        ctx->agg_spos = arena_alloc<int32_t>(sc->persist, agg_pairs);
+        if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat || !ctx->agg_spos)
             ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_geom_radius_fill(sc, points, radii, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs, ctx->agg_idx,
-                                     ctx->agg_dist, ctx->agg_compat));
-        if (sc != ctx) ASR_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
+                                     ctx->agg_dist, ctx->agg_compat, ctx->agg_spos, &ctx->agg_sorted));
+        if (sc != ctx) {
+            ASR_HIP_CHECK(sc, hipEventRecord(ctx->aux_t1, sc->stream));
+            ASR_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
+        }
         return ASR_HIP_OK;
     };
     int search_rc = ASR_HIP_OK;
@@ -717,6 +776,10 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         name_it(ctx, "aggregation_row_splits", ctx->agg_rs, 8 * (g0.v + 1));
     }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    // everything implicit_network allocates from the persist arena goes above this mark, so that
+    // repeated network() calls on one build do not grow the arena
+    arena_mark(ctx->persist, ctx->build_mark);
+    ctx->build_mark_ok = true;
     return ASR_HIP_OK;
 }
 
@@ -727,6 +790,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     if (n != ctx->sizes.num_points || ctx->sizes.num_voxels[0] == 0)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: no matching implicit_build");
     ctx->scratch.reset();
+    if (ctx->build_mark_ok) arena_rewind(ctx->persist, ctx->build_mark);
     Net net{ctx, {weights, num_weights}};
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
@@ -744,11 +808,12 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     float* imp_pairs = arena_alloc<float>(ctx->persist, P > V0 ? P : V0);
     float* feats1 = arena_alloc<float>(ctx->persist, (size_t)V0 * C0);
     if (!feats || !imp_pairs || !feats1) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_make_feats<<<grid_for(n, 256), 256, 0, ctx->stream>>>(normals, n, feats);
+    k_make_feats<<<grid_for(n, 256), 256, 0, ctx->stream>>>(normals, ctx->agg_sorted, n, feats);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(asr_conv_agg_importance(ctx, ctx->agg_compat, ctx->agg_dist, P, imp_pairs));
-    ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, points, feats, ctx->agg_idx,
-                           imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1));
+    // positions, features and pair indices all in Morton order (the search's own point order)
+    ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, (const float*)ctx->agg_sorted, feats,
+                           ctx->agg_spos, imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1, 1));
     ctx->feats1 = feats1;
     ctx->importance = imp_pairs;
     name_it(ctx, "feats1", feats1, 4 * (size_t)V0 * C0);
@@ -913,15 +978,24 @@ int asr_hip_implicit_get(asr_hip_context* ctx, const char* name, void* dst, size
                                           hipMemcpyDeviceToDevice, ctx->stream));
     return ASR_HIP_OK;
 }
-int asr_hip_implicit_stage_ms(asr_hip_context* ctx, float out_ms[6]) {
+int asr_hip_implicit_stage_ms(asr_hip_context* ctx, float out_ms[8]) {
     CTX_GUARD(ctx);
     if (!ctx->ev_ok || !out_ms) ASR_FAIL(ctx, ASR_HIP_EINVAL, "stage_ms: nothing recorded");
     ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    const int pairs[6][2] = {{0, 1}, {1, 2}, {2, 3}, {4, 5}, {5, 6}, {6, 7}};
-    for (int i = 0; i < 6; ++i) {
+    // [0] octree [1] grids [2] aggregation search [3] continuous conv [4] unet [5] decode
+    // [6] geometry wall (octree start .. search joined) [7] network wall.  With the search on the
+    // auxiliary stream (option "overlap", default) [1] and [2] run concurrently: [2] is then measured
+    // on the auxiliary stream and [0] + [1] + [2] > [6].
+    const int pairs[8][2] = {{0, 1}, {1, 2}, {2, 3}, {4, 5}, {5, 6}, {6, 7}, {0, 3}, {4, 7}};
+    for (int i = 0; i < 8; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, ctx->ev[pairs[i][0]], ctx->ev[pairs[i][1]]) != hipSuccess) ms = -1.f;
         out_ms[i] = ms;
+    }
+    if (ctx->search_overlapped && ctx->aux_t0 && ctx->aux_t1) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->aux_t0, ctx->aux_t1) != hipSuccess) ms = -1.f;
+        out_ms[2] = ms;
     }
     return ASR_HIP_OK;
 }

@@ -55,10 +55,17 @@ struct Arena {
     }
 };
 
-// mark/rewind for temporaries inside one API call
+// mark/rewind: remembers the bump pointers of an arena
 struct ArenaMark {
     std::vector<size_t> used;
 };
+static inline void arena_mark(const Arena& a, ArenaMark& m) {
+    m.used.clear();
+    for (auto& s : a.slabs) m.used.push_back(s.used);
+}
+static inline void arena_rewind(Arena& a, const ArenaMark& m) {
+    for (size_t i = 0; i < a.slabs.size(); ++i) a.slabs[i].used = i < m.used.size() ? m.used[i] : 0;
+}
 
 struct GridDev {
     i64 v = 0, p = 0;
@@ -81,9 +88,24 @@ struct GridDev {
     int32_t* perm_down = nullptr;  // rows = next coarser grid (inverted up lists)
 };
 
+// Tunables of one context (asr_hip_context_set_option); the defaults can also be seeded from the
+// environment (ASR_SCONV_MIN_BLOCKS, ...) when the context is created, for experiments.
+struct AsrOptions {
+    i64 sconv_min_blocks = 2816;  // narrow the column tile until a launch has this many blocks (11 per CU)
+    i64 sconv_wide_min = 2048;    // 8-wave (128-row) blocks when they still give this many blocks
+    i64 sconv_dry = 0;            // measurement aid: 1 = prologue + epilogue, 2 = no wave-level slot skip, 3 = prologue
+    i64 row_segment = 524288;     // rows are regrouped inside segments of this many consecutive rows
+    i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
+    i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
+};
+
 struct asr_hip_context {
     hipStream_t stream = nullptr;
     std::string err;
+    AsrOptions opt;
+    std::map<std::string, i64> sconv_launches;  // "NT,KC,IMP,WAVES,DUAL" -> launches (asr_hip_sparse_conv_variant_counts)
+    ArenaMark build_mark;                         // persist arena right after implicit_build
+    bool build_mark_ok = false;
     Arena persist;  // results that outlive a call (octree, grids, values)
     Arena scratch;  // temporaries
     // last octree
@@ -98,6 +120,8 @@ struct asr_hip_context {
     float* agg_dist = nullptr;
     float* agg_compat = nullptr;
     i64* agg_rs = nullptr;
+    int32_t* agg_spos = nullptr;         // neighbour of each aggregation pair as a position in Morton order
+    const float4* agg_sorted = nullptr;  // points in Morton order (x, y, z, original index bits)
     float* values = nullptr;
     float* feats1 = nullptr;
     float* importance = nullptr;
@@ -115,6 +139,8 @@ struct asr_hip_context {
                                     // with the grid hierarchy build (asr_api.hip implicit_build)
     bool aux_stream_owned = false;
     hipEvent_t aux_ev = nullptr;
+    hipEvent_t aux_t0 = nullptr, aux_t1 = nullptr;  // search start / end on the auxiliary stream
+    bool search_overlapped = false;
 };
 
 #define ASR_FAIL(ctx, code, ...)                         \
@@ -227,12 +253,16 @@ int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out
                           int32_t* up_idx, uint8_t* up_kidx, i64* up_rs);
 int asr_geom_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame, const u64* keys,
                         i64 v, float* centers, float* sizes);
+// keep: arena for the Morton-ordered point arrays (scratch when null); fill: spos (optional) receives
+// each pair's neighbour as a position in Morton order, sorted_out the Morton-ordered points (x, y, z,
+// original index bits) they refer to
 int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                           i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
-                          i64* num_pairs);
+                          i64* num_pairs, Arena* keep = nullptr);
 int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* radii, i64 n,
                          const float* centers, const float* sizes, i64 v, const i64* rs,
-                         int32_t* idx, float* dist, float* compat);
+                         int32_t* idx, float* dist, float* compat, int32_t* spos = nullptr,
+                         const float4** sorted_out = nullptr);
 int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                                    const float* radii, i64 n, i64* counts_out);
 int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts, i64 n, int k,
@@ -259,7 +289,7 @@ int asr_conv_agg_importance(asr_hip_context* ctx, const float* compat, const flo
 int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_pos,
                    const float* extents, const float* inp_pos, const float* inp_feat,
                    const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
-                   int cout, int normalize, const float* bias, int relu, float* out);
+                   int cout, int normalize, const float* bias, int relu, float* out, int sorted4 = 0);
 int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* args);
 int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gidx, const i64* rs,
                     i64 rows, float* out);

@@ -64,6 +64,10 @@ __device__ inline void cconv_pair_coords(float dx, float dy, float dz, float& ux
 // The trilinear weight of cell c along an axis is the hat function max(0, 1 - |u - c|), which
 // equals the (1-a, a) corner weights of linear interpolation with border clamping.
 // No memory access sits in the inner loop.
+// SORTED: inp_pos / inp_feat are float4 arrays (x, y, z, -) / (f0..f3) in Morton order and nidx holds positions in
+// that order: the neighbours of one voxel (and of the next voxels, which follow in Morton order too) share
+// cache lines, where the AoS gathers at original indices fetch one line per pair.
+template <bool SORTED>
 __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
                                    const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
                                    i64 p0, int cnt, int lane, int cin, int c0, float ox, float oy,
@@ -75,13 +79,23 @@ __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const floa
         const int32_t i = nidx[p];
         const float w = nimp ? nimp[p] : 1.f;
         norm_lane += w;
-        cconv_pair_coords((inp_pos[3 * (i64)i] - ox) * sc2, (inp_pos[3 * (i64)i + 1] - oy) * sc2,
-                          (inp_pos[3 * (i64)i + 2] - oz) * sc2, ux, uy, uz);
-        const float* f = inp_feat + (i64)i * cin + c0;
-        f0 = w * f[0];
-        if (c0 + 1 < cin) f1 = w * f[1];
-        if (c0 + 2 < cin) f2 = w * f[2];
-        if (c0 + 3 < cin) f3 = w * f[3];
+        if (SORTED) {
+            const float4 P = reinterpret_cast<const float4*>(inp_pos)[i];
+            const float4 F = reinterpret_cast<const float4*>(inp_feat)[i];
+            cconv_pair_coords((P.x - ox) * sc2, (P.y - oy) * sc2, (P.z - oz) * sc2, ux, uy, uz);
+            f0 = w * F.x;
+            f1 = w * F.y;
+            f2 = w * F.z;
+            f3 = w * F.w;
+        } else {
+            cconv_pair_coords((inp_pos[3 * (i64)i] - ox) * sc2, (inp_pos[3 * (i64)i + 1] - oy) * sc2,
+                              (inp_pos[3 * (i64)i + 2] - oz) * sc2, ux, uy, uz);
+            const float* f = inp_feat + (i64)i * cin + c0;
+            f0 = w * f[0];
+            if (c0 + 1 < cin) f1 = w * f[1];
+            if (c0 + 2 < cin) f2 = w * f[2];
+            if (c0 + 3 < cin) f3 = w * f[3];
+        }
     }
     // v_readlane with a uniform lane index: a scalar broadcast, not an LDS round trip (ds_bpermute)
 #define ASR_BCAST(x_) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_), j))
@@ -106,7 +120,7 @@ __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const floa
 // its part (broadcast B reads, contiguous W reads) and log2(64 / COUT_MAX) shuffles join the parts.
 // (A per-lane partial product followed by a 32-value reduce-scatter butterfly was measured at
 // 6.4 ms of this kernel's 9.8 ms on the 10 M cloud.)
-template <int COUT_MAX>
+template <int COUT_MAX, bool SORTED>
 __global__ __launch_bounds__(512) void k_cconv(const float* __restrict__ filters,
                                                const float* __restrict__ out_pos,
                                                const float* __restrict__ extents,
@@ -154,8 +168,8 @@ __global__ __launch_bounds__(512) void k_cconv(const float* __restrict__ filters
             const float sc2 = 2.f * (1.f / extents[q]);
             float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
             for (i64 p0 = b; p0 < e; p0 += 64)
-                cconv_batch(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane,
-                            cin, c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
+                cconv_batch<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane,
+                                    cin, c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
             s_b[wib][lane] = make_float4(B0, B1, B2, B3);
             const float norm = wave_reduce_sum(norm_lane);
             __builtin_amdgcn_wave_barrier();  // LDS ops of one wave complete in order
@@ -196,7 +210,7 @@ __global__ void k_cconv_heavy_list(const i64* rs, i64 num_out, i64 thr, int32_t*
     if (rs[q + 1] - rs[q] > thr) list[atomicAdd(count, 1)] = (int32_t)q;
 }
 
-template <int COUT_MAX>
+template <int COUT_MAX, bool SORTED>
 __global__ __launch_bounds__(1024) void k_cconv_heavy(
         const float* __restrict__ filters, const float* __restrict__ out_pos,
         const float* __restrict__ extents, const float* __restrict__ inp_pos,
@@ -219,8 +233,8 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
     for (int c0 = 0; c0 < cin; c0 += 4) {
         float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
         for (i64 p0 = b + 64 * (i64)wave; p0 < e; p0 += 64 * 16)
-            cconv_batch(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane, cin,
-                        c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
+            cconv_batch<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane, cin,
+                                c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
         const float norm = wave_reduce_sum(norm_lane);
         __syncthreads();  // previous chunk's partials consumed
         s_part[wave][lane][0] = B0;
@@ -727,8 +741,9 @@ int asr_conv_agg_importance(asr_hip_context* ctx, const float* compat, const flo
 int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_pos,
                    const float* extents, const float* inp_pos, const float* inp_feat,
                    const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
-                   int cout, int normalize, const float* bias, int relu, float* out) {
+                   int cout, int normalize, const float* bias, int relu, float* out, int sorted4) {
     if (num_out <= 0) return ASR_HIP_OK;
+    if (sorted4 && cin != 4) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: the Morton-ordered layout needs cin == 4");
     if (cout < 1 || cout > 64) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cout must be 1..64");
     if (cin < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cin must be >= 1");
     // 512-thread blocks, <= 4 per CU: 32 waves per CU hide the dependent row_splits -> index ->
@@ -743,14 +758,24 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     k_cconv_heavy_list<<<grid_for(num_out, 256), 256, 0, ctx->stream>>>(rs, num_out, CCONV_HEAVY, heavy,
                                                                       d_count);
     ASR_CHECK_LAUNCH(ctx);
-#define ASR_LAUNCH_CCONV(C_)                                                                      \
-    k_cconv<C_><<<blocks, 512, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, \
-                                                 nimp, rs, num_out, cin, cout, normalize, bias,    \
-                                                 relu, out, CCONV_HEAVY);
-#define ASR_LAUNCH_CCONV_HEAVY(C_)                                                                 \
-    k_cconv_heavy<C_><<<n_heavy, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos,        \
-                                                         inp_feat, nidx, nimp, rs, heavy, cin, cout, \
-                                                         normalize, bias, relu, out);
+#define ASR_LAUNCH_CCONV_S(C_, S_)                                                                       \
+    k_cconv<C_, S_><<<blocks, 512, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx,    \
+                                                     nimp, rs, num_out, cin, cout, normalize, bias, relu, \
+                                                     out, CCONV_HEAVY);
+#define ASR_LAUNCH_CCONV(C_)        \
+    if (sorted4)                    \
+        ASR_LAUNCH_CCONV_S(C_, true) \
+    else                            \
+        ASR_LAUNCH_CCONV_S(C_, false)
+#define ASR_LAUNCH_CCONV_HEAVY_S(C_, S_)                                                                  \
+    k_cconv_heavy<C_, S_><<<n_heavy, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, \
+                                                             nidx, nimp, rs, heavy, cin, cout, normalize,  \
+                                                             bias, relu, out);
+#define ASR_LAUNCH_CCONV_HEAVY(C_)        \
+    if (sorted4)                          \
+        ASR_LAUNCH_CCONV_HEAVY_S(C_, true) \
+    else                                  \
+        ASR_LAUNCH_CCONV_HEAVY_S(C_, false)
     if (cout <= 8)
         ASR_LAUNCH_CCONV(8)
     else if (cout <= 32)
@@ -771,6 +796,8 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     }
 #undef ASR_LAUNCH_CCONV
 #undef ASR_LAUNCH_CCONV_HEAVY
+#undef ASR_LAUNCH_CCONV_S
+#undef ASR_LAUNCH_CCONV_HEAVY_S
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }
@@ -808,25 +835,40 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     const int ctot = a.cout + (dual ? a.cout_b : 0);
     if (dual && (!imp || a.cout % 16 != 8 || a.cout_b != 8 || a.residual || (uintptr_t)a.filters_b % 16 != 0))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: second filter bank needs importance, cout %% 16 == 8, cout_b == 8");
-    static const int dry = getenv("ASR_SCONV_DRY") ? atoi(getenv("ASR_SCONV_DRY")) : 0;
+    const int dry = (int)ctx->opt.sconv_dry;
     if (dry) a.algo = dry == 2 ? 8 : (dry == 3 ? 7 : 9);
     // widest column tile that fits cout, narrowed while the launch has too few blocks to fill
     // 256 CUs (coarse grids have only a few thousand rows; the gather is then repeated per
     // column chunk, which those levels can afford).  128-row blocks (8 waves) halve the weight
     // panel traffic per MFMA and are used whenever they still give enough blocks.
+    // force_nt / force_waves (tests): pick the instance regardless of the problem size.
     int nt = ctot > 128 ? 16 : ctot > 64 ? 8 : ctot > 32 ? 4 : ctot > 16 ? 2 : 1;
     const i64 tiles64 = (a.num_out + 63) / 64;
-    static const i64 min_blocks = getenv("ASR_SCONV_MIN_BLOCKS") ? atoll(getenv("ASR_SCONV_MIN_BLOCKS")) : 2816;  // 11 blocks per CU
-    while (nt > 2 && tiles64 * ((ctot + nt * 16 - 1) / (nt * 16)) < min_blocks) nt >>= 1;
+    if (a.force_nt) {
+        if (a.force_nt != 1 && a.force_nt != 2 && a.force_nt != 4 && a.force_nt != 8 && a.force_nt != 16)
+            ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: force_nt must be 1, 2, 4, 8 or 16");
+        nt = a.force_nt;
+    } else {
+        while (nt > 2 && tiles64 * ((ctot + nt * 16 - 1) / (nt * 16)) < ctx->opt.sconv_min_blocks) nt >>= 1;
+    }
     while (dual && ctot % (nt * 16) != 0) nt >>= 1;  // bank b must be the last tile of the last column chunk
+    if (a.force_nt && nt != a.force_nt)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: force_nt %d does not divide the two-bank width %d", a.force_nt, ctot);
     const i64 tiles128 = (a.num_out + 127) / 128;
-    static const i64 wide_min = getenv("ASR_SCONV_WIDE_MIN") ? atoll(getenv("ASR_SCONV_WIDE_MIN")) : 2048;
-    const bool wide = nt >= 2 && tiles128 * ((ctot + nt * 16 - 1) / (nt * 16)) >= wide_min;
+    bool wide = nt >= 2 && tiles128 * ((ctot + nt * 16 - 1) / (nt * 16)) >= ctx->opt.sconv_wide_min;
+    if (a.force_waves) {
+        if ((a.force_waves != 4 && a.force_waves != 8) || (a.force_waves == 8 && nt < 2))
+            ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: force_waves must be 4 or 8 (8 needs nt >= 2)");
+        wide = a.force_waves == 8;
+    }
+    int kc_used = 0, waves_used = 0;
 #define ASR_LAUNCH_SCONV(NT_, KC_, W_)                                                           \
     {                                                                                            \
         const i64 tiles_ = (a.num_out + W_ * 16 - 1) / (W_ * 16);                                \
         const i64 ny_ = (ctot + NT_ * 16 - 1) / (NT_ * 16);                                      \
         dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));                   \
+        kc_used = KC_;                                                                           \
+        waves_used = W_;                                                                         \
         if (dual)                                                                                \
             k_sconv_mfma<NT_, KC_, true, W_, true><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(a, zeros); \
         else if (imp)                                                                            \
@@ -851,6 +893,11 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
         default:
             if (a.cin <= 32) ASR_LAUNCH_SCONV(1, 32, 4) else ASR_LAUNCH_SCONV(1, 64, 4)
             break;
+    }
+    {
+        char key[48];
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d", nt, kc_used, imp ? 1 : 0, waves_used, dual ? 1 : 0);
+        ++ctx->sconv_launches[key];
     }
 #undef ASR_LAUNCH_SCONV_W
 #undef ASR_LAUNCH_SCONV

@@ -432,12 +432,18 @@ __global__ void k_point_codes(asr_octree_frame f, const float* pts, i64 n, u64* 
     codes[i] = asr_morton3d((u64)x, (u64)y, (u64)z);
     ids[i] = (int32_t)i;
 }
-__global__ void k_gather_points(const float* pts, const int32_t* ids, i64 n, float4* sorted) {
+__global__ void k_gather_points(const float* pts, const int32_t* ids, i64 n, float4* sorted, int32_t* rank) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t id = ids[i];
     sorted[i] = make_float4(pts[3 * (i64)id], pts[3 * (i64)id + 1], pts[3 * (i64)id + 2],
                             __int_as_float(id));
+    if (rank) rank[id] = (int32_t)i;  // original index -> position in Morton order
+}
+// per-point radii in Morton order (the compat factor of a pair then reads next to its neighbours)
+__global__ void k_gather_radii(const float* radii, const int32_t* ids, i64 n, float* out) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = radii[ids[i]];
 }
 __device__ inline int query_level(const asr_octree_frame& f, float r) {
     int lev = 0;
@@ -570,7 +576,8 @@ __device__ inline int radius_cells(const asr_octree_frame& f, const HashTab& t, 
     return total;
 }
 // candidate i of the concatenated cell ranges
-__device__ inline float4 radius_candidate(const float4* sorted, const int* s_pref, const int* s_beg, int i) {
+__device__ inline float4 radius_candidate(const float4* sorted, const int* s_pref, const int* s_beg, int i,
+                                          int* pos_out = nullptr) {
     int lo = 0, hi = 27;  // cell c with pref[c] <= i < pref[c+1]
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -579,7 +586,9 @@ __device__ inline float4 radius_candidate(const float4* sorted, const int* s_pre
         else
             hi = mid;
     }
-    return sorted[s_beg[lo] + (i - s_pref[lo])];
+    const int pos = s_beg[lo] + (i - s_pref[lo]);  // position in Morton order
+    if (pos_out) *pos_out = pos;
+    return sorted[pos];
 }
 
 template <int MODE>
@@ -592,6 +601,7 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     __shared__ int s_pref[4][28];
     __shared__ int s_beg[4][28];
     __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
+    __shared__ int s_pos[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const i64 q = blockIdx.x * (i64)4 + wave;
     if (q == v && lane == 0) counts[v] = 0;
@@ -606,9 +616,9 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
         const int i = i0 + lane;
         bool hit = false;
         float d = 0.f;
-        int id = 0;
+        int id = 0, pos = 0;
         if (i < total) {
-            const float4 pt = radius_candidate(sorted, s_pref[wave], s_beg[wave], i);
+            const float4 pt = radius_candidate(sorted, s_pref[wave], s_beg[wave], i, &pos);
             d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
             hit = d < r2;
             id = __float_as_int(pt.w);
@@ -616,7 +626,10 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
         const unsigned long long m = __ballot(hit);
         if (MODE == 2 && hit) {
             const i64 o = found + __popcll(m & ((1ull << lane) - 1));
-            if (o < RADIUS_LIGHT) s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+            if (o < RADIUS_LIGHT) {
+                s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+                s_pos[wave][o] = pos;
+            }
         }
         found += __popcll(m);
         if (MODE == 2 && found > RADIUS_LIGHT) heavy = true;
@@ -639,11 +652,15 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     }
     __builtin_amdgcn_wave_barrier();
     const int h = (int)found;
+    // rows are ordered by (squared distance, ORIGINAL index); what is stored is (distance, position in
+    // Morton order): k_radius_place turns the position back into the index with a clustered read
     u64 mine[RADIUS_LIGHT / 64];
+    int mypos[RADIUS_LIGHT / 64];
     int rank[RADIUS_LIGHT / 64];
 #pragma unroll
     for (int u = 0; u < RADIUS_LIGHT / 64; ++u) {
         mine[u] = lane + 64 * u < h ? s_keys[wave][lane + 64 * u] : 0;
+        mypos[u] = lane + 64 * u < h ? s_pos[wave][lane + 64 * u] : 0;
         rank[u] = 0;
     }
     for (int j = 0; j < h; ++j) {  // LDS broadcast reads
@@ -653,7 +670,7 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     }
 #pragma unroll
     for (int u = 0; u < RADIUS_LIGHT / 64; ++u)
-        if (lane + 64 * u < h) tmp[q * RADIUS_LIGHT + rank[u]] = mine[u];
+        if (lane + 64 * u < h) tmp[q * RADIUS_LIGHT + rank[u]] = (mine[u] & 0xffffffff00000000ull) | (u32)mypos[u];
 }
 
 // Heavy rows: RADIUS_SPLIT blocks per row, each block walks 1/RADIUS_SPLIT of the candidates.
@@ -704,9 +721,12 @@ __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const 
     }
     if (!FILL && lane == 0 && found) atomicAdd((unsigned long long*)&counts[q], found);
 }
-// copies the light rows from their fixed slots to the CSR positions: 16 lanes per row
+// copies the light rows from their fixed slots to the CSR positions: 16 lanes per row.  The slots hold
+// (squared distance, position in Morton order); index and radius come from the Morton-ordered arrays
+// (neighbours of one voxel are close in that order: clustered reads instead of one line per pair)
 __global__ void k_radius_place(const u64* tmp, const i64* rs, const uint8_t* is_heavy, i64 v, const float* sizes,
-                               const float* radii, int32_t* idx, float* dist, float* compat) {
+                               const int32_t* ids, const float* srad, int32_t* idx, int32_t* spos, float* dist,
+                               float* compat) {
     const i64 q = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 4;
     const int l = threadIdx.x & 15;
     if (q >= v) return;
@@ -716,11 +736,12 @@ __global__ void k_radius_place(const u64* tmp, const i64* rs, const uint8_t* is_
     const float a = sizes[q];
     for (int i = l; i < cnt; i += 16) {
         const u64 k = tmp[q * RADIUS_LIGHT + i];
-        const int32_t id = (int32_t)(k & 0xffffffffu);
-        idx[b + i] = id;
+        const int32_t pos = (int32_t)(k & 0xffffffffu);
+        idx[b + i] = ids[pos];
+        if (spos) spos[b + i] = pos;
         dist[b + i] = __uint_as_float((unsigned)(k >> 32));
         if (compat) {
-            float bb = 2 * radii[id];
+            float bb = 2 * srad[pos];
             float ratio = fminf(a, bb) / fmaxf(a, bb);
             compat[b + i] = ratio * ratio;
         }
@@ -733,7 +754,7 @@ __global__ void k_heavy_counts(const int32_t* heavy, i64 nh, const i64* rs, i64*
 }
 __global__ void k_radius_unpack_heavy(const u64* keys, const int32_t* hrow, i64 num_pairs, const int32_t* heavy,
                                       const i64* hoff, const i64* rs, const float* sizes, const float* radii,
-                                      int32_t* idx, float* dist, float* compat) {
+                                      const int32_t* rank, int32_t* idx, int32_t* spos, float* dist, float* compat) {
     i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (p >= num_pairs) return;
     const int j = hrow[p];
@@ -742,6 +763,7 @@ __global__ void k_radius_unpack_heavy(const u64* keys, const int32_t* hrow, i64 
     const u64 k = keys[p];
     const int32_t id = (int32_t)(k & 0xffffffffu);
     idx[o] = id;
+    if (spos) spos[o] = rank[id];
     dist[o] = __uint_as_float((unsigned)(k >> 32));
     if (compat) {
         float a = sizes[q];
@@ -899,26 +921,71 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
             // exact.  Optional inlier vote (KDTree::ComputeInlier): neighbours among the k nearest
             // whose radius is below radius_fraction * radius_i
             if (inlier_out) {
+                // The vote is over exactly `need` neighbours, like the k results of a kNN query
+                // (nsearch.cpp:62-80): all candidates strictly closer than the k-th distance, plus as
+                // many of the candidates AT that distance as are needed to reach k, taken in ascending
+                // point index (which tie a k-d tree returns is traversal dependent; this is the
+                // deterministic rule, and the one the brute-force check in the tests uses).
                 const float thr = radii_in[__float_as_int(me.w)] * radius_fraction;
-                int votes = 0;
+                auto cand_pt = [&](int i) -> float4 {
+                    int lo = 0, hi = 27;
+                    while (hi - lo > 1) {
+                        int mid = (lo + hi) >> 1;
+                        if (s_pref[wave][mid] <= i)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    return sorted[s_beg[wave][lo] + (i - s_pref[wave][lo])];
+                };
+                int c_lt = 0, n_eq = 0, votes_lt = 0, votes_eq = 0;
                 for (int i0 = 0; i0 < total; i0 += 64) {
                     const int i = i0 + lane;
-                    bool v = false;
+                    bool lt = false, eq = false, voter = false;
                     if (i < total) {
-                        int lo = 0, hi = 27;
-                        while (hi - lo > 1) {
-                            int mid = (lo + hi) >> 1;
-                            if (s_pref[wave][mid] <= i)
-                                lo = mid;
-                            else
-                                hi = mid;
-                        }
-                        const float4 pt = sorted[s_beg[wave][lo] + (i - s_pref[wave][lo])];
-                        const float dd = sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z);
-                        v = __float_as_uint(dd) <= kth_bits && radii_in[__float_as_int(pt.w)] < thr;
+                        const float4 pt = cand_pt(i);
+                        const u32 db = __float_as_uint(sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z));
+                        lt = db < kth_bits;
+                        eq = db == kth_bits;
+                        voter = (lt || eq) && radii_in[__float_as_int(pt.w)] < thr;
                     }
-                    votes += __popcll(__ballot(v));
+                    c_lt += __popcll(__ballot(lt));
+                    n_eq += __popcll(__ballot(eq));
+                    votes_lt += __popcll(__ballot(lt && voter));
+                    votes_eq += __popcll(__ballot(eq && voter));
                 }
+                const int admit = need - c_lt;  // >= 1: the k-th neighbour itself sits at kth_bits
+                if (n_eq > admit) {
+                    // more ties than places: the `admit` smallest indices among them (bit search)
+                    u32 idx_hi = 0;  // largest t with #{ties with index < t} < admit == the admit-th smallest index
+                    for (int bit = 30; bit >= 0; --bit) {
+                        const u32 trial = idx_hi | (1u << bit);
+                        int below = 0;
+                        for (int i0 = 0; i0 < total; i0 += 64) {
+                            const int i = i0 + lane;
+                            bool b2 = false;
+                            if (i < total) {
+                                const float4 pt = cand_pt(i);
+                                b2 = __float_as_uint(sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z)) == kth_bits &&
+                                     (u32)__float_as_int(pt.w) < trial;
+                            }
+                            below += __popcll(__ballot(b2));
+                        }
+                        if (below < admit) idx_hi = trial;
+                    }
+                    votes_eq = 0;
+                    for (int i0 = 0; i0 < total; i0 += 64) {
+                        const int i = i0 + lane;
+                        bool v = false;
+                        if (i < total) {
+                            const float4 pt = cand_pt(i);
+                            v = __float_as_uint(sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z)) == kth_bits &&
+                                (u32)__float_as_int(pt.w) <= idx_hi && radii_in[__float_as_int(pt.w)] < thr;
+                        }
+                        votes_eq += __popcll(__ballot(v));
+                    }
+                }
+                const int votes = votes_lt + votes_eq;
                 if (lane == 0) inlier_out[__float_as_int(me.w)] = votes < outlier_threshold ? 1 : 0;
             }
             break;
@@ -1255,7 +1322,7 @@ int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs
     k_row_masks<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(kidx, rs, v, masks, ids);
     ASR_CHECK_LAUNCH(ctx);
     // order by (segment, mask) with two stable LSD radix sorts: by mask, then by segment id
-    static const bool lpt = !(getenv("ASR_ROW_LPT") && atoi(getenv("ASR_ROW_LPT")) == 0);
+    const bool lpt = ctx->opt.row_lpt != 0;
     int32_t* perm_m = perm_out;  // (segment, mask) order; re-ordered by chunk cost below
     if (lpt && v > 128) {
         perm_m = arena_alloc<int32_t>(ctx->scratch, v);
@@ -1340,7 +1407,9 @@ int asr_geom_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame, con
 struct RadiusState {
     bool valid = false;
     asr_octree_frame frame;
-    float4* sorted = nullptr;
+    float4* sorted = nullptr;  // points in Morton order, w = original index
+    int32_t* ids = nullptr;    // original index of the point at each Morton position
+    int32_t* rank = nullptr;   // inverse of ids (only when the caller asked for it)
     HashTab tab;
     int32_t* start = nullptr;
     int32_t* end = nullptr;
@@ -1361,24 +1430,30 @@ void asr_geom_release(asr_hip_context* ctx) {
 
 // points sorted by level-21 Morton code + hash map (cell, level) -> [start, end) for levels
 // lmin..lmax; everything lives in the scratch arena
+// `keep`: arena for the arrays that outlive the search (Morton-ordered points, ids, rank); the scratch
+// arena when null.  `want_rank`: also build the original index -> Morton position table.
 static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                             i64 n, int lmin, int lmax, RadiusState& st) {
+                             i64 n, int lmin, int lmax, RadiusState& st, Arena* keep = nullptr,
+                             bool want_rank = false) {
     int host[16];
     st.frame = *frame;
     st.n = n;
+    Arena& ka = keep ? *keep : ctx->scratch;
     u64* codes_u = arena_alloc<u64>(ctx->scratch, n + 1);
     u64* codes = arena_alloc<u64>(ctx->scratch, n + 1);
     int32_t* ids_u = arena_alloc<int32_t>(ctx->scratch, n + 1);
-    int32_t* ids = arena_alloc<int32_t>(ctx->scratch, n + 1);
-    st.sorted = arena_alloc<float4>(ctx->scratch, n + 1);
-    if (!codes_u || !codes || !ids_u || !ids || !st.sorted)
+    int32_t* ids = arena_alloc<int32_t>(ka, n + 1);
+    st.sorted = arena_alloc<float4>(ka, n + 1);
+    st.ids = ids;
+    st.rank = want_rank ? arena_alloc<int32_t>(ka, n + 1) : nullptr;
+    if (!codes_u || !codes || !ids_u || !ids || !st.sorted || (want_rank && !st.rank))
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
     if (n > 0) {
         k_point_codes<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, n, codes_u, ids_u, ctx->d_flags);
         ASR_CHECK_LAUNCH(ctx);
         ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes_u, codes, ids_u, ids, n, 63)));
-        k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted);
+        k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted, st.rank);
         ASR_CHECK_LAUNCH(ctx);
     }
     HashTab dummy{nullptr, nullptr, 0};
@@ -1419,7 +1494,7 @@ static int query_level_range(asr_hip_context* ctx, const asr_octree_frame* frame
 
 int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                           i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
-                          i64* num_pairs) {
+                          i64* num_pairs, Arena* keep) {
     ASR_TRY(ensure_flags(ctx));
     RadiusState& st = rstate(ctx);
     st.valid = false;
@@ -1433,7 +1508,7 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     st.v = v;
     int lmin, lmax;
     ASR_TRY(query_level_range(ctx, frame, sizes, v, &lmin, &lmax));
-    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st));
+    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st, keep, true));
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     st.tmp = arena_alloc<u64>(ctx->scratch, (size_t)v * RADIUS_LIGHT);
     st.heavy = arena_alloc<int32_t>(ctx->scratch, v);
@@ -1508,16 +1583,27 @@ int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const floa
 
 int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* radii, i64 n,
                          const float* centers, const float* sizes, i64 v, const i64* rs,
-                         int32_t* idx, float* dist, float* compat) {
+                         int32_t* idx, float* dist, float* compat, int32_t* spos, const float4** sorted_out) {
     RadiusState& st = rstate(ctx);
     (void)pts;
+    if (sorted_out) *sorted_out = nullptr;
     if (v <= 0) return ASR_HIP_OK;
     if (!st.valid || st.n != n || st.v != v)
         ASR_FAIL(ctx, ASR_HIP_EINVAL,
                  "asr_hip_multi_radius_search_fill must follow the matching _count call");
+    if (sorted_out) *sorted_out = st.sorted;
+    float* srad = nullptr;
+    if (compat) {
+        srad = arena_alloc<float>(ctx->scratch, n + 1);
+        if (!srad) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        if (n > 0) {
+            k_gather_radii<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(radii, st.ids, n, srad);
+            ASR_CHECK_LAUNCH(ctx);
+        }
+    }
     // light rows: already sorted in their fixed slots, copy them to the CSR positions
-    k_radius_place<<<grid_for(v * 16, BLK), BLK, 0, ctx->stream>>>(st.tmp, rs, st.is_heavy, v, sizes, radii, idx, dist,
-                                                                   compat);
+    k_radius_place<<<grid_for(v * 16, BLK), BLK, 0, ctx->stream>>>(st.tmp, rs, st.is_heavy, v, sizes, st.ids, srad, idx,
+                                                                   spos, dist, compat);
     ASR_CHECK_LAUNCH(ctx);
     const i64 nh = st.num_heavy;
     if (nh > 0) {
@@ -1551,7 +1637,7 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         ASR_TRY((sort_pairs<int32_t, u64>(ctx, ctx->scratch, t_row_s, t_row, k_s, k_u, hp, bits_for(nh + 1))));
         k_s = k_u;  // sorted keys; t_row holds the sorted rows
         k_radius_unpack_heavy<<<grid_for(hp, BLK), BLK, 0, ctx->stream>>>(k_s, t_row, hp, st.heavy, hoff, rs, sizes,
-                                                                        radii, idx, dist, compat);
+                                                                        radii, st.rank, idx, spos, dist, compat);
         ASR_CHECK_LAUNCH(ctx);
     }
     st.valid = false;

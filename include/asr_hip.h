@@ -62,6 +62,15 @@ const char* asr_hip_version(void); /* asr::GetVersionStr, cpp/lib/asr.hpp:29 */
 size_t asr_hip_struct_size(const char* name);
 /* bytes currently reserved by the arena */
 size_t asr_hip_context_reserved_bytes(const asr_hip_context* ctx);
+/* HIP device the context is bound to (the device current when it was created); every entry point
+ * selects it on the calling thread.  -1 for a null context. */
+int asr_hip_context_device(const asr_hip_context* ctx);
+/* Per-context tunables (no process-wide state).  Names: "sconv_min_blocks" (2816) and
+ * "sconv_wide_min" (2048): launch-size thresholds that pick the sparse-conv tile shape;
+ * "row_segment" (524288), "row_lpt" (1): MFMA row regrouping; "overlap" (1): aggregation search on a
+ * second stream; "sconv_dry" (0): measurement aid.  Results never depend on them. */
+int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value);
+int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value);
 
 /* ---- a3: octree frame (cpp/lib/octree.cpp:20-42), host only --------------------------- */
 int asr_octree_frame_init(asr_octree_frame* frame, const float bb_min[3], const float bb_max[3]);
@@ -227,8 +236,16 @@ typedef struct asr_sparse_conv_args {
     const float* filters_b;            /* dev [K, cin, cout_b] or NULL                       */
     const float* bias_b;               /* dev [cout_b] or NULL                               */
     int cout_b;
+    /* 0 = chosen from the problem size.  Otherwise the MFMA kernel instance is forced: column tile
+     * width force_nt * 16 (1, 2, 4, 8, 16) and force_waves * 16 rows per block (4 or 8) -- lets a
+     * small input run the instances that large inputs select (parity tests). */
+    int force_nt;
+    int force_waves;
 } asr_sparse_conv_args;
 int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* args);
+/* Launch statistics of the MFMA sparse conv since the last reset: text "NT,KC,IMP,WAVES,DUAL:count;..."
+ * (template instance k_sconv_mfma<NT,KC,IMP,WAVES,DUAL> -> number of launches), NUL terminated. */
+int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t cap, int reset);
 
 /* MFMA tiling order for asr_hip_sparse_conv_f32: reorders the rows of a CSR inside segments of
  * `segment_rows` consecutive rows (0 = default) by their set of kernel slots, so that 16-row MFMA
@@ -312,9 +329,11 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points_dev,
  * be NULL to query only. */
 int asr_hip_implicit_get(asr_hip_context* ctx, const char* name, void* dst_dev,
                          size_t* nbytes);
-/* per-stage wall times (ms, hip events) of the last forward: octree, grids, aggregation
- * search, continuous conv, unet, decode. */
-int asr_hip_implicit_stage_ms(asr_hip_context* ctx, float out_ms[6]);
+/* per-stage times (ms, hip events) of the last forward: [0] octree, [1] grids, [2] aggregation
+ * search, [3] continuous conv, [4] unet, [5] decode, [6] geometry wall (octree start .. search
+ * joined), [7] network wall.  With option "overlap" (default) the search runs on a second stream
+ * concurrently with the grids: [2] is measured on that stream and [0]+[1]+[2] exceeds [6]. */
+int asr_hip_implicit_stage_ms(asr_hip_context* ctx, float out_ms[8]);
 
 #ifdef __cplusplus
 }

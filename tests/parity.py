@@ -4,7 +4,7 @@ parity tests, smoke() and bench.py's cpu_baseline.  TEST INFRASTRUCTURE, never t
 The reference's model file cannot travel to the GPU box, so the network wiring is restated here
 following models/v0/net_definitions_torch.py (line numbers in the comments); the restatement is
 itself pinned against tests/golden/unet_*.npz, which were produced by the reference's own model
-code (tests/test_oracle_network.py).
+code (tests/test_oracle_ops.py::test_network_restatement_matches_reference_model_fixture).
 """
 import os
 import sys
@@ -18,6 +18,30 @@ for p in (REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd")):
         sys.path.insert(0, p)
 
 from oracle import oracle as O  # noqa: E402
+
+
+def assert_close(a, b, atol=1e-5, rtol=1e-5):
+    """the north_star tolerance, per element and without any magnitude scaling:
+    |a - b| <= 1e-5 + 1e-5 |b|.  Used for the implicit values and for every single operator."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b)
+    assert np.all(err <= atol + rtol * np.abs(b)), \
+        "max err %.3e (ref max %.3e)" % (err.max() if err.size else 0.0, np.abs(b).max() if b.size else 0.0)
+
+
+def assert_close_scaled(a, b, tol=1e-5):
+    """|a - b| <= 1e-5 * max(1, max|b|): ONLY for deep intermediate feature maps (`code`, the input of the
+    decoder, after 53 fp32 convolutions whose activations reach 10..40): the rounding error of such a
+    tensor is relative to the magnitude of the activations that were summed, not to the (possibly tiny)
+    element it lands on.  The values computed from it are checked with assert_close."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    err = np.abs(a - b)
+    assert np.all(err <= tol * scale), "max err %.3e (ref max %.3e)" % (err.max() if err.size else 0.0, scale)
 
 
 def oracle_geometry(points, radii, bb_min, bb_max, radius_scale=1.0, max_depth=21, timings=None):

@@ -1,0 +1,32 @@
+"""The k_sconv_mfma<NT,KC,IMP,WAVES,DUAL> template instances that `python bench.py` launches at 10 M
+points (full-width UNet5), as listed by the committed rocprofv3 kernel trace of that command.  The GPU
+parity tests force every one of them against the oracle (tests/test_gpu_sconv_variants.py)."""
+import glob
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (NT, KC, IMP, WAVES, DUAL)
+BENCH_INSTANCES = {
+    (4, 32, 1, 8, 1), (4, 32, 0, 8, 0), (8, 16, 1, 8, 1), (8, 16, 0, 8, 0), (4, 32, 1, 4, 1),
+    (4, 32, 0, 4, 0), (2, 64, 1, 4, 1), (2, 64, 0, 4, 0), (16, 16, 0, 8, 0), (2, 64, 0, 8, 0),
+    (2, 32, 0, 8, 0),
+}
+
+
+def instances_in_trace(path):
+    """set of instances named in a profiles/*_sconv_trace.csv (scripts/layer_table.py input)"""
+    out = set()
+    with open(path) as f:
+        for line in f:  # the template arguments contain commas and the file is not quoted
+            m = re.match(r"k_sconv_mfma<(\d+), (\d+), (true|false), (\d+), (true|false)>", line)
+            if m:
+                out.add((int(m.group(1)), int(m.group(2)), int(m.group(3) == "true"), int(m.group(4)),
+                         int(m.group(5) == "true")))
+    return out
+
+
+def latest_trace():
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_10m_sconv_trace.csv")))
+    return files[-1] if files else None

@@ -34,9 +34,9 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_lib.Weight) == 8 + 8 + 8 + 5 * 8
     assert ctypes.sizeof(_lib.ImplicitSizes) == 8 * (2 + 5 + 5 + 1)
     assert ctypes.sizeof(_lib.ImplicitParams) == 4 * (1 + 1 + 3 + 3 + 1)
-    assert ctypes.sizeof(_lib.SparseConvArgs) == 192
+    assert ctypes.sizeof(_lib.SparseConvArgs) == 200
     lib = _lib.load()
-    assert lib.asr_hip_struct_size(b"asr_sparse_conv_args") == 192
+    assert lib.asr_hip_struct_size(b"asr_sparse_conv_args") == 200
     assert lib.asr_hip_struct_size(b"nope") == 0
 
 
@@ -84,3 +84,19 @@ def test_no_cpu_fallback_in_product():
     if not torch.cuda.is_available():
         with pytest.raises(_lib.AsrHipError):
             _lib.Context()
+
+
+def test_bench_instance_list_matches_committed_profile():
+    """tests/sconv_instances.py (the instances the GPU parity tests force) == the k_sconv_mfma
+    instances in the newest committed 10 M-point kernel trace of bench.py"""
+    import sconv_instances as si
+    path = si.latest_trace()
+    assert path is not None
+    assert si.instances_in_trace(path) == si.BENCH_INSTANCES, path
+
+
+def test_options_without_a_gpu():
+    """set/get option validate their arguments without touching the device"""
+    lib = _lib.load()
+    assert lib.asr_hip_context_set_option(None, b"overlap", ctypes.c_int64(0)) == 1
+    assert lib.asr_hip_context_device(None) == -1

@@ -20,6 +20,13 @@ def _u64(t):
 def _cloud(kind, n, seed):
     if kind == "sphere":
         pts, nrm = synth.sphere_cloud(n, seed)
+    elif kind == "lattice":  # grid-sampled cloud: many exactly equal distances (ties at the k-th neighbour)
+        m = int(round(n ** (1 / 3)))
+        g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        g = g[np.random.default_rng(seed).permutation(len(g))]
+        pts = (g * np.float32(0.0625)).astype(np.float32)
+        nrm = np.tile(np.float32([0, 0, 1]), (len(pts), 1))
+        n = len(pts)
     else:
         p, q = synth.scan_cloud(n, seed=seed, device="cpu", density_variance=10.0 if kind == "mixed" else 1.0)
         pts, nrm = p.numpy(), q.numpy()
@@ -206,7 +213,7 @@ def test_kdtree_prefilter_queries(gpu):
     """KDTree mirror (cpp/pybind/module.cpp:455-489): exact k-th neighbour radius, inlier vote and
     radius neighbour counts vs brute force"""
     import adaptivesurfacereconstruction as asr
-    for kind, n, seed in (("scan", 6000, 5), ("mixed", 4000, 6), ("sphere", 3000, 7)):
+    for kind, n, seed in (("scan", 6000, 5), ("mixed", 4000, 6), ("sphere", 3000, 7), ("lattice", 1728, 8)):
         pts, nrm, rad, bb = _cloud(kind, n, seed)
         if kind == "sphere":
             pts[:50] = pts[50:100]  # duplicates: zero distances and ties
@@ -219,11 +226,12 @@ def test_kdtree_prefilter_queries(gpu):
         cnt = tree.compute_radius_neighbors(r24 * 1.3)
         assert cnt == O.radius_count(pts, (r24 * 1.3).astype(np.float32)).tolist()
         inl = tree.compute_inlier(r24, radius_fraction=0.9, k=24, outlier_threshold=3)
-        # brute force vote over the k nearest (squared distance <= k-th smallest)
+        # brute force vote over exactly the k nearest, ties at the k-th distance by ascending index
+        # (cpp/lib/nsearch.cpp:62-80 votes over the k results of knnSearch)
         d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2)
         d2 = (d2[..., 0] + d2[..., 1]) + d2[..., 2]
-        kth = np.sort(d2, axis=1)[:, 23]
-        votes = ((d2 <= kth[:, None]) & (r24[None, :] < (r24 * np.float32(0.9))[:, None])).sum(1)
+        order = np.argsort(d2, axis=1, kind="stable")[:, :24]  # stable: equal distances keep index order
+        votes = (r24[order] < (r24 * np.float32(0.9))[:, None]).sum(1)
         assert np.array_equal(inl, votes < 3)
     with pytest.raises(ValueError):
         asr.KDTree(pts[:, :2])

@@ -12,6 +12,10 @@ from asr_hip import synth
 pytestmark = pytest.mark.gpu
 
 
+_close = parity.assert_close
+_close_scaled = parity.assert_close_scaled
+
+
 def _prep(n, seed, gpu):
     pts, nrm = synth.scan_cloud(n, seed=seed, device=gpu)
     radii = torch.from_numpy(synth.knn_radii(pts.cpu().numpy(), 24)).to(gpu)
@@ -38,10 +42,8 @@ def test_one_million_points_vs_oracle(gpu):
     for k in ("aggregation_neighbors_index", "aggregation_neighbors_dist", "aggregation_row_splits"):
         assert np.array_equal(pipe.get(k).cpu().numpy(), ref[k]), k
     assert np.abs(pipe.get("aggregation_scale_compat").cpu().numpy() - ref["aggregation_scale_compat"]).max() <= 1e-6
-    scale = max(1.0, float(np.abs(ref["code"]).max()))
-    assert np.abs(pipe.get("code").cpu().numpy() - ref["code"]).max() <= 2e-5 * scale
-    vs = max(1.0, float(np.abs(ref["values"]).max()))
-    assert np.abs(values.cpu().numpy() - ref["values"]).max() <= 1e-5 * vs
+    _close_scaled(pipe.get("code").cpu().numpy(), ref["code"])
+    _close(values.cpu().numpy(), ref["values"])
     # contouring + component filter: bit exact vs the serial restatement on the same field
     from oracle import oracle as O
     centers = pipe.get("voxel_centers0")
@@ -55,6 +57,76 @@ def test_one_million_points_vs_oracle(gpu):
         assert np.array_equal(got_v.cpu().numpy().view(np.uint32), want_v.view(np.uint32))
         assert np.array_equal(got_t.cpu().numpy(), want_t)
     assert got_t.shape[0] > 0
+
+
+def test_one_million_points_full_width_vs_oracle(gpu):
+    """channel_div = 1 (the widths of the bench) at 1 M points: implicit values within 1e-5 of the
+    oracle, once with the launcher's own tile choice and once with 8-wave blocks everywhere (what
+    the launcher picks from ~2.5 M points on); the launch counters show which instances ran."""
+    from asr_hip.pipeline import ImplicitPipeline
+    pts, nrm, radii, bb = _prep(1_000_000, 33, gpu)
+    weights = synth.make_weights(1, seed=33)
+    ref = parity.oracle_forward(pts.cpu().numpy(), nrm.cpu().numpy(), radii.cpu().numpy(), bb[0], bb[1], weights)
+    pipe = ImplicitPipeline(weights, device=gpu)
+    seen = set()
+    for wide_min in (None, 0):
+        if wide_min is not None:
+            pipe.ctx.set_option("sconv_wide_min", wide_min)
+        pipe.ctx.sconv_variant_counts(reset=True)
+        values = pipe.forward(pts, nrm, radii, bb[0], bb[1])
+        seen |= set(pipe.ctx.sconv_variant_counts())
+        assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), ref["voxel_keys0"])
+        _close(pipe.get("feats1").cpu().numpy(), ref["feats1"])
+        _close_scaled(pipe.get("code").cpu().numpy(), ref["code"])
+        _close(values.cpu().numpy(), ref["values"])
+    from sconv_instances import BENCH_INSTANCES
+    wide = {i for i in BENCH_INSTANCES if i[3] == 8}
+    assert wide <= seen, (wide - seen, seen)
+
+
+def test_ten_million_points_single_layers_vs_oracle(gpu):
+    """C3 size: one full-width layer per grid level through the launcher's OWN tile choice at 10 M
+    points (the instances of the bench), each compared with the oracle on the same CSR."""
+    from asr_hip import ops
+    from asr_hip.pipeline import ImplicitPipeline
+    from oracle import oracle as O
+    from sconv_instances import BENCH_INSTANCES
+    pts, nrm, radii, bb = _prep(10_000_000, 1000, gpu)
+    pipe = ImplicitPipeline(synth.make_weights(4, seed=2), device=gpu)
+    pipe.build(pts, radii, bb[0], bb[1])
+    ctx = ops.context(gpu)
+    rng = np.random.default_rng(9)
+    seen = set()
+    # (level, cin, cout_a, cout_b): encblock0.conv2, encblock0.conv1a+1b, decblock0.conv2,
+    # encblock1.conv2, encblock2.conv1a+1b, decblock3.conv1, encblock4.conv2
+    for level, cin, ca, cb in ((0, 64, 64, 0), (0, 32, 56, 8), (0, 32, 32, 0), (1, 128, 128, 0), (2, 256, 248, 8),
+                               (3, 512, 256, 0), (4, 256, 256, 0)):
+        s = str(level)
+        idx, kidx, rs = (pipe.get("neighbors_index" + s), pipe.get("neighbors_kernel_index" + s),
+                         pipe.get("neighbors_row_splits" + s))
+        v = rs.numel() - 1
+        f = rng.standard_normal((v, cin)).astype(np.float32)
+        W = (rng.standard_normal((55, cin, ca)) * np.sqrt(2.0 / (8 * cin))).astype(np.float32)
+        b = (rng.standard_normal(ca) * 0.1).astype(np.float32)
+        d = lambda a: torch.from_numpy(a).to(gpu)  # noqa: E731
+        perm = ops.row_groups(kidx, rs)
+        ctx.sconv_variant_counts(reset=True)
+        hi, hk, hr = idx.cpu().numpy(), kidx.cpu().numpy(), rs.cpu().numpy()
+        if cb:
+            Wb = (rng.standard_normal((55, cin, cb)) * np.sqrt(2.0 / (8 * cin))).astype(np.float32)
+            bb_ = (rng.standard_normal(cb) * 0.1).astype(np.float32)
+            imp = rng.uniform(0.05, 1.0, size=v).astype(np.float32)
+            out = ops.sparse_conv(d(W), d(f), idx, kidx, rs, inp_importance=d(imp), normalize=True, bias=d(b),
+                                  relu=True, algo=2, row_perm=perm, filters_b=d(Wb), bias_b=d(bb_)).cpu().numpy()
+            _close(out[:, :ca], np.maximum(O.sparse_conv(W, f, hi, hk, None, hr, False) + b, 0))
+            _close(out[:, ca:], np.maximum(O.sparse_conv(Wb, f, hi, hk, imp[hi.astype(np.int64)], hr, True) + bb_, 0))
+        else:
+            out = ops.sparse_conv(d(W), d(f), idx, kidx, rs, bias=d(b), relu=True, algo=2, row_perm=perm)
+            _close(out.cpu().numpy(), np.maximum(O.sparse_conv(W, f, hi, hk, None, hr, False) + b, 0))
+        inst = set(ctx.sconv_variant_counts())
+        assert len(inst) == 1 and inst <= BENCH_INSTANCES, inst
+        seen |= inst
+    assert len(seen) >= 6, seen
 
 
 def test_ten_million_points_properties(gpu):
@@ -165,5 +237,4 @@ def test_config_c2_single_scale_cconv_one_million_uniform_points(gpu):
     imp = (rcompat * O.window_poly6(rdist)).astype(np.float32)
     out = ops.continuous_conv(d(W), centers, sizes, d(pts), d(feats), idx, d(imp), rs, True)
     ref = O.continuous_conv(W, g0["voxel_centers"], g0["voxel_sizes"], pts, feats, ridx, imp, rrs, True)
-    err = np.abs(out.cpu().numpy() - ref)
-    assert err.max() <= 1e-5 * max(1.0, float(np.abs(ref).max())), err.max()
+    _close(out.cpu().numpy(), ref)

@@ -399,13 +399,16 @@ int asr_hip_decode_mlp(asr_hip_context* ctx, const float* code, int64_t v, int c
 // ==========================================================================================
 namespace {
 
-// cpp/lib/asr.cpp:168-176: feats = [nx, ny, nz, 1], written in Morton order (sorted[s].w = original index of
-// the point at position s) so that the continuous conv reads a voxel's neighbours from adjacent rows
-__global__ void k_make_feats(const float* normals, const float4* sorted, i64 n, float* feats) {
+// cpp/lib/asr.cpp:168-176: feats = [nx, ny, nz, 1].  Written as 32-byte records {x, y, z, -, nx, ny, nz, 1} in
+// Morton order (sorted[s].w = original index of the point at position s): the continuous conv reads position
+// and features of a pair from one cache line, and the neighbours of a voxel from adjacent records
+__global__ void k_make_feats(const float* normals, const float4* sorted, i64 n, float* rec) {
     i64 s = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (s >= n) return;
-    const i64 i = __float_as_int(sorted[s].w);
-    reinterpret_cast<float4*>(feats)[s] =
+    const float4 p = sorted[s];
+    const i64 i = __float_as_int(p.w);
+    reinterpret_cast<float4*>(rec)[2 * s] = p;
+    reinterpret_cast<float4*>(rec)[2 * s + 1] =
             make_float4(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2], 1.f);
 }
 
@@ -804,7 +807,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     if (ck->shape[0] != 4 || ck->shape[1] != 4 || ck->shape[2] != 4 || ck->shape[3] != 4)
         ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "cconv_block_in.conv1.kernel must be [4,4,4,4,C]");
     const int C0 = (int)ck->shape[4];
-    float* feats = arena_alloc<float>(ctx->scratch, 4 * (size_t)n);
+    float* feats = arena_alloc<float>(ctx->scratch, 8 * (size_t)n);
     float* imp_pairs = arena_alloc<float>(ctx->persist, P > V0 ? P : V0);
     float* feats1 = arena_alloc<float>(ctx->persist, (size_t)V0 * C0);
     if (!feats || !imp_pairs || !feats1) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
@@ -812,7 +815,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(asr_conv_agg_importance(ctx, ctx->agg_compat, ctx->agg_dist, P, imp_pairs));
     // positions, features and pair indices all in Morton order (the search's own point order)
-    ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, (const float*)ctx->agg_sorted, feats,
+    ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, feats, feats,
                            ctx->agg_spos, imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1, 1));
     ctx->feats1 = feats1;
     ctx->importance = imp_pairs;

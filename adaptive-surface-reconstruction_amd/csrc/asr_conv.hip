@@ -58,21 +58,39 @@ __device__ inline void cconv_pair_coords(float dx, float dy, float dz, float& ux
     uz = fminf(fmaxf((dz + 0.5f) * 3.f, 0.f), 3.f);
 }
 
-// Accumulates pairs [p0, p0+cnt) (cnt <= 64) of one output voxel into this lane's filter cell:
-// lane j loads pair j (index, position, importance, 4 features) and computes its coordinates; the
-// wave then walks the batch with scalar broadcasts (v_readlane: the loop counter is uniform).
-// The trilinear weight of cell c along an axis is the hat function max(0, 1 - |u - c|), which
+// wave-wide sum on the DPP network (row shifts + row broadcasts), result in every lane.  __shfl_xor would
+// go through ds_bpermute: an LDS round trip and a bounds select per step.
+__device__ inline float wave_sum_dpp(float v) {
+#define ASR_DPP_ADD(ctrl_, rmask_)                                                                              \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl_, rmask_, 0xf, false));
+    ASR_DPP_ADD(0x111, 0xf)  // row_shr:1
+    ASR_DPP_ADD(0x112, 0xf)  // row_shr:2
+    ASR_DPP_ADD(0x114, 0xf)  // row_shr:4
+    ASR_DPP_ADD(0x118, 0xf)  // row_shr:8   -> lane 15 of each row holds the row sum
+    ASR_DPP_ADD(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    ASR_DPP_ADD(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef ASR_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Accumulates pairs [p0, p0+cnt) (cnt <= 64, wave uniform) of one output voxel into this lane's filter
+// cell.  Lane j loads pair j (index, position, importance, 4 features), computes its filter
+// coordinates and parks (ux, uy, uz, f0) / (f1, f2, f3, -) in the wave's LDS slab; the wave then walks the
+// batch reading each pair with two uniform-address ds_read_b128 (LDS broadcasts, issued ahead of their
+// use: they do not take VALU issue slots, where the seven v_readlane per pair of the previous version
+// were a third of the kernel's VALU instructions).
+// The trilinear weight of cell c along an axis is the hat function clamp(1 - |u - c|, 0, 1), which
 // equals the (1-a, a) corner weights of linear interpolation with border clamping.
-// No memory access sits in the inner loop.
-// SORTED: inp_pos / inp_feat are float4 arrays (x, y, z, -) / (f0..f3) in Morton order and nidx holds positions in
-// that order: the neighbours of one voxel (and of the next voxels, which follow in Morton order too) share
-// cache lines, where the AoS gathers at original indices fetch one line per pair.
+// SORTED: inp_pos is an array of 32-byte records {x, y, z, -, f0, f1, f2, f3} in Morton order (inp_feat unused) and
+// nidx holds positions in that order: the neighbours of one voxel (and of the next voxels, which follow in
+// Morton order too) share cache lines, and position + features of a pair come from ONE line, where the AoS
+// gathers at original indices fetch two lines per pair.
 template <bool SORTED>
 __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
                                    const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
                                    i64 p0, int cnt, int lane, int cin, int c0, float ox, float oy,
                                    float oz, float sc2, float cxf, float cyf, float czf, float& B0,
-                                   float& B1, float& B2, float& B3, float& norm_lane) {
+                                   float& B1, float& B2, float& B3, float& norm_lane, float4* s_pair) {
     float ux = 0.f, uy = 0.f, uz = 0.f, f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
     if (lane < cnt) {
         const i64 p = p0 + lane;
@@ -80,8 +98,8 @@ __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const floa
         const float w = nimp ? nimp[p] : 1.f;
         norm_lane += w;
         if (SORTED) {
-            const float4 P = reinterpret_cast<const float4*>(inp_pos)[i];
-            const float4 F = reinterpret_cast<const float4*>(inp_feat)[i];
+            const float4 P = reinterpret_cast<const float4*>(inp_pos)[2 * (i64)i];
+            const float4 F = reinterpret_cast<const float4*>(inp_pos)[2 * (i64)i + 1];
             cconv_pair_coords((P.x - ox) * sc2, (P.y - oy) * sc2, (P.z - oz) * sc2, ux, uy, uz);
             f0 = w * F.x;
             f1 = w * F.y;
@@ -97,19 +115,22 @@ __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const floa
             if (c0 + 3 < cin) f3 = w * f[3];
         }
     }
-    // v_readlane with a uniform lane index: a scalar broadcast, not an LDS round trip (ds_bpermute)
-#define ASR_BCAST(x_) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x_), j))
+    __builtin_amdgcn_wave_barrier();  // the previous batch's reads are done (LDS ops of a wave complete in order)
+    s_pair[2 * lane] = make_float4(ux, uy, uz, f0);
+    s_pair[2 * lane + 1] = make_float4(f1, f2, f3, 0.f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
     for (int j = 0; j < cnt; ++j) {
-        const float wx = fmaxf(0.f, 1.f - fabsf(ASR_BCAST(ux) - cxf));
-        const float wy = fmaxf(0.f, 1.f - fabsf(ASR_BCAST(uy) - cyf));
-        const float wz = fmaxf(0.f, 1.f - fabsf(ASR_BCAST(uz) - czf));
+        const float4 a = s_pair[2 * j], b = s_pair[2 * j + 1];
+        const float wx = fminf(fmaxf(1.f - fabsf(a.x - cxf), 0.f), 1.f);
+        const float wy = fminf(fmaxf(1.f - fabsf(a.y - cyf), 0.f), 1.f);
+        const float wz = fminf(fmaxf(1.f - fabsf(a.z - czf), 0.f), 1.f);
         const float wt = wx * wy * wz;
-        B0 += wt * ASR_BCAST(f0);
-        B1 += wt * ASR_BCAST(f1);
-        B2 += wt * ASR_BCAST(f2);
-        B3 += wt * ASR_BCAST(f3);
+        B0 += wt * a.w;
+        B1 += wt * b.x;
+        B2 += wt * b.y;
+        B3 += wt * b.z;
     }
-#undef ASR_BCAST
 }
 
 // One wave per output voxel, persistent blocks (grid-stride over voxels).  The 4-channel slice
@@ -121,7 +142,7 @@ __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const floa
 // (A per-lane partial product followed by a 32-value reduce-scatter butterfly was measured at
 // 6.4 ms of this kernel's 9.8 ms on the 10 M cloud.)
 template <int COUT_MAX, bool SORTED>
-__global__ __launch_bounds__(512) void k_cconv(const float* __restrict__ filters,
+__global__ __launch_bounds__(1024, 8) void k_cconv(const float* __restrict__ filters,
                                                const float* __restrict__ out_pos,
                                                const float* __restrict__ extents,
                                                const float* __restrict__ inp_pos,
@@ -135,7 +156,8 @@ __global__ __launch_bounds__(512) void k_cconv(const float* __restrict__ filters
     constexpr int PARTS = 64 / COUT_MAX;      // lane = (part, o)
     constexpr int CELLS = 64 / PARTS;         // cells summed by one lane
     __shared__ __attribute__((aligned(16))) float4 s_f[64 * COUT_MAX];  // [cell][o] -> 4 channels
-    __shared__ __attribute__((aligned(16))) float4 s_b[8][64];           // per wave: B[cell]
+    __shared__ __attribute__((aligned(16))) float4 s_b[16][64];          // per wave: B[cell]
+    __shared__ __attribute__((aligned(16))) float4 s_pair[16][128];      // per wave: the current batch of pairs
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const float cxf = (float)(lane & 3), cyf = (float)((lane >> 2) & 3), czf = (float)(lane >> 4);
     const i64 wave0 = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
@@ -156,7 +178,11 @@ __global__ __launch_bounds__(512) void k_cconv(const float* __restrict__ filters
         }
         __syncthreads();
         for (i64 q = wave0; q < num_out; q += nwaves) {
-            const i64 b = rs[q], e = rs[q + 1];
+            // q is wave uniform: row bounds through scalar registers, so that the pair loop is a scalar loop
+            const i64 b = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(rs[q] >> 32)) << 32) |
+                                (u32)__builtin_amdgcn_readfirstlane((int)rs[q]));
+            const i64 e = (i64)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(rs[q + 1] >> 32)) << 32) |
+                                (u32)__builtin_amdgcn_readfirstlane((int)rs[q + 1]));
             if (e - b > heavy_rows) continue;  // long rows go to k_cconv_heavy (16 waves per row)
             float* orow = out + q * cout;
             if (e == b) {
@@ -169,9 +195,10 @@ __global__ __launch_bounds__(512) void k_cconv(const float* __restrict__ filters
             float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
             for (i64 p0 = b; p0 < e; p0 += 64)
                 cconv_batch<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane,
-                                    cin, c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
+                                    cin, c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane,
+                                    s_pair[wib]);
             s_b[wib][lane] = make_float4(B0, B1, B2, B3);
-            const float norm = wave_reduce_sum(norm_lane);
+            const float norm = wave_sum_dpp(norm_lane);
             __builtin_amdgcn_wave_barrier();  // LDS ops of one wave complete in order
             float r = 0.f;
 #pragma unroll 8
@@ -216,72 +243,79 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
         const float* __restrict__ extents, const float* __restrict__ inp_pos,
         const float* __restrict__ inp_feat, const int32_t* __restrict__ nidx,
         const float* __restrict__ nimp, const i64* __restrict__ rs, const int32_t* __restrict__ list,
-        int cin, int cout, int normalize, const float* __restrict__ bias, int relu,
-        float* __restrict__ out) {
+        const int* __restrict__ list_count, int cin, int cout, int normalize, const float* __restrict__ bias,
+        int relu, float* __restrict__ out) {
     __shared__ float s_part[16][64][4];
     __shared__ float s_norm[16];
+    __shared__ __attribute__((aligned(16))) float4 s_pair[16][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 q = list[blockIdx.x];
     const float cxf = (float)(lane & 3), cyf = (float)((lane >> 2) & 3), czf = (float)(lane >> 4);
-    const i64 b = rs[q], e = rs[q + 1];
-    const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
-    const float sc2 = 2.f * (1.f / extents[q]);
-    float acc[COUT_MAX];
-#pragma unroll
-    for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
-    float norm_total = 0.f;
-    for (int c0 = 0; c0 < cin; c0 += 4) {
-        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
-        for (i64 p0 = b + 64 * (i64)wave; p0 < e; p0 += 64 * 16)
-            cconv_batch<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane, cin,
-                                c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane);
-        const float norm = wave_reduce_sum(norm_lane);
-        __syncthreads();  // previous chunk's partials consumed
-        s_part[wave][lane][0] = B0;
-        s_part[wave][lane][1] = B1;
-        s_part[wave][lane][2] = B2;
-        s_part[wave][lane][3] = B3;
-        if (lane == 0) s_norm[wave] = norm;
-        __syncthreads();
-        if (wave == 0) {
-            B0 = B1 = B2 = B3 = 0.f;
-            float nt = 0.f;
-            for (int w2 = 0; w2 < 16; ++w2) {
-                B0 += s_part[w2][lane][0];
-                B1 += s_part[w2][lane][1];
-                B2 += s_part[w2][lane][2];
-                B3 += s_part[w2][lane][3];
-                nt += s_norm[w2];
-            }
-            if (c0 == 0) norm_total = nt;
-            const float* wrow = filters + ((i64)lane * cin + c0) * cout;
-#pragma unroll
-            for (int o = 0; o < COUT_MAX; ++o) {
-                if (o < cout) {
-                    float s = wrow[o] * B0;
-                    if (c0 + 1 < cin) s += wrow[cout + o] * B1;
-                    if (c0 + 2 < cin) s += wrow[2 * cout + o] * B2;
-                    if (c0 + 3 < cin) s += wrow[3 * cout + o] * B3;
-                    acc[o] += s;
+    // the number of long rows stays on the device (no host round trip in the middle of the network):
+    // a fixed grid strides over the list
+    const int n_list = *list_count;
+    for (int li = blockIdx.x; li < n_list; li += gridDim.x) {
+        __syncthreads();  // the previous row's LDS partials are consumed
+        const i64 q = list[li];
+        const i64 b = rs[q], e = rs[q + 1];
+        const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
+        const float sc2 = 2.f * (1.f / extents[q]);
+        float acc[COUT_MAX];
+    #pragma unroll
+        for (int o = 0; o < COUT_MAX; ++o) acc[o] = 0.f;
+        float norm_total = 0.f;
+        for (int c0 = 0; c0 < cin; c0 += 4) {
+            float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
+            for (i64 p0 = b + 64 * (i64)wave; p0 < e; p0 += 64 * 16)
+                cconv_batch<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane, cin,
+                                    c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane, s_pair[wave]);
+            const float norm = wave_sum_dpp(norm_lane);
+            __syncthreads();  // previous chunk's partials consumed
+            s_part[wave][lane][0] = B0;
+            s_part[wave][lane][1] = B1;
+            s_part[wave][lane][2] = B2;
+            s_part[wave][lane][3] = B3;
+            if (lane == 0) s_norm[wave] = norm;
+            __syncthreads();
+            if (wave == 0) {
+                B0 = B1 = B2 = B3 = 0.f;
+                float nt = 0.f;
+                for (int w2 = 0; w2 < 16; ++w2) {
+                    B0 += s_part[w2][lane][0];
+                    B1 += s_part[w2][lane][1];
+                    B2 += s_part[w2][lane][2];
+                    B3 += s_part[w2][lane][3];
+                    nt += s_norm[w2];
+                }
+                if (c0 == 0) norm_total = nt;
+                const float* wrow = filters + ((i64)lane * cin + c0) * cout;
+    #pragma unroll
+                for (int o = 0; o < COUT_MAX; ++o) {
+                    if (o < cout) {
+                        float s = wrow[o] * B0;
+                        if (c0 + 1 < cin) s += wrow[cout + o] * B1;
+                        if (c0 + 2 < cin) s += wrow[2 * cout + o] * B2;
+                        if (c0 + 3 < cin) s += wrow[3 * cout + o] * B3;
+                        acc[o] += s;
+                    }
                 }
             }
         }
-    }
-    if (wave != 0) return;
-    float mine = 0.f;
-#pragma unroll
-    for (int o = 0; o < COUT_MAX; ++o) {
-        if (o < cout) {
-            float s = wave_reduce_sum(acc[o]);
-            if (lane == o) mine = s;
+        if (wave != 0) continue;
+        float mine = 0.f;
+    #pragma unroll
+        for (int o = 0; o < COUT_MAX; ++o) {
+            if (o < cout) {
+                float s = wave_reduce_sum(acc[o]);
+                if (lane == o) mine = s;
+            }
         }
-    }
-    if (lane < cout) {
-        float r = mine;
-        if (normalize && norm_total != 0.f) r = r / norm_total;
-        if (bias) r += bias[lane];
-        if (relu) r = fmaxf(r, 0.f);
-        out[q * cout + lane] = r;
+        if (lane < cout) {
+            float r = mine;
+            if (normalize && norm_total != 0.f) r = r / norm_total;
+            if (bias) r += bias[lane];
+            if (relu) r = fmaxf(r, 0.f);
+            out[q * cout + lane] = r;
+        }
     }
 }
 
@@ -746,10 +780,10 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     if (sorted4 && cin != 4) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: the Morton-ordered layout needs cin == 4");
     if (cout < 1 || cout > 64) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cout must be 1..64");
     if (cin < 1) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cin must be >= 1");
-    // 512-thread blocks, <= 4 per CU: 32 waves per CU hide the dependent row_splits -> index ->
-    // position load chain of every voxel
-    unsigned blocks = grid_for(num_out * 64, 512);
-    if (blocks > 256 * 4) blocks = 256 * 4;  // persistent: the filter slice is staged once per block
+    // 1024-thread blocks (80 KB of LDS: filter slice + per-wave slabs), 2 per CU: 32 waves per CU hide the
+    // dependent row_splits -> index -> position load chain of every voxel
+    unsigned blocks = grid_for(num_out * 64, 1024);
+    if (blocks > 256 * 2) blocks = 256 * 2;  // persistent: the filter slice is staged once per block
     // long rows: collect, then one 1024-thread block per row
     int32_t* heavy = arena_alloc<int32_t>(ctx->scratch, (size_t)num_out);
     int* d_count = arena_alloc<int>(ctx->scratch, 4);
@@ -759,7 +793,7 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
                                                                       d_count);
     ASR_CHECK_LAUNCH(ctx);
 #define ASR_LAUNCH_CCONV_S(C_, S_)                                                                       \
-    k_cconv<C_, S_><<<blocks, 512, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx,    \
+    k_cconv<C_, S_><<<blocks, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx,   \
                                                      nimp, rs, num_out, cin, cout, normalize, bias, relu, \
                                                      out, CCONV_HEAVY);
 #define ASR_LAUNCH_CCONV(C_)        \
@@ -768,9 +802,9 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     else                            \
         ASR_LAUNCH_CCONV_S(C_, false)
 #define ASR_LAUNCH_CCONV_HEAVY_S(C_, S_)                                                                  \
-    k_cconv_heavy<C_, S_><<<n_heavy, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, \
-                                                             nidx, nimp, rs, heavy, cin, cout, normalize,  \
-                                                             bias, relu, out);
+    k_cconv_heavy<C_, S_><<<512, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, \
+                                                         nimp, rs, heavy, d_count, cin, cout, normalize,   \
+                                                         bias, relu, out);
 #define ASR_LAUNCH_CCONV_HEAVY(C_)        \
     if (sorted4)                          \
         ASR_LAUNCH_CCONV_HEAVY_S(C_, true) \
@@ -783,17 +817,12 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     else
         ASR_LAUNCH_CCONV(64)
     ASR_CHECK_LAUNCH(ctx);
-    int n_heavy = 0;
-    ASR_HIP_CHECK(ctx, hipMemcpyAsync(&n_heavy, d_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (n_heavy > 0) {
-        if (cout <= 8)
-            ASR_LAUNCH_CCONV_HEAVY(8)
-        else if (cout <= 32)
-            ASR_LAUNCH_CCONV_HEAVY(32)
-        else
-            ASR_LAUNCH_CCONV_HEAVY(64)
-    }
+    if (cout <= 8)
+        ASR_LAUNCH_CCONV_HEAVY(8)
+    else if (cout <= 32)
+        ASR_LAUNCH_CCONV_HEAVY(32)
+    else
+        ASR_LAUNCH_CCONV_HEAVY(64)
 #undef ASR_LAUNCH_CCONV
 #undef ASR_LAUNCH_CCONV_HEAVY
 #undef ASR_LAUNCH_CCONV_S

@@ -605,18 +605,20 @@ static void radius_search(Oracle& o, const float* pts, i64 n, const float* radii
 // ---------------------------------------------------------------------------------
 // A.1 continuous_conv: align_corners, linear, ball_to_cube_radial, normalize, per-output
 // extent, per-neighbour importance; filters [4,4,4,Cin,Cout] indexed [z][y][x].
-static void cconv(const float* filters, const float* out_pos, const float* extents,
+template <class Acc>
+static void cconv_t(const float* filters, const float* out_pos, const float* extents,
                   const float* inp_pos, const float* inp_feat, const int32_t* nidx,
                   const float* nimp, const i64* rs, i64 v, int cin, int cout, int normalize,
                   float* out) {
     const int S = 4;
 #pragma omp parallel
     {
-        std::vector<float> B(size_t(64) * cin);
+        std::vector<Acc> B(size_t(64) * cin);
+        std::vector<Acc> acc((size_t)cout);
 #pragma omp for schedule(dynamic, 256)
         for (i64 q = 0; q < v; ++q) {
-            std::fill(B.begin(), B.end(), 0.f);
-            float norm = 0.f;
+            std::fill(B.begin(), B.end(), Acc(0));
+            Acc norm = 0;
             float inv_e = 1.f / extents[q];
             for (i64 p = rs[q]; p < rs[q + 1]; ++p) {
                 int32_t i = nidx[p];
@@ -650,47 +652,78 @@ static void cconv(const float* filters, const float* out_pos, const float* exten
                     float wt = ((c & 1) ? a[0] : 1.f - a[0]) * ((c & 2) ? a[1] : 1.f - a[1]) *
                                ((c & 4) ? a[2] : 1.f - a[2]);
                     int cell = (zi * S + yi) * S + xi;
-                    float* b = &B[size_t(cell) * cin];
-                    for (int ic = 0; ic < cin; ++ic) b[ic] += wt * (w * inp_feat[i64(i) * cin + ic]);
+                    Acc* b = &B[size_t(cell) * cin];
+                    for (int ic = 0; ic < cin; ++ic) b[ic] += (Acc)wt * ((Acc)w * (Acc)inp_feat[i64(i) * cin + ic]);
                 }
             }
             float* o = out + q * cout;
-            for (int oc = 0; oc < cout; ++oc) o[oc] = 0.f;
+            for (int oc = 0; oc < cout; ++oc) acc[oc] = 0;
             for (int kc = 0; kc < 64 * cin; ++kc) {
-                float b = B[kc];
-                if (b == 0.f) continue;
+                Acc b = B[kc];
+                if (b == 0) continue;
                 const float* w = filters + size_t(kc) * cout;
-                for (int oc = 0; oc < cout; ++oc) o[oc] += w[oc] * b;
+                for (int oc = 0; oc < cout; ++oc) acc[oc] += (Acc)w[oc] * b;
             }
-            if (normalize && norm != 0.f)
-                for (int oc = 0; oc < cout; ++oc) o[oc] /= norm;
+            if (normalize && norm != 0)
+                for (int oc = 0; oc < cout; ++oc) acc[oc] /= norm;
+            for (int oc = 0; oc < cout; ++oc) o[oc] = (float)acc[oc];
         }
     }
 }
 
-// A.2 sparse_conv: filters [K,Cin,Cout]
+static int& precise_flag();
+static void cconv(const float* filters, const float* out_pos, const float* extents,
+                  const float* inp_pos, const float* inp_feat, const int32_t* nidx,
+                  const float* nimp, const i64* rs, i64 v, int cin, int cout, int normalize,
+                  float* out) {
+    if (precise_flag())
+        cconv_t<double>(filters, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs, v, cin, cout, normalize, out);
+    else
+        cconv_t<float>(filters, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs, v, cin, cout, normalize, out);
+}
+
+// A.2 sparse_conv: filters [K,Cin,Cout].  Acc = float: fp32 accumulation in pair order (what an fp32
+// implementation computes); Acc = double ("precise" mode): the same sums accumulated in double and
+// rounded once -- the value every fp32 summation order approximates, used as the checker where a
+// max-norm over 10^6+ outputs of a 53-layer network would otherwise measure the ORACLE's own rounding.
+template <class Acc>
+static void sparse_conv_t(const float* filters, const float* feat, i64 feat_ld, const int32_t* nidx,
+                          const uint8_t* nk, const float* nimp, const i64* rs, i64 v, int cin,
+                          int cout, int normalize, float* out, i64 out_ld) {
+#pragma omp parallel
+    {
+        std::vector<Acc> acc((size_t)cout);
+#pragma omp for schedule(dynamic, 128)
+        for (i64 q = 0; q < v; ++q) {
+            float* o = out + q * out_ld;
+            for (int oc = 0; oc < cout; ++oc) acc[oc] = 0;
+            Acc norm = 0;
+            for (i64 p = rs[q]; p < rs[q + 1]; ++p) {
+                float w = nimp ? nimp[p] : 1.f;
+                norm += w;
+                const float* f = feat + i64(nidx[p]) * feat_ld;
+                const float* W = filters + size_t(nk[p]) * cin * cout;
+                for (int ic = 0; ic < cin; ++ic) {
+                    Acc a = (Acc)w * (Acc)f[ic];
+                    const float* wr = W + size_t(ic) * cout;
+                    for (int oc = 0; oc < cout; ++oc) acc[oc] += (Acc)wr[oc] * a;
+                }
+            }
+            if (normalize && norm != 0)
+                for (int oc = 0; oc < cout; ++oc) acc[oc] /= norm;
+            for (int oc = 0; oc < cout; ++oc) o[oc] = (float)acc[oc];
+        }
+    }
+}
+static int g_precise = 0;
+static int& precise_flag() { return g_precise; }
 static void sparse_conv(const float* filters, const float* feat, i64 feat_ld, const int32_t* nidx,
                         const uint8_t* nk, const float* nimp, const i64* rs, i64 v, int cin,
                         int cout, int normalize, float* out, i64 out_ld) {
-#pragma omp parallel for schedule(dynamic, 128)
-    for (i64 q = 0; q < v; ++q) {
-        float* o = out + q * out_ld;
-        for (int oc = 0; oc < cout; ++oc) o[oc] = 0.f;
-        float norm = 0.f;
-        for (i64 p = rs[q]; p < rs[q + 1]; ++p) {
-            float w = nimp ? nimp[p] : 1.f;
-            norm += w;
-            const float* f = feat + i64(nidx[p]) * feat_ld;
-            const float* W = filters + size_t(nk[p]) * cin * cout;
-            for (int ic = 0; ic < cin; ++ic) {
-                float a = w * f[ic];
-                const float* wr = W + size_t(ic) * cout;
-                for (int oc = 0; oc < cout; ++oc) o[oc] += wr[oc] * a;
-            }
-        }
-        if (normalize && norm != 0.f)
-            for (int oc = 0; oc < cout; ++oc) o[oc] /= norm;
-    }
+    if (g_precise)
+        sparse_conv_t<double>(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
+    else
+        sparse_conv_t<float>(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
 }
 
 
@@ -970,7 +1003,41 @@ static void remove_components(Mesh& m, i64 keep_n, i64 min_size) {
 // ---------------------------------------------------------------------------------
 // C API
 // ---------------------------------------------------------------------------------
+template <class Acc>
+static void decode_t(const float* code, i64 v, int c, const float* w1, const float* b1, int h1,
+                const float* w2, const float* b2, int h2, const float* w3, const float* sizes,
+                float* out) {
+#pragma omp parallel for
+    for (i64 q = 0; q < v; ++q) {
+        std::vector<Acc> f1(h1), f2(h2);
+        for (int j = 0; j < h1; ++j) {
+            Acc s = 0;  // torch Linear: x @ W^T + b, W [h1, 3+c]; shifts are zero
+            const float* w = w1 + size_t(j) * (3 + c);
+            for (int k = 0; k < c; ++k) s += (Acc)code[q * c + k] * (Acc)w[3 + k];
+            s += b1[j];
+            f1[j] = s > 0 ? s : Acc(0);
+        }
+        for (int j = 0; j < h2; ++j) {
+            Acc s = 0;
+            const float* w = w2 + size_t(j) * h1;
+            for (int k = 0; k < h1; ++k) s += f1[k] * (Acc)w[k];
+            s += b2[j];
+            f2[j] = s > 0 ? s : Acc(0);
+        }
+        for (int j = 0; j < 2; ++j) {
+            Acc s = 0;
+            const float* w = w3 + size_t(j) * h2;
+            for (int k = 0; k < h2; ++k) s += f2[k] * (Acc)w[k];
+            out[q * 2 + j] = (float)s;
+        }
+        if (sizes) out[q * 2] *= sizes[q];
+    }
+}
+
 extern "C" {
+// 1: the floating point ops accumulate in double (see sparse_conv_t); 0 (default): fp32 throughout
+void orc_set_precise(int on) { g_precise = on; }
+int orc_get_precise() { return g_precise; }
 
 Oracle* orc_create() { return new Oracle(); }
 void orc_destroy(Oracle* o) { delete o; }
@@ -1151,31 +1218,10 @@ void orc_invert_neighbors_list(i64 num_points, const int32_t* idx, const i64* rs
 void orc_decode(const float* code, i64 v, int c, const float* w1, const float* b1, int h1,
                 const float* w2, const float* b2, int h2, const float* w3, const float* sizes,
                 float* out) {
-#pragma omp parallel for
-    for (i64 q = 0; q < v; ++q) {
-        std::vector<float> f1(h1), f2(h2);
-        for (int j = 0; j < h1; ++j) {
-            float s = 0.f;  // torch Linear: x @ W^T + b, W [h1, 3+c]; shifts are zero
-            const float* w = w1 + size_t(j) * (3 + c);
-            for (int k = 0; k < c; ++k) s += code[q * c + k] * w[3 + k];
-            s += b1[j];
-            f1[j] = s > 0.f ? s : 0.f;
-        }
-        for (int j = 0; j < h2; ++j) {
-            float s = 0.f;
-            const float* w = w2 + size_t(j) * h1;
-            for (int k = 0; k < h1; ++k) s += f1[k] * w[k];
-            s += b2[j];
-            f2[j] = s > 0.f ? s : 0.f;
-        }
-        for (int j = 0; j < 2; ++j) {
-            float s = 0.f;
-            const float* w = w3 + size_t(j) * h2;
-            for (int k = 0; k < h2; ++k) s += f2[k] * w[k];
-            out[q * 2 + j] = s;
-        }
-        if (sizes) out[q * 2] *= sizes[q];
-    }
+    if (g_precise)
+        decode_t<double>(code, v, c, w1, b1, h1, w2, b2, h2, w3, sizes, out);
+    else
+        decode_t<float>(code, v, c, w1, b1, h1, w2, b2, h2, w3, sizes, out);
 }
 // contouring + component filter; results are kept in a per-thread mesh until fetched
 static thread_local contour::Mesh g_mesh;

@@ -185,6 +185,22 @@ class Oracle:
         return idx, dist, rs, compat
 
 
+class precise:
+    """context manager: the floating point ops (continuous_conv, sparse_conv, decode) accumulate in
+    double and round once -- the value every fp32 summation order approximates.  Checker for the
+    large-cloud parity tests, where the max-norm over 10^6 outputs would otherwise also measure the
+    rounding of the ORACLE's own fp32 pair-order sums."""
+
+    def __enter__(self):
+        self._old = lib().orc_get_precise()
+        lib().orc_set_precise(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_precise(self._old)
+        return False
+
+
 # ---- Open3D ops (SURVEY Appendix A) ------------------------------------------------------
 def continuous_conv(filters, out_positions, extents, inp_positions, inp_features, neighbors_index,
                     neighbors_importance, neighbors_row_splits, normalize=True):

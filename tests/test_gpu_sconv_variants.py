@@ -184,7 +184,8 @@ def test_whole_path_full_width_with_bench_tile_shapes(gpu, opts, expect):
     rad = synth.knn_radii(pts, 24)
     bb = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(channel_div=1, seed=4)
-    ref = parity.oracle_forward(pts, nrm, rad, bb[0], bb[1], weights)
+    with O.precise():
+        ref = parity.oracle_forward(pts, nrm, rad, bb[0], bb[1], weights)
     pipe = ImplicitPipeline(weights, device=gpu)
     for k, val in opts.items():
         pipe.ctx.set_option(k, val)

@@ -265,10 +265,12 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
                 neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False,
                 residual=None, out=None, return_importance=False, algo=0,
                 neighbors_importance=None, row_perm=None, filters_b=None, bias_b=None, force_nt=0,
-                force_waves=0):
+                force_waves=0, num_rows=None):
     """SpecialSparseConv.forward (models/common_torch.py:95-148) in one launch.  filters_b / bias_b:
     optional second filter bank (conv1a + conv1b of a SparseConvBlock in one pass): output columns
-    [cout, cout + cout_b); importance, normalize and the returned importance sum then belong to bank b."""
+    [cout, cout + cout_b); importance, normalize and the returned importance sum then belong to bank b.
+    num_rows (with row_perm): compute only the rows row_perm[:num_rows] -- a rank of a sharded run computes the
+    rows it owns and leaves the other rows of `out` untouched."""
     filters = _dev(filters, torch.float32)
     K, cin, cout = filters.shape
     inp_features = _dev(inp_features, torch.float32)
@@ -299,7 +301,12 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     a.neighbors_index = nidx.data_ptr()
     a.neighbors_kernel_index = nk.data_ptr()
     a.neighbors_row_splits = rs.data_ptr()
-    a.num_out = v
+    if num_rows is not None:
+        if row_perm is None or not 0 <= int(num_rows) <= row_perm.shape[0]:
+            raise RuntimeError("sparse_conv: num_rows needs a row_perm with at least that many rows")
+        a.num_out = int(num_rows)
+    else:
+        a.num_out = v
     a.num_inp = inp_features.shape[0]
     a.kernel_size = K
     a.cin = cin

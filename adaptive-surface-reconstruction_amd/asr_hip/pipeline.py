@@ -32,6 +32,9 @@ _ARRAY_TYPES = {
     "down_neighbors_index": (torch.int32, 0),
     "down_neighbors_kernel_index": (torch.uint8, 0),
     "down_neighbors_row_splits": (torch.int64, 0),
+    "tiling": (torch.int32, 0),
+    "tiling_up": (torch.int32, 0),
+    "tiling_down": (torch.int32, 0),
     "aggregation_neighbors_index": (torch.int32, 0),
     "aggregation_neighbors_dist": (torch.float32, 0),
     "aggregation_row_splits": (torch.int64, 0),

@@ -1,0 +1,362 @@
+"""One scan across the GPUs of a node (BASELINE config C4): spatial sharding of the
+network half of the hot path with halo exchange of boundary feature rows.
+
+The reference has no multi-device path at all (cpp/lib/asr.cpp:161-163 creates CPU tensors); what
+defines the halo is the stencil of its operators: one face ring per 55-slot convolution on the same /
+child / parent level (cpp/lib/grid.cpp:99-170) and the parent <-> children coupling of the transitions
+(cpp/lib/grid.cpp:206-242).
+
+Scheme (one process per GPU, torch.distributed; backend "nccl" = RCCL over xGMI):
+  * the octree and the five grids are built on every rank (integer work, ~15 % of a 10 M-point step) so
+    that every rank can derive ownership and all send / receive lists locally, without any negotiation;
+  * grid-0 voxels are cut into `world` contiguous ranges of the Morton order of their cells (location
+    codes sort level-major, so the keys are first normalised to level 21) with equal numbers of
+    neighbour pairs; a coarser voxel belongs to the owner of its first child (carried voxels keep their
+    owner), so every level is partitioned by the same space-filling curve;
+  * a rank computes only the rows it owns: aggregation search + continuous conv for its grid-0 voxels,
+    every sparse conv through the kernel's row list (asr_sparse_conv_args.row_perm / num_out), the
+    decoder for its voxels.  Activations live in full-size buffers addressed by global row index;
+  * before a convolution reads a buffer, the rows of that buffer that the rank's output rows reference
+    but other ranks own (the halo, a few thousand boundary voxels) are exchanged point to point
+    (batched isend / irecv: RCCL grouped send/recv) -- per convolution, no redundant ring compute;
+  * the per-rank values are stitched with one all-reduce of a zero-initialised [V0, 2] array.
+Every row is computed by the same kernel from the same inputs in the same summation order as on one
+GPU, so the stitched result is bit-identical to the single-GPU result (tested).
+
+This module is device agnostic (torch tensor algebra + a small `backend` object doing the arithmetic):
+the GPU backend wraps the C ABI (HipBackend); the world-size-2 gloo test on CPU plugs in the oracle.
+"""
+import torch
+import torch.distributed as dist
+
+NUM_GRIDS = 5
+
+
+# ---- ownership ---------------------------------------------------------------------------------------
+def key_levels(keys):
+    """level of each location code (cpp/lib/octreebase.h:41-57): keys are uint64 bit patterns held in
+    int64; a level-21 key has bit 63 set and shows up negative"""
+    lev = torch.zeros_like(keys)
+    for l in range(1, 21):
+        lev += (keys >= (1 << (3 * l))).to(keys.dtype)
+    return torch.where(keys < 0, torch.full_like(keys, 21), lev)
+
+
+def normalized_codes(keys):
+    """Morton code of each voxel's minimum corner at level 21 (a space-filling order across levels;
+    the location codes themselves sort level-major)"""
+    lev = key_levels(keys)
+    marker = torch.ones_like(keys) << (3 * lev)
+    return (keys ^ marker) << (3 * (21 - lev))
+
+
+def partition_level0(keys0, row_splits0, world):
+    """owner[v] for the grid-0 voxels: contiguous ranges of the Morton order with equal pair counts"""
+    order = torch.argsort(normalized_codes(keys0))
+    weight = (row_splits0[1:] - row_splits0[:-1])[order].to(torch.float64)
+    cum = torch.cumsum(weight, 0) - 0.5 * weight
+    total = float(weight.sum())
+    owner_sorted = torch.clamp((cum * (world / max(total, 1.0))).floor().to(torch.int64), 0, world - 1)
+    owner = torch.empty_like(owner_sorted)
+    owner[order] = owner_sorted
+    return owner
+
+
+def coarser_owner(owner, up_index, up_kernel_index, v_coarse):
+    """a coarse voxel belongs to the owner of its first child (slot 0); a voxel carried to the coarser
+    grid unchanged (slot 8, cpp/lib/grid.cpp:206-242) keeps its owner"""
+    first = (up_kernel_index == 0) | (up_kernel_index == 8)
+    out = torch.full((v_coarse,), -1, dtype=owner.dtype, device=owner.device)
+    out[up_index[first].long()] = owner[first]
+    return out
+
+
+# ---- halo exchange -----------------------------------------------------------------------------------
+class ExchangePlan:
+    """rows of one input buffer to send to / receive from each peer before a consumer CSR is applied.
+    send[d] / recv[s]: sorted int64 row indices (same order on both sides by construction)."""
+
+    def __init__(self, send, recv):
+        self.send = send
+        self.recv = recv
+
+    @property
+    def num_recv(self):
+        return sum(int(r.numel()) for r in self.recv.values())
+
+    @property
+    def num_send(self):
+        return sum(int(r.numel()) for r in self.send.values())
+
+
+def make_plan(rank, world, csr_index, csr_row_splits, owner_out, owner_in):
+    """Halo of the consumer rows every rank owns: pairs (row, idx) whose two ends have different owners;
+    the input row `idx` travels from owner_in[idx] to owner_out[row]."""
+    idx = csr_index.long()
+    lens = csr_row_splits[1:] - csr_row_splits[:-1]
+    row_owner = torch.repeat_interleave(owner_out, lens)
+    src_owner = owner_in[idx]
+    cross = row_owner != src_owner
+    send, recv = {}, {}
+    if bool(cross.any()):
+        v_in = owner_in.shape[0]
+        # unique (dst rank, input row): code = dst * v_in + row, sorted
+        code = torch.unique(row_owner[cross] * v_in + idx[cross])
+        dst = code // v_in
+        row = code - dst * v_in
+        src = owner_in[row]
+        for peer in range(world):
+            if peer == rank:
+                continue
+            m = (dst == rank) & (src == peer)
+            if bool(m.any()):
+                recv[peer] = row[m]
+            m = (src == rank) & (dst == peer)
+            if bool(m.any()):
+                send[peer] = row[m]
+    return ExchangePlan(send, recv)
+
+
+def exchange(tensors, plan, group=None):
+    """fills the halo rows of each tensor in `tensors` (same row space, e.g. features and importance) in
+    place.  Point to point, batched: one grouped send/recv per call."""
+    if not plan.send and not plan.recv:
+        return
+    # gloo moves CPU tensors only: stage GPU tensors through the host (single-GPU multi-process tests)
+    via_host = dist.get_backend(group) == "gloo" and tensors[0].is_cuda
+    p2p, landing = [], []
+    for t in tensors:
+        for peer, rows in plan.send.items():
+            buf = t.index_select(0, rows)
+            p2p.append(dist.P2POp(dist.isend, buf.cpu() if via_host else buf.contiguous(), peer, group))
+        for peer, rows in plan.recv.items():
+            buf = torch.empty((rows.numel(),) + tuple(t.shape[1:]), dtype=t.dtype,
+                              device="cpu" if via_host else t.device)
+            p2p.append(dist.P2POp(dist.irecv, buf, peer, group))
+            landing.append((t, rows, buf))
+    for req in dist.batch_isend_irecv(p2p):
+        req.wait()
+    for t, rows, buf in landing:
+        t.index_copy_(0, rows, buf.to(t.device))
+
+
+# ---- the sharded forward ------------------------------------------------------------------------------
+class ShardedNetwork:
+    """aggregate / unet / decode (models/v0/net_definitions_torch.py:535-666) over the rows this rank
+    owns.  geom: dict of torch tensors with the input_dict keys of cpp/lib/asr.cpp:159-312 for the five
+    grids (plus "down_neighbors_*<i>", the inverted up lists); weights: dict state_dict name -> tensor."""
+
+    def __init__(self, backend, geom, weights, rank, world, group=None):
+        self.be, self.g, self.w = backend, geom, weights
+        self.rank, self.world, self.group = rank, world, group
+        self.v = [int(geom["voxel_keys%d" % i].shape[0]) for i in range(NUM_GRIDS)]
+        g = geom
+        owner = [partition_level0(g["voxel_keys0"], g["neighbors_row_splits0"], world)]
+        for i in range(NUM_GRIDS - 1):
+            owner.append(coarser_owner(owner[i], g["up_neighbors_index%d" % i],
+                                       g["up_neighbors_kernel_index%d" % i], self.v[i + 1]))
+        self.owner = owner
+        self.rows = []   # owned rows per level, in the MFMA tiling order when the geometry provides one
+        for i in range(NUM_GRIDS):
+            mine = owner[i] == rank
+            tiling = g.get("tiling%d" % i)
+            if tiling is not None:
+                t = tiling.long()
+                self.rows.append(t[mine[t]])
+            else:
+                self.rows.append(torch.nonzero(mine).reshape(-1))
+        self.plans = {}
+        for i in range(NUM_GRIDS):
+            self.plans["nb", i] = make_plan(rank, world, g["neighbors_index%d" % i],
+                                            g["neighbors_row_splits%d" % i], owner[i], owner[i])
+        for i in range(NUM_GRIDS - 1):
+            # up lists: rows = grid i, inputs = grid i+1; down lists: rows = grid i+1, inputs = grid i
+            self.plans["up", i] = make_plan(rank, world, g["up_neighbors_index%d" % i],
+                                            g["up_neighbors_row_splits%d" % i], owner[i], owner[i + 1])
+            self.plans["down", i] = make_plan(rank, world, g["down_neighbors_index%d" % i],
+                                              g["down_neighbors_row_splits%d" % i], owner[i + 1], owner[i])
+
+    # -- helpers
+    def _csr(self, kind, i):
+        pre = {"nb": "neighbors", "up": "up_neighbors", "down": "down_neighbors"}[kind]
+        return (self.g["%s_index%d" % (pre, i)], self.g["%s_kernel_index%d" % (pre, i)],
+                self.g["%s_row_splits%d" % (pre, i)])
+
+    def _conv(self, name, x, kind, i, out_level, imp=None, normalize=False, residual=None, dual=False,
+              imp_replicated=False):
+        """one SpecialSparseConv (+ bias, ReLU; models/common_torch.py:95-148) on the owned rows of
+        `out_level`; x: full-size input buffer whose owned rows are valid.  dual: conv1a + conv1b of a block
+        (plain bank | importance weighted, normalised bank) -> (out, out_importance).  imp: importance of the
+        INPUT rows (valid on the owned rows, its halo travels with the features) unless imp_replicated."""
+        halo = [x] if imp is None or imp_replicated else [x, imp]
+        exchange(halo, self.plans[kind, i], self.group)
+        rows = self.rows[out_level]
+        if dual:
+            return self.be.sparse_conv_ab(self.w[name + ".conv1a.kernel"], self.w[name + ".conv1a.bias"],
+                                          self.w[name + ".conv1b.kernel"], self.w[name + ".conv1b.bias"], x,
+                                          self._csr(kind, i), rows, self.v[out_level], imp)
+        return self.be.sparse_conv(self.w[name + ".kernel"], self.w[name + ".bias"], x, self._csr(kind, i), rows,
+                                   self.v[out_level], imp, normalize, residual)
+
+    def _block(self, name, x, i, imp, with_imp, imp_replicated=False):
+        """SparseConvBlock (net_definitions_torch.py:253-302)"""
+        out_imp = None
+        if with_imp:
+            f, out_imp = self._conv(name, x, "nb", i, i, imp=imp, dual=True, imp_replicated=imp_replicated)
+        else:
+            f = self._conv(name + ".conv1", x, "nb", i, i)
+        for k in (2, 3, 4):
+            f = self._conv(name + ".conv%d" % k, f, "nb", i, i)
+        return f, out_imp
+
+    def forward(self, points, normals, radii, frame_or_bb, scale_sdf=True):
+        """-> (values_owned [n_owned, 2], owned_rows).  stitch() assembles the full array."""
+        g, w, be = self.g, self.w, self.be
+        V0 = self.v[0]
+        own0 = self.rows[0]
+        # ---- aggregate (net_definitions_torch.py:640-653): search + continuous conv for the owned voxels
+        feats1_own, _ = be.aggregate(points, normals, radii, frame_or_bb, g["voxel_centers0"][own0],
+                                     g["voxel_sizes0"][own0], w["cconv_block_in.conv1.kernel"],
+                                     w["cconv_block_in.conv1.bias"])
+        feats1 = torch.zeros((V0, feats1_own.shape[1]), dtype=feats1_own.dtype, device=feats1_own.device)
+        feats1[own0] = feats1_own
+        # SURVEY B.2 (net_definitions_torch.py:572-578 -> common_torch.py:125): encblock0 indexes the per-PAIR
+        # importance array of the aggregation with grid-0 VOXEL indices, i.e. it reads the importance of the
+        # first V0 pairs of the global CSR.  Those belong to the first few percent of the voxels in index
+        # order; every rank searches that prefix itself (replicated, no communication).
+        imp_prefix = self._importance_prefix(points, normals, radii, frame_or_bb, V0)
+        # ---- unet (net_definitions_torch.py:535-638)
+        enc = [None] * NUM_GRIDS
+        enc[0], imp = self._block("sparseconv_encblock0", feats1, 0, imp_prefix, True, imp_replicated=True)
+        for i in range(1, NUM_GRIDS):
+            dn = "sparseconv_down%d" % (i if i < 4 else 3)   # down3 is re-used for 3 -> 4 (:596-598)
+            t, imp_d = self._conv(dn, enc[i - 1], "down", i - 1, i, imp=imp, dual=True)
+            enc[i], imp = self._block("sparseconv_encblock%d" % i, t, i, imp_d, True)
+        cur = enc[4]
+        for i in (3, 2, 1):
+            up = self._conv("sparseconv_up%d.conv1" % i, cur, "up", i, i)
+            cur, _ = self._block("sparseconv_decblock%d" % i, torch.cat([up, enc[i]], 1), i, None, False)
+        f21 = self._conv("sparseconv_up0.conv1", cur, "up", 0, 0, residual=enc[0])  # :631-633
+        code, _ = self._block("sparseconv_decblock0", f21, 0, None, False)
+        # ---- decode + sdf scale (:655-666, cpp/lib/asr.cpp:324-336)
+        values = be.decode(code[own0], w, g["voxel_sizes0"][own0] if scale_sdf else None)
+        return values, own0
+
+    def _importance_prefix(self, points, normals, radii, frame_or_bb, V0):
+        g, be = self.g, self.be
+        k = min(V0, max(1024, V0 // 8))
+        while True:
+            imp = be.aggregate(points, normals, radii, frame_or_bb, g["voxel_centers0"][:k], g["voxel_sizes0"][:k],
+                               None, None)[1]
+            if imp.shape[0] >= V0 or k >= V0:
+                break
+            k = min(V0, 2 * k)
+        if imp.shape[0] < V0:  # the reference would index out of range here (torch raises)
+            raise RuntimeError("aggregation pairs (%d) < voxels (%d): reference indexing is out of range"
+                               % (imp.shape[0], V0))
+        return imp[:V0].contiguous()
+
+    def stitch(self, values_owned, owned_rows):
+        """full [V0, 2] values on every rank: the owned row sets partition the rows, so a sum of
+        zero-initialised arrays is exact"""
+        full = torch.zeros((self.v[0], values_owned.shape[1]), dtype=values_owned.dtype,
+                           device=values_owned.device)
+        full[owned_rows] = values_owned
+        if self.world > 1:
+            via_host = dist.get_backend(self.group) == "gloo" and full.is_cuda
+            buf = full.cpu() if via_host else full
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            full = buf.to(values_owned.device)
+        return full
+
+    def halo_rows(self):
+        """{(kind, level): rows received per application of that stencil} -- for reporting"""
+        return {k: p.num_recv for k, p in self.plans.items()}
+
+
+# ---- GPU backend: the C ABI through asr_hip.ops --------------------------------------------------------
+class HipBackend:
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def sparse_conv(self, kernel, bias, x, csr, rows, v_out, imp=None, normalize=False, residual=None):
+        from . import ops
+        idx, kidx, rs = csr
+        out = torch.zeros((v_out, kernel.shape[2]), dtype=torch.float32, device=self.device)
+        return ops.sparse_conv(kernel, x, idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias,
+                               relu=True, residual=residual, out=out, return_importance=imp is not None,
+                               row_perm=rows.to(torch.int32), num_rows=rows.numel())
+
+    def sparse_conv_ab(self, ka, ba, kb, bb, x, csr, rows, v_out, imp):
+        """conv1a + conv1b in one launch when the fused kernel takes the widths, else two launches"""
+        from . import ops
+        idx, kidx, rs = csr
+        ca, cb = ka.shape[2], kb.shape[2]
+        out = torch.zeros((v_out, ca + cb), dtype=torch.float32, device=self.device)
+        perm = rows.to(torch.int32)
+        if ca % 16 == 8 and cb == 8 and x.shape[1] % 4 == 0:
+            _, oimp = ops.sparse_conv(ka, x, idx, kidx, rs, inp_importance=imp, normalize=True, bias=ba, relu=True,
+                                      out=out, return_importance=True, algo=2, row_perm=perm,
+                                      num_rows=rows.numel(), filters_b=kb, bias_b=bb)
+            return out, oimp
+        a = self.sparse_conv(ka, ba, x, csr, rows, v_out)
+        b, oimp = self.sparse_conv(kb, bb, x, csr, rows, v_out, imp, True)
+        out[:, :ca] = a
+        out[:, ca:] = b
+        return out, oimp
+
+    def aggregate(self, points, normals, radii, frame, centers, sizes, kernel, bias):
+        from . import ops
+        centers, sizes = centers.contiguous(), sizes.contiguous()
+        idx, dist_, rs, compat = ops.multi_radius_search(frame, points, radii, centers, sizes)
+        imp = ops.aggregation_importance(compat, dist_)
+        if kernel is None:
+            return None, imp
+        feats = torch.cat([normals, torch.ones((normals.shape[0], 1), dtype=normals.dtype, device=normals.device)], 1)
+        out = ops.continuous_conv(kernel, centers, sizes, points, feats, idx, imp, rs, normalize=True, bias=bias,
+                                  relu=True)
+        return out, imp
+
+    def decode(self, code, w, sizes):
+        from . import ops
+        return ops.decode_mlp(code.contiguous(), w["dense_decoder1.weight"], w["dense_decoder1.bias"],
+                              w["dense_decoder2.weight"], w["dense_decoder2.bias"], w["dense_decoder3.weight"],
+                              voxel_sizes=sizes.contiguous() if sizes is not None else None)
+
+
+def geometry_from_pipeline(pipe):
+    """the grid arrays of the last ImplicitPipeline.build() as the dict ShardedNetwork takes"""
+    g = {}
+    for i in range(NUM_GRIDS):
+        for k in ("voxel_keys", "voxel_centers", "voxel_sizes", "neighbors_index", "neighbors_kernel_index",
+                  "neighbors_row_splits", "tiling"):
+            g["%s%d" % (k, i)] = pipe.get("%s%d" % (k, i))
+        if i < NUM_GRIDS - 1:
+            for k in ("up_neighbors_index", "up_neighbors_kernel_index", "up_neighbors_row_splits",
+                      "down_neighbors_index", "down_neighbors_kernel_index", "down_neighbors_row_splits"):
+                g["%s%d" % (k, i)] = pipe.get("%s%d" % (k, i))
+    return g
+
+
+class ShardedImplicitPipeline:
+    """points / normals / radii (replicated on every rank) -> values[V0, 2] with the network half sharded
+    over the ranks of `group`; same call signature as ImplicitPipeline.forward."""
+
+    def __init__(self, weights, device, group=None, point_radius_scale=1.0, octree_max_depth=21, scale_sdf=True):
+        from .pipeline import ImplicitPipeline
+        self.pipe = ImplicitPipeline(weights, device=device, point_radius_scale=point_radius_scale,
+                                     octree_max_depth=octree_max_depth, scale_sdf=scale_sdf)
+        self.pipe.ctx.set_option("build_search", 0)  # each rank searches only the rows it owns
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.net = None
+
+    def forward(self, points, normals, radii, bb_min, bb_max):
+        from . import _lib
+        pipe = self.pipe
+        pipe.build(points, radii, bb_min, bb_max)
+        geom = geometry_from_pipeline(pipe)
+        self.net = ShardedNetwork(HipBackend(pipe.device), geom, pipe._weights, self.rank, self.world, self.group)
+        values, rows = self.net.forward(points, normals, radii, _lib.frame_init(bb_min, bb_max), pipe.scale_sdf)
+        return self.net.stitch(values, rows)

@@ -37,6 +37,7 @@ const OptEntry k_options[] = {
         {"row_segment", "ASR_ROW_SEGMENT", &AsrOptions::row_segment},
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"overlap", "ASR_OVERLAP", &AsrOptions::overlap},
+        {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
 };
 }  // namespace
 
@@ -634,7 +635,8 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     // Aggregation neighbours (cpp/lib/asr.cpp:266-273) on the auxiliary context: its own stream, arenas,
     // counters and host thread, overlapped with the grid hierarchy below.  Both are chains of
     // latency-bound kernels with host round trips for the data-dependent sizes; neither fills the GPU.
-    const bool overlap = ctx->opt.overlap != 0;
+    const bool want_search = ctx->opt.build_search != 0;
+    const bool overlap = want_search && ctx->opt.overlap != 0;
     asr_hip_context* sc = ctx;  // context the search runs on
     if (overlap) {
         if (!ctx->aux) {
@@ -738,6 +740,8 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             name_it(ctx, "down_neighbors_index" + s, prev.down_idx, 4 * prev.v);
             name_it(ctx, "down_neighbors_kernel_index" + s, prev.down_kidx, prev.v);
             name_it(ctx, "down_neighbors_row_splits" + s, prev.down_rs, 8 * (g.v + 1));
+            name_it(ctx, "tiling_up" + s, prev.perm_up, 4 * prev.v);
+            name_it(ctx, "tiling_down" + s, prev.perm_down, 4 * g.v);
         }
         if (i > 0) {
             g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
@@ -759,18 +763,19 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         name_it(ctx, "neighbors_index" + s, g.nidx, 4 * g.p);
         name_it(ctx, "neighbors_kernel_index" + s, g.nkidx, g.p);
         name_it(ctx, "neighbors_row_splits" + s, g.nrs, 8 * (g.v + 1));
+        name_it(ctx, "tiling" + s, g.perm_nb, 4 * g.v);
     }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     if (overlap)
         worker.join();
-    else
+    else if (want_search)
         search_rc = search();
     if (search_rc != ASR_HIP_OK) {
         if (sc != ctx) ctx->err = sc->err;
         return search_rc;
     }
-    {
+    if (want_search) {
         GridDev& g0 = ctx->grids[0];
         ctx->sizes.num_agg_pairs = agg_pairs;
         name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * agg_pairs);
@@ -792,6 +797,8 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_TRY(ensure_events(ctx));
     if (n != ctx->sizes.num_points || ctx->sizes.num_voxels[0] == 0)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: no matching implicit_build");
+    if (!ctx->agg_rs || !ctx->agg_sorted || ctx->opt.build_search == 0)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: the build skipped the aggregation search (option build_search)");
     ctx->scratch.reset();
     if (ctx->build_mark_ok) arena_rewind(ctx->persist, ctx->build_mark);
     Net net{ctx, {weights, num_weights}};

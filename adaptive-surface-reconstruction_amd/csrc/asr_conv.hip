@@ -328,6 +328,7 @@ __global__ void k_sconv_scalar(asr_sparse_conv_args a) {
     i64 q = t / a.cout;
     int oc = (int)(t % a.cout);
     if (q >= a.num_out) return;
+    if (a.row_perm) q = a.row_perm[q];  // row list (global row indices)
     float acc = 0.f, norm = 0.f;
     for (i64 p = a.neighbors_row_splits[q]; p < a.neighbors_row_splits[q + 1]; ++p) {
         int32_t i = a.neighbors_index[p];
@@ -417,11 +418,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
         // of dependent global loads and sits in front of every tile
         constexpr int TPR = NTHR / TM;
         const int prow = tid / TPR, pj = tid % TPR;
+        // entry row0 + prow of the row list; with a row list the rows are GLOBAL indices that may exceed
+        // num_out (a rank of a sharded run lists only the rows it owns)
         i64 q = row0 + prow;
-        if (q < a.num_out && a.row_perm) q = a.row_perm[q];
+        const bool valid = q < a.num_out;
+        if (valid && a.row_perm) q = a.row_perm[q];
         unsigned long long m = 0;
         float norm = 0.f;
-        if (q < a.num_out) {
+        if (valid) {
             const i64 pe = a.neighbors_row_splits[q + 1];
             for (i64 p = a.neighbors_row_splits[q] + pj; p < pe; p += TPR) {
                 int k = a.neighbors_kernel_index[p];

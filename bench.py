@@ -153,6 +153,34 @@ def pipelined_rate(pipe, weights, dev, inputs, n, steps):
     return {"points_per_s": n * steps / dt, "ms_per_cloud": dt / steps * 1e3, "depth": 2, "clouds": steps}
 
 
+def one_scan_line(args, world, n, dt, sharded):
+    """bench line of --shard one-scan: ONE cloud over all ranks, total work fixed ("strong")"""
+    steps = max(args.steps, 1)
+    net = sharded.net
+    return {
+        "metric": "input points/sec to signed implicit values",
+        "value": n * steps / dt,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "one %d-point scan-like synthetic cloud sharded over %d GPU(s) by Morton range; "
+                               "grids replicated, aggregation + 53 sparse convs + decoder on owned rows, halo "
+                               "exchange per convolution (RCCL send/recv), values stitched by all-reduce" % (n, world),
+                   "points": n,
+                   "voxels": net.v,
+                   "owned_rows_rank0": [int(r.numel()) for r in net.rows],
+                   "halo_rows_rank0": {"%s%d" % k: v for k, v in net.halo_rows().items()},
+                   "parallelism": "spatial sharding, %d ranks" % world},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +191,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-context run (profiling)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--shard", choices=["replicas", "one-scan"], default="replicas",
+                    help="replicas (default): one scan per GPU, no collective, weak scaling.  one-scan: ONE cloud of "
+                         "--points points sharded over the GPUs by Morton range with halo exchange (RCCL), strong scaling")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -187,14 +218,21 @@ def main():
 
     # ---- inputs (untimed): one scan per rank, radii = exact 24-NN distance -------------------
     n = args.points
-    pts, nrm = synth.scan_cloud(n, seed=rank_seed(rank), device=dev)
+    one_scan = args.shard == "one-scan"
+    # one-scan: every rank holds the same cloud (seed of rank 0); replicas: one scan per rank
+    pts, nrm = synth.scan_cloud(n, seed=rank_seed(0 if one_scan else rank), device=dev)
     t_knn = time.perf_counter()
     radii = synth.knn_radii_gpu(pts, 24)  # pre-filter row D.4 on the GPU, untimed input preparation
     torch.cuda.synchronize()
     t_knn = time.perf_counter() - t_knn
     bb_min, bb_max = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(1, seed=0, init="reference")  # released weights are not in the repo
-    pipe = ImplicitPipeline(weights, device=dev)
+    if one_scan:
+        from asr_hip.sharding import ShardedImplicitPipeline
+        sharded = ShardedImplicitPipeline(weights, dev)
+        pipe = sharded.pipe
+    else:
+        pipe = ImplicitPipeline(weights, device=dev)
     shapes = synth.unet5_param_shapes(1)
 
     def barrier():
@@ -203,6 +241,8 @@ def main():
         torch.cuda.synchronize()
 
     def step():
+        if one_scan:
+            return sharded.forward(pts, nrm, radii, bb_min, bb_max)
         return pipe.forward(pts, nrm, radii, bb_min, bb_max)
 
     for _ in range(args.warmup):
@@ -213,12 +253,20 @@ def main():
     for _ in range(args.steps):
         values = step()
         # stage times come from hip events recorded on the stream inside the library
-        for k, v in pipe.stage_ms().items():
-            stage_sum[k] += v
+        if not one_scan:
+            for k, v in pipe.stage_ms().items():
+                stage_sum[k] += v
     barrier()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world, dev)
     assert values.shape[0] == pipe.sizes.num_voxels[0] and bool(torch.isfinite(values).all())
+    if one_scan:
+        if rank == 0:
+            print(json.dumps(one_scan_line(args, world, n, dt, sharded)))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     mesh_info = mesh_stage(pipe, synth) if rank == 0 else None
     pipelined = None
     if world == 1 and not args.no_pipelined:

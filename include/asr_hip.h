@@ -68,7 +68,9 @@ int asr_hip_context_device(const asr_hip_context* ctx);
 /* Per-context tunables (no process-wide state).  Names: "sconv_min_blocks" (2816) and
  * "sconv_wide_min" (2048): launch-size thresholds that pick the sparse-conv tile shape;
  * "row_segment" (524288), "row_lpt" (1): MFMA row regrouping; "overlap" (1): aggregation search on a
- * second stream; "sconv_dry" (0): measurement aid.  Results never depend on them. */
+ * second stream; "sconv_dry" (0): measurement aid; "build_search" (1): 0 makes asr_hip_implicit_build stop
+ * after the grid hierarchy (a rank of a sharded run searches only the rows it owns).  Results never depend
+ * on the tuning options. */
 int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value);
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value);
 
@@ -324,7 +326,9 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points_dev,
  *       "neighbors_kernel_index<i>", "neighbors_row_splits<i>", "up_neighbors_index<i>",
  *       "up_neighbors_kernel_index<i>", "up_neighbors_row_splits<i>",
  *       "aggregation_neighbors_index", "aggregation_neighbors_dist",
- *       "aggregation_row_splits", "aggregation_scale_compat", "nodes"
+ *       "aggregation_row_splits", "aggregation_scale_compat", "nodes",
+ *       "down_neighbors_{index,kernel_index,row_splits}<i>" (inverted up lists, rows = grid i+1),
+ *       "tiling<i>", "tiling_up<i>", "tiling_down<i>" (int32 MFMA tiling orders of the three CSRs)
  * (the input_dict keys of cpp/lib/asr.cpp:159-312). nbytes returns the byte size; dst_dev may
  * be NULL to query only. */
 int asr_hip_implicit_get(asr_hip_context* ctx, const char* name, void* dst_dev,

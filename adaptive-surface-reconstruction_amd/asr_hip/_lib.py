@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libasr_hip.so")
 
 ASR_MAX_LEVEL = 21
 ASR_NUM_GRIDS = 5
+CONV16_F16 = 1      # ASR_CONV16_F16: f16 activations + weights, f32 accumulate (config C5)
+CONV16_BF16X3 = 2   # ASR_CONV16_BF16X3: exact three-way bf16 split, fp32-class results
+PRECISIONS = {"f32": 0, "f16": CONV16_F16, "bf16x3": CONV16_BF16X3}
 
 
 class AsrHipError(RuntimeError):
@@ -77,6 +80,7 @@ class ImplicitParams(ctypes.Structure):
         ("bb_min", ctypes.c_float * 3),
         ("bb_max", ctypes.c_float * 3),
         ("scale_sdf", ctypes.c_int),
+        ("precision", ctypes.c_int),
     ]
 
 
@@ -95,7 +99,8 @@ EXPORTS = [
     "asr_hip_context_create", "asr_hip_context_destroy", "asr_hip_context_set_stream",
     "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes",
     "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_set_option", "asr_hip_context_get_option",
-    "asr_hip_sparse_conv_variant_counts",
+    "asr_hip_sparse_conv_variant_counts", "asr_hip_sparse_conv_packed_bytes", "asr_hip_sparse_conv_pack",
+    "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_convert_f16",
     "asr_octree_frame_init", "asr_hip_point_keys", "asr_hip_octree_build", "asr_hip_octree_get", "asr_hip_dual_cells_count", "asr_hip_dual_cells_fill",
     "asr_hip_contour_count", "asr_hip_contour_fill", "asr_hip_components_count", "asr_hip_components_fill",
     "asr_hip_unordered_set_order", "asr_density_inlier",
@@ -124,6 +129,7 @@ def load():
         lib.asr_hip_version.restype = ctypes.c_char_p
         lib.asr_hip_context_reserved_bytes.restype = ctypes.c_size_t
         lib.asr_hip_struct_size.restype = ctypes.c_size_t
+        lib.asr_hip_sparse_conv_packed_bytes.restype = ctypes.c_size_t
         for name, cls in (("asr_octree_frame", OctreeFrame), ("asr_sparse_conv_args", SparseConvArgs),
                           ("asr_weight", Weight), ("asr_implicit_params", ImplicitParams),
                           ("asr_implicit_sizes", ImplicitSizes)):
@@ -184,14 +190,15 @@ class Context:
         return int(self.lib.asr_hip_context_device(self._h))
 
     def sconv_variant_counts(self, reset=False):
-        """{(NT, KC, IMP, WAVES, DUAL): launches} of k_sconv_mfma since the last reset"""
+        """{(NT, KC, IMP, WAVES, DUAL): launches} of k_sconv_mfma since the last reset; launches of the 16-bit
+        kernel k_sconv_mfma16 have a sixth field, the mode (1 = f16, 2 = bf16x3)"""
         buf = ctypes.create_string_buffer(4096)
         self.call("asr_hip_sparse_conv_variant_counts", buf, ctypes.c_size_t(4096), int(bool(reset)))
         out = {}
         for item in buf.value.decode().split(";"):
             if item:
                 k, c = item.split(":")
-                out[tuple(int(x) for x in k.split(","))] = int(c)
+                out[tuple(int(x) for x in k.split(","))] = int(c)  # 6th field (16-bit kernels): mode
         return out
 
     def reserved_bytes(self):

@@ -334,6 +334,82 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     return out
 
 
+def pack_filters(filters, mode, filters_b=None):
+    """re-packed 16-bit copy of a filter tensor [K, cin, cout] (+ second bank [K, cin, cout_b]) for
+    sparse_conv16 (asr_hip_sparse_conv_pack); mode: "f16" or "bf16x3".  Pack once per weight tensor."""
+    m = _lib.PRECISIONS[mode]
+    filters = _dev(filters, torch.float32)
+    fb = _dev(filters_b, torch.float32) if filters_b is not None else None
+    K, cin, cout = filters.shape
+    cb = fb.shape[2] if fb is not None else 0
+    nbytes = _lib.load().asr_hip_sparse_conv_packed_bytes(m, int(K), int(cin), int(cout), int(cb))
+    if nbytes == 0:
+        raise RuntimeError("pack_filters: bad shape / mode")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
+    context(_same_device(filters, fb)).call("asr_hip_sparse_conv_pack", m, ptr(filters), ptr(fb), int(K), int(cin),
+                                            int(cout), int(cb), ptr(out))
+    return out
+
+
+def sparse_conv16(mode, packed, kernel_size, cin, cout, inp_features, neighbors_index, neighbors_kernel_index,
+                  neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False, residual=None,
+                  out=None, out_dtype=None, return_importance=False, neighbors_importance=None, row_perm=None,
+                  num_rows=None, cout_b=0, bias_b=None, force_nt=0, force_waves=0):
+    """SpecialSparseConv.forward on the 16-bit matrix cores (asr_hip_sparse_conv_f16 / _bf16x3).
+    mode "f16": inp_features / residual are float16 tensors, out is float16 (default) or float32;
+    mode "bf16x3": float32 in and out, fp32-class result.  packed: pack_filters(filters, mode[, filters_b])."""
+    m = _lib.PRECISIONS[mode]
+    act = torch.float16 if mode == "f16" else torch.float32
+    inp_features = _dev(inp_features, act)
+    nidx = _dev(neighbors_index, torch.int32)
+    nk = _dev(neighbors_kernel_index, torch.uint8)
+    rs = _dev(neighbors_row_splits, torch.int64)
+    v = rs.shape[0] - 1
+    if inp_features.shape[1] != cin:
+        raise RuntimeError("sparse_conv16: feature width does not match the filter")
+    imp = _dev(inp_importance, torch.float32) if inp_importance is not None else None
+    nimp = _dev(neighbors_importance, torch.float32) if neighbors_importance is not None else None
+    b = _dev(bias, torch.float32) if bias is not None else None
+    bb = _dev(bias_b, torch.float32) if bias_b is not None else None
+    res = _dev(residual, act) if residual is not None else None
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else act
+    if out_dtype not in (torch.float32, act):
+        raise RuntimeError("sparse_conv16: out must be float32 or the activation type")
+    if out is None:
+        out = torch.empty((v, cout + cout_b), dtype=out_dtype, device=inp_features.device)
+    oimp = torch.empty(v, dtype=torch.float32, device=inp_features.device) if return_importance else None
+    perm = _dev(row_perm, torch.int32) if row_perm is not None else None
+    a = _lib.SparseConvArgs()
+    a.inp_features = inp_features.data_ptr()
+    a.inp_ld = inp_features.stride(0)
+    a.inp_importance = imp.data_ptr() if imp is not None else None
+    a.neighbors_importance = nimp.data_ptr() if nimp is not None else None
+    a.neighbors_index = nidx.data_ptr()
+    a.neighbors_kernel_index = nk.data_ptr()
+    a.neighbors_row_splits = rs.data_ptr()
+    a.num_out = v if num_rows is None else int(num_rows)
+    a.num_inp = inp_features.shape[0]
+    a.kernel_size, a.cin, a.cout, a.cout_b = int(kernel_size), int(cin), int(cout), int(cout_b)
+    a.normalize = int(bool(normalize))
+    a.bias = b.data_ptr() if b is not None else None
+    a.bias_b = bb.data_ptr() if bb is not None else None
+    a.relu = int(bool(relu))
+    a.residual = res.data_ptr() if res is not None else None
+    a.residual_ld = res.stride(0) if res is not None else 0
+    a.out = out.data_ptr()
+    a.out_ld = out.stride(0)
+    a.out_importance = oimp.data_ptr() if oimp is not None else None
+    a.row_perm = perm.data_ptr() if perm is not None else None
+    a.force_nt, a.force_waves = int(force_nt), int(force_waves)
+    ctx = context(_same_device(packed, inp_features, nidx, nk, rs, imp, nimp, b, bb, res, out, perm))
+    if mode == "f16":
+        ctx.call("asr_hip_sparse_conv_f16", ctypes.byref(a), ptr(packed), int(out.dtype == torch.float16))
+    else:
+        ctx.call("asr_hip_sparse_conv_bf16x3", ctypes.byref(a), ptr(packed))
+    return (out, oimp) if return_importance else out
+
+
 def row_groups(neighbors_kernel_index, neighbors_row_splits, segment_rows=0):
     """MFMA tiling order of a CSR's rows (asr_hip_row_groups)"""
     nk = _dev(neighbors_kernel_index, torch.uint8)

@@ -51,7 +51,13 @@ class ImplicitPipeline:
               "geometry_wall", "network_wall")
 
     def __init__(self, weights, device="cuda:0", point_radius_scale=1.0, octree_max_depth=21,
-                 scale_sdf=True):
+                 scale_sdf=True, precision="f32"):
+        """precision: arithmetic of the 53 sparse convs -- "f32" (exact f32 MFMA, the reference's type),
+        "f16" (f16 activations and weights, f32 accumulate: BASELINE config C5) or "bf16x3" (exact three-way
+        bf16 split on the bf16 matrix cores: fp32-class results)"""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
+        self.precision = precision
         if not torch.cuda.is_available():
             raise AsrHipError("no GPU visible: the MI355X path cannot run (no CPU fallback)")
         self.device = torch.device(device)
@@ -86,6 +92,7 @@ class ImplicitPipeline:
             p.bb_min[d] = float(bb_min[d])
             p.bb_max[d] = float(bb_max[d])
         p.scale_sdf = int(self.scale_sdf)
+        p.precision = _lib.PRECISIONS[self.precision]
         return p
 
     def _stream(self):

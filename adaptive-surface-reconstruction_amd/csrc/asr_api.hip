@@ -101,6 +101,8 @@ int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t c
     return ASR_HIP_OK;
 }
 static void release_members(asr_hip_context* ctx) {
+    for (auto& kv : ctx->packed_weights) (void)hipFree(kv.second);
+    ctx->packed_weights.clear();
     asr_geom_release(ctx);
     asr_mesh_release(ctx);
     ctx->persist.release();
@@ -360,6 +362,37 @@ int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* a)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: null argument");
     return asr_conv_sparse(ctx, a);
 }
+size_t asr_hip_sparse_conv_packed_bytes(int mode, int K, int cin, int cout, int cout_b) {
+    if ((mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3) || K < 1 || cin < 1 || cout < 1 || cout_b < 0) return 0;
+    return asr_conv16_packed_bytes(mode, K, cin, cout, cout_b);
+}
+int asr_hip_sparse_conv_pack(asr_hip_context* ctx, int mode, const float* filters, const float* filters_b, int K,
+                             int cin, int cout, int cout_b, void* packed_out) {
+    CTX_GUARD(ctx);
+    return asr_conv16_pack(ctx, mode, filters, filters_b, K, cin, cout, cout_b, packed_out);
+}
+static int check_conv16_args(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed) {
+    if (!a || !packed) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: null args");
+    if (a->num_out > 0 && (!a->inp_features || !a->neighbors_index || !a->neighbors_kernel_index ||
+                           !a->neighbors_row_splits || !a->out))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: null argument");
+    return ASR_HIP_OK;
+}
+int asr_hip_sparse_conv_f16(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed, int out_is_f16) {
+    CTX_GUARD(ctx);
+    ASR_TRY(check_conv16_args(ctx, a, packed));
+    return asr_conv_sparse16(ctx, a, packed, ASR_CONV16_F16, out_is_f16 ? 1 : 0);
+}
+int asr_hip_sparse_conv_bf16x3(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed) {
+    CTX_GUARD(ctx);
+    ASR_TRY(check_conv16_args(ctx, a, packed));
+    return asr_conv_sparse16(ctx, a, packed, ASR_CONV16_BF16X3, 0);
+}
+int asr_hip_convert_f16(asr_hip_context* ctx, const void* in, int64_t n, void* out, int to_f16) {
+    CTX_GUARD(ctx);
+    if (n > 0 && (!in || !out)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "convert_f16: null argument");
+    return asr_conv16_convert(ctx, in, n, out, to_f16);
+}
 int asr_hip_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const int64_t* rs, int64_t v,
                        int64_t seg, int32_t* perm_out) {
     CTX_GUARD(ctx);
@@ -436,14 +469,46 @@ struct WeightTable {
 };
 
 struct Feat {
-    float* p;
-    i64 ld;
+    float* p;  // f16 data when the network runs with ASR_CONV16_F16 activations (see Net::esz)
+    i64 ld;    // row stride in elements
     int c;
 };
 
 struct Net {
     asr_hip_context* ctx;
     WeightTable wt;
+    int precision = 0;  // 0 = exact f32 MFMA, ASR_CONV16_F16, ASR_CONV16_BF16X3 (asr_implicit_params.precision)
+
+    size_t esz() const { return precision == ASR_CONV16_F16 ? 2 : 4; }  // bytes per activation element
+    // activation buffer [rows, c] in the scratch arena (element type per precision)
+    float* act(i64 rows, int c) { return (float*)ctx->scratch.alloc((size_t)rows * c * esz()); }
+    float* col(float* base, int c) const { return (float*)((char*)base + (size_t)c * esz()); }  // column offset
+
+    // packed 16-bit copy of a (two-bank) filter tensor, made once per weight tensor and mode
+    int packed(const asr_weight* ka, const asr_weight* kb, const void** out) {
+        auto key = std::make_pair((const void*)ka->data, precision);
+        auto it = ctx->packed_weights.find(key);
+        if (it == ctx->packed_weights.end()) {
+            const int cb = kb ? (int)kb->shape[2] : 0;
+            const size_t bytes = asr_conv16_packed_bytes(precision, (int)ka->shape[0], (int)ka->shape[1],
+                                                         (int)ka->shape[2], cb);
+            void* p = nullptr;
+            ASR_HIP_CHECK(ctx, hipMalloc(&p, bytes));
+            it = ctx->packed_weights.emplace(key, p).first;
+            ASR_TRY(asr_conv16_pack(ctx, precision, ka->data, kb ? kb->data : nullptr, (int)ka->shape[0],
+                                    (int)ka->shape[1], (int)ka->shape[2], cb, p));
+        }
+        *out = it->second;
+        return ASR_HIP_OK;
+    }
+    // dispatch of one assembled argument block: f32 kernel or a 16-bit variant; out_f32: the layer's output
+    // feeds the decoder (f32 `code`)
+    int launch(asr_sparse_conv_args& a, const asr_weight* ka, const asr_weight* kb, bool out_f32) {
+        if (precision == 0) return asr_conv_sparse(ctx, &a);
+        const void* pk = nullptr;
+        ASR_TRY(packed(ka, kb, &pk));
+        return asr_conv_sparse16(ctx, &a, pk, precision, precision == ASR_CONV16_F16 && !out_f32);
+    }
 
     int get(const std::string& name, int ndim, const asr_weight** out) {
         const asr_weight* w = wt.find(name);
@@ -459,7 +524,7 @@ struct Net {
     int conv(const std::string& prefix, int K, Feat in, const int32_t* nidx, const uint8_t* nk,
              const i64* rs, const int32_t* perm, i64 num_out, i64 num_inp, const float* imp,
              int normalize, float* out, i64 out_ld, int expect_cout, float* out_imp,
-             const float* residual, i64 residual_ld) {
+             const float* residual, i64 residual_ld, bool out_f32 = false) {
         const asr_weight *k, *b;
         ASR_TRY(get(prefix + ".kernel", 3, &k));
         ASR_TRY(get(prefix + ".bias", 1, &b));
@@ -491,7 +556,7 @@ struct Net {
         a.out_ld = out_ld;
         a.out_importance = out_imp;
         a.row_perm = perm;
-        return asr_conv_sparse(ctx, &a);
+        return launch(a, k, nullptr, out_f32);
     }
     // conv1a + conv1b of a block in one launch (second filter bank of asr_sparse_conv_args): same
     // gather, one extra column tile.  Falls back to two launches for widths the fused kernel does not take.
@@ -503,7 +568,7 @@ struct Net {
         ASR_TRY(get(name + ".conv1a.bias", 1, &ba));
         ASR_TRY(get(name + ".conv1b.kernel", 3, &kb));
         ASR_TRY(get(name + ".conv1b.bias", 1, &bb));
-        const bool fused = ca % 16 == 8 && cb == 8 && in.c % 4 == 0 && in.ld % 4 == 0 && ka->shape[0] == K &&
+        const bool fused = ca % 16 == 8 && cb == 8 && in.c % 8 == 0 && in.ld % 8 == 0 && ka->shape[0] == K &&
                            kb->shape[0] == K && ka->shape[1] == in.c && kb->shape[1] == in.c &&
                            ka->shape[2] == ca && kb->shape[2] == cb && ba->shape[0] == ca && bb->shape[0] == cb &&
                            (uintptr_t)kb->data % 16 == 0 && (uintptr_t)ka->data % 16 == 0 &&
@@ -511,8 +576,8 @@ struct Net {
         if (!fused) {
             ASR_TRY(conv(name + ".conv1a", K, in, nidx, nk, rs, perm, num_out, num_inp, nullptr, 0, out, out_ld, ca,
                          nullptr, nullptr, 0));
-            return conv(name + ".conv1b", K, in, nidx, nk, rs, perm, num_out, num_inp, imp, 1, out + ca, out_ld, cb,
-                        out_imp, nullptr, 0);
+            return conv(name + ".conv1b", K, in, nidx, nk, rs, perm, num_out, num_inp, imp, 1, col(out, ca), out_ld,
+                        cb, out_imp, nullptr, 0);
         }
         asr_sparse_conv_args a;
         memset(&a, 0, sizeof(a));
@@ -539,7 +604,7 @@ struct Net {
         a.out_importance = out_imp;
         a.row_perm = perm;
         a.algo = 2;
-        return asr_conv_sparse(ctx, &a);
+        return launch(a, ka, kb, false);
     }
     int cout_of(const std::string& prefix, int* c) {
         const asr_weight* k;
@@ -551,11 +616,11 @@ struct Net {
     // SparseConvBlock with conv1a/conv1b (normalized_channels < output_channels) or plain
     // conv1 (decoder blocks): net_definitions_torch.py:253-302.  `out` receives conv4.
     int block(const std::string& name, Feat in, const GridDev& g, const float* imp, bool with_imp,
-              Feat out, float** out_imp) {
+              Feat out, float** out_imp, bool out_f32 = false) {
         asr_hip_context* c = ctx;
         int C = out.c;
-        float* t1 = arena_alloc<float>(c->scratch, (size_t)g.v * C);
-        float* t2 = arena_alloc<float>(c->scratch, (size_t)g.v * C);
+        float* t1 = act(g.v, C);
+        float* t2 = act(g.v, C);
         if (!t1 || !t2) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
         if (with_imp) {
             int ca, cb;
@@ -576,7 +641,7 @@ struct Net {
         ASR_TRY(conv(name + ".conv3", 55, f2, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C, C,
                      nullptr, nullptr, 0));
         ASR_TRY(conv(name + ".conv4", 55, f1, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, out.p,
-                     out.ld, C, nullptr, nullptr, 0));
+                     out.ld, C, nullptr, nullptr, 0, out_f32));
         return ASR_HIP_OK;
     }
     // SparseConvTransitionBlock down (conv1a/conv1b): net_definitions_torch.py:357-387
@@ -802,6 +867,9 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ctx->scratch.reset();
     if (ctx->build_mark_ok) arena_rewind(ctx->persist, ctx->build_mark);
     Net net{ctx, {weights, num_weights}};
+    net.precision = prm->precision;
+    if (net.precision != 0 && net.precision != ASR_CONV16_F16 && net.precision != ASR_CONV16_BF16X3)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: precision must be 0, ASR_CONV16_F16 or ASR_CONV16_BF16X3");
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
     const i64 P = ctx->sizes.num_agg_pairs;
@@ -859,8 +927,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
             ASR_TRY(net.cout_of("sparseconv_decblock" + std::to_string(i) + ".conv4", &c_dec[i]));
         }
     }
-    Arena& S = ctx->scratch;
-    auto buf = [&](i64 rows, int c) { return arena_alloc<float>(S, (size_t)rows * c); };
+    auto buf = [&](i64 rows, int c) { return net.act(rows, c); };  // element type per precision
     // concat buffers [up_i | enc_i] for levels 1..3; level 0 uses a residual add
     float* cat[4] = {nullptr, nullptr, nullptr, nullptr};
     int cat_ld[4] = {0, 0, 0, 0};
@@ -875,11 +942,17 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
 
     Feat enc_out[5];
     enc_out[0] = Feat{f2, c_enc[0], c_enc[0]};
-    for (int i = 1; i <= 3; ++i) enc_out[i] = Feat{cat[i] + c_up[i], cat_ld[i], c_enc[i]};
+    for (int i = 1; i <= 3; ++i) enc_out[i] = Feat{net.col(cat[i], c_up[i]), cat_ld[i], c_enc[i]};
     enc_out[4] = Feat{f10, c_enc[4], c_enc[4]};
 
     float* imp = nullptr;
-    ASR_TRY(net.block("sparseconv_encblock0", Feat{feats1, C0, C0}, g[0], imp_pairs, true, enc_out[0],
+    float* feats1_in = feats1;
+    if (net.precision == ASR_CONV16_F16) {  // f16 activations: the continuous conv's f32 output is converted once
+        feats1_in = buf(V0, C0);
+        if (!feats1_in) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_conv16_convert(ctx, feats1, V0 * (i64)C0, feats1_in, 1));
+    }
+    ASR_TRY(net.block("sparseconv_encblock0", Feat{feats1_in, C0, C0}, g[0], imp_pairs, true, enc_out[0],
                       &imp));
     for (int i = 1; i <= 4; ++i) {
         std::string dn = "sparseconv_down" + std::to_string(i < 4 ? i : 3);
@@ -914,7 +987,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     {
         float* dummy = nullptr;
         ASR_TRY(net.block("sparseconv_decblock0", Feat{f21, c_up[0], c_up[0]}, g[0], nullptr, false,
-                          Feat{code, c_dec[0], c_dec[0]}, &dummy));
+                          Feat{code, c_dec[0], c_dec[0]}, &dummy, true));  // `code` is f32 in every mode
     }
     ctx->code = code;
     name_it(ctx, "code", code, 4 * (size_t)V0 * c_dec[0]);

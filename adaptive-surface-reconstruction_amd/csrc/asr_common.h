@@ -142,6 +142,9 @@ struct asr_hip_context {
     hipEvent_t aux_ev = nullptr;
     hipEvent_t aux_t0 = nullptr, aux_t1 = nullptr;  // search start / end on the auxiliary stream
     bool search_overlapped = false;
+    // packed 16-bit copies of the weight tensors of the whole-path driver, keyed by (pointer of the f32
+    // tensor, mode); the weights of a pipeline are static, so they are packed once
+    std::map<std::pair<const void*, int>, void*> packed_weights;
 };
 
 #define ASR_FAIL(ctx, code, ...)                         \
@@ -292,6 +295,13 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
                    const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
                    int cout, int normalize, const float* bias, int relu, float* out, int sorted4 = 0);
 int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* args);
+// asr_conv16.hip: 16-bit matrix-core variants (f16 activations / exact bf16x3 split)
+size_t asr_conv16_packed_bytes(int mode, int K, int cin, int cout, int cout_b);
+int asr_conv16_pack(asr_hip_context* ctx, int mode, const float* wa, const float* wb, int K, int cin, int ca, int cb,
+                    void* out);
+int asr_conv16_convert(asr_hip_context* ctx, const void* in, i64 n, void* out, int to_f16);
+int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed, int mode,
+                      int out_f16);
 int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gidx, const i64* rs,
                     i64 rows, float* out);
 int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const float* w1,

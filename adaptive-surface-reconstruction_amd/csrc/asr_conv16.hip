@@ -1,0 +1,575 @@
+// asr_conv16.hip -- a12 on the 16-bit matrix cores of gfx950 (v_mfma_f32_16x16x32_{f16,bf16}, 16x the rate
+// of the f32-input MFMA), two arithmetic modes behind one gather-GEMM kernel:
+//
+//   ASR_CONV16_F16     config C5 of BASELINE.json: activations live in HBM as f16 (half the gather bytes that
+//                      bound the level-0 layers), weights are rounded to f16 once, products accumulate in f32.
+//   ASR_CONV16_BF16X3  fp32-class results from bf16 MFMAs: every f32 operand is split EXACTLY into three bf16
+//                      terms (a = a0 + a1 + a2: a0 = rn(a), a1 = rn(a - a0), a2 = the rest; 8 mantissa bits
+//                      each), and a*b is evaluated as the six products a_i*b_j with i + j <= 2, accumulated in
+//                      f32.  The dropped terms are below 2^-24 |a*b| and signed, i.e. less than the error of
+//                      one fp32 rounding.  6 MFMAs at 16x the f32-MFMA rate = 2.7x the f32 matrix peak for
+//                      the same algorithmic FLOP.
+//
+// Weights are re-packed once per weight tensor (asr_conv16_pack): [plane][slot k][column][cin] with cin
+// contiguous and padded to 32, so that a B fragment (8 consecutive k of one column) is one 16-byte piece in
+// HBM, in the LDS panel and in the register.  Same tiling / slot-skipping / two-filter-bank scheme as
+// k_sconv_mfma (asr_conv.hip); reference semantics: models/common_torch.py:95-148.
+#include "asr_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint16_t u16;
+
+constexpr int NBR_LD = 57;
+
+__device__ inline u16 f32_to_bf16_bits(float x) {  // round to nearest even
+    const f32x2 v = {x, 0.f};
+    return (u16)(__builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)) & 0xffffu);
+}
+
+__device__ inline u16 f32_to_f16_bits(float x) {
+    _Float16 h = (_Float16)x;  // round to nearest even
+    return __builtin_bit_cast(u16, h);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: filters [K, cin, cout] (+ bank b [K, cin, cout_b], appended as columns) ->
+// packed [planes][K][ctot_pad][cin_pad] 16-bit, zero padded
+// ------------------------------------------------------------------------------------------
+__global__ void k_pack_filters(const float* __restrict__ wa, const float* __restrict__ wb, int K, int cin, int ca,
+                               int cb, int cin_pad, int ctot_pad, int mode, u16* __restrict__ out) {
+    const i64 total = (i64)K * ctot_pad * cin_pad;
+    for (i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
+        const int c = (int)(e % cin_pad);
+        const int col = (int)((e / cin_pad) % ctot_pad);
+        const int k = (int)(e / ((i64)cin_pad * ctot_pad));
+        float w = 0.f;
+        if (c < cin) {
+            if (col < ca)
+                w = wa[((i64)k * cin + c) * ca + col];
+            else if (col < ca + cb)
+                w = wb[((i64)k * cin + c) * cb + (col - ca)];
+        }
+        if (mode == ASR_CONV16_F16) {
+            out[e] = f32_to_f16_bits(w);
+        } else {  // exact three-way bf16 split, round to nearest (w = b0 + b1 + b2)
+            const u16 b0 = f32_to_bf16_bits(w);
+            const float r1 = w - __uint_as_float((unsigned)b0 << 16);
+            const u16 b1 = f32_to_bf16_bits(r1);
+            const float r2 = r1 - __uint_as_float((unsigned)b1 << 16);
+            out[e] = b0;
+            out[total + e] = b1;
+            out[2 * total + e] = f32_to_bf16_bits(r2);
+        }
+    }
+}
+
+__global__ void k_f32_to_f16(const float* __restrict__ in, i64 n, u16* __restrict__ out) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f32_to_f16_bits(in[i]);
+}
+__global__ void k_f16_to_f32(const u16* __restrict__ in, i64 n, float* __restrict__ out) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)__builtin_bit_cast(_Float16, in[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel.  Block = WAVES waves, tile = WAVES*16 output rows x NT*16 columns; per (slot, KC-deep cin panel)
+// step the weight panel [planes][NCOL][KC] goes global -> registers -> LDS (XOR-swizzled 16-byte pieces,
+// conflict-free ds_read_b128), double buffered, with the same two-step register prefetch as k_sconv_mfma.
+// Lane (r = l & 15, g = l >> 4) gathers the 8 consecutive cin values c0 + 32 j + 8 g .. + 7 of its row's
+// neighbour: 16 bytes of f16, or 32 bytes of f32 that are split into three bf16 fragments in registers.
+// Importance (conv1b) is applied per (row, slot) on the accumulator side: the slot's products go to a
+// temporary accumulator that is scaled and added when the slot is finished -- exact f32 scaling in both
+// modes, no second A operand.
+// ------------------------------------------------------------------------------------------
+template <int KC>
+__device__ inline int swz(int col, int slot) {  // 16-byte piece index inside a panel row, swizzled
+    if (KC == 32) return slot ^ ((0x6C >> (2 * ((col >> 2) & 3))) & 3);
+    return slot ^ ((col >> 1) & 7);
+}
+
+template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16(
+        asr_sparse_conv_args a, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
+        const float* __restrict__ zeros) {
+    constexpr int TM = WAVES * 16;
+    constexpr int NTHR = WAVES * 64;
+    constexpr int NCOL = NT * 16;
+    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : 1;
+    constexpr int SLOTS = KC / 8;                 // 16-byte pieces per panel row
+    constexpr int NJ = KC / 32;                   // MFMA k-chunks per panel
+    constexpr int PV = PLANES * NCOL * SLOTS;     // 16-byte pieces per panel
+    constexpr int SV = (PV + NTHR - 1) / NTHR;
+    constexpr bool SV_EXACT = PV % NTHR == 0;
+    constexpr int PLANE_PIECES = NCOL * SLOTS;
+    constexpr int AW = MODE == ASR_CONV16_F16 ? 1 : 2;  // 16-byte loads per lane per k-chunk
+    __shared__ int s_nbr[TM * NBR_LD];
+    // per (row, slot) importance: only the single-bank IMP form keeps it in LDS.  The two-bank form reads
+    // inp_importance[neighbour] from global memory at the head of a slot's last step (80 KB of LDS per 8-wave
+    // block = two blocks per CU; with the table it was 108 KB and one block)
+    __shared__ float s_w[IMP ? TM * NBR_LD : 1];
+    __shared__ float s_norm[TM];
+    __shared__ int s_row[TM];
+    __shared__ unsigned long long s_mask[TM];
+    __shared__ __attribute__((aligned(16))) u32x4 s_B[2][PV];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nY = ctot_pad / NCOL;  // the launcher picks NT so that NCOL divides the padded width
+    i64 tile = blockIdx.x;
+    int ychunk = 0;
+    if (nY > 1) {  // column chunks of one row tile on one XCD, consecutive dispatch slots (see k_sconv_mfma)
+        const i64 r8 = blockIdx.x >> 3;
+        ychunk = (int)(r8 % nY);
+        tile = (r8 / nY) * 8 + (blockIdx.x & 7);
+    }
+    const i64 row0 = tile * TM;
+    if (row0 >= a.num_out) return;
+    const int n0 = ychunk * NCOL;
+    const int K = a.kernel_size;
+    const int cin = a.cin;
+    const int ca = a.cout;
+    const int cout = a.cout + (DUAL ? a.cout_b : 0);
+    const bool has_b = DUAL && ychunk == nY - 1;
+
+    for (int i = tid; i < TM * NBR_LD; i += NTHR) {
+        s_nbr[i] = -1;
+        if (IMP) s_w[i] = 0.f;
+    }
+    __syncthreads();
+    {
+        constexpr int TPR = NTHR / TM;
+        const int prow = tid / TPR, pj = tid % TPR;
+        i64 q = row0 + prow;
+        const bool valid = q < a.num_out;
+        if (valid && a.row_perm) q = a.row_perm[q];
+        unsigned long long m = 0;
+        float norm = 0.f;
+        if (valid) {
+            const i64 pe = a.neighbors_row_splits[q + 1];
+            for (i64 p = a.neighbors_row_splits[q] + pj; p < pe; p += TPR) {
+                int k = a.neighbors_kernel_index[p];
+                int32_t i = a.neighbors_index[p];
+                if (k >= K) continue;
+                s_nbr[prow * NBR_LD + k] = i;
+                m |= 1ull << k;
+                float w = 1.f;
+                if (IMP || DUAL) {
+                    w = a.neighbors_importance ? a.neighbors_importance[p] : a.inp_importance[i];
+                    if (IMP) s_w[prow * NBR_LD + k] = w;
+                }
+                norm += w;
+            }
+        } else {
+            q = -1;
+        }
+#pragma unroll
+        for (int o = 1; o < TPR; o <<= 1) {
+            m |= __shfl_xor(m, o, 64);
+            norm += __shfl_xor(norm, o, 64);
+        }
+        if (pj == 0) {
+            s_row[prow] = (int)q;
+            s_mask[prow] = m;
+            s_norm[prow] = norm;
+        }
+    }
+    __syncthreads();
+
+    const int r = lane & 15, g = lane >> 4;
+    const int lrow = wave * 16 + r;
+    unsigned long long wmask = s_mask[lrow];
+    unsigned long long bmask = s_mask[lane];
+    if (TM > 64) bmask |= s_mask[64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bmask |= __shfl_xor(bmask, o, 64);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) wmask |= __shfl_xor(wmask, o, 64);
+    wmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wmask) |
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wmask >> 32)) << 32);
+    bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
+    bmask &= (1ull << K) - 1;
+
+    f32x4 acc[NT];
+    f32x4 tacc[IMP ? NT : 1];  // per-slot accumulators of the importance-weighted bank
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (IMP ? NT : 1); ++t) tacc[t] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_b = {0.f, 0.f, 0.f, 0.f};  // DUAL: bank b of the last column tile
+
+    const int npanel = (cin + KC - 1) / KC;
+    const i64 plane_stride = (i64)K * ctot_pad * cin_pad;  // elements per weight plane
+
+#define ASR_SEQ_ADVANCE(todo, k, p)                          \
+    if ((k) >= 0 && ++(p) == npanel) {                       \
+        (p) = 0;                                             \
+        (todo) &= (todo)-1;                                  \
+        (k) = (todo) ? __builtin_ctzll(todo) : -1;           \
+    }
+    u32x4 stage0[SV], stage1[SV];
+    u32x4 a_q0[NJ * AW], a_q1[NJ * AW];
+
+    auto load_panel = [&](const int qk, const int qp, u32x4 (&st)[SV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            const int e = tid + s * NTHR;               // piece index: (plane, column, slot)
+            const int pl = e / PLANE_PIECES;
+            const int rem = e % PLANE_PIECES;
+            const int col = rem / SLOTS, slot = rem % SLOTS;
+            const int c = qp * KC + 8 * slot;
+            const bool ok = qk >= 0 && c < cin_pad && (SV_EXACT || e < PV);
+            const u16* src = packed + pl * plane_stride + ((i64)(qk < 0 ? 0 : qk) * ctot_pad + n0 + col) * cin_pad + c;
+            st[s] = *reinterpret_cast<const u32x4*>(ok ? (const void*)src : (const void*)zeros);
+        }
+    };
+    auto store_panel = [&](int buf, const u32x4 (&st)[SV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            const int e = tid + s * NTHR;
+            const int pl = e / PLANE_PIECES;
+            const int rem = e % PLANE_PIECES;
+            const int col = rem / SLOTS, slot = rem % SLOTS;
+            if (SV_EXACT || e < PV) s_B[buf][pl * PLANE_PIECES + col * SLOTS + swz<KC>(col, slot)] = st[s];
+        }
+    };
+    int cache_k = -2;
+    const char* cache_row = (const char*)zeros;
+    bool cache_valid = false;
+    constexpr int ESZ = MODE == ASR_CONV16_F16 ? 2 : 4;  // bytes per activation element
+    auto gather_a = [&](const int qk, const int qp, u32x4 (&aq)[NJ * AW]) __attribute__((always_inline)) {
+        if (qk != cache_k) {
+            cache_k = qk;
+            const int idx = qk < 0 ? -1 : s_nbr[lrow * NBR_LD + qk];
+            cache_valid = idx >= 0;
+            cache_row = (const char*)a.inp_features + (i64)(cache_valid ? idx : 0) * a.inp_ld * ESZ;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = qp * KC + 32 * j + 8 * g;
+#pragma unroll
+            for (int h = 0; h < AW; ++h) {
+                // cin % 8 == 0 (f16) / cin % 4 == 0 (f32): a 16-byte piece is inside or outside the row
+                const int cc = c + 4 * h;
+                const void* src = (cache_valid && cc < cin) ? (const void*)(cache_row + (i64)cc * ESZ) : (const void*)zeros;
+                aq[j * AW + h] = *reinterpret_cast<const u32x4*>(src);
+            }
+        }
+    };
+
+    unsigned long long todo1 = bmask;
+    int k_cur = bmask ? __builtin_ctzll(bmask) : -1, p_cur = 0;
+    int k1 = k_cur, p1 = 0;
+    ASR_SEQ_ADVANCE(todo1, k1, p1)
+    if (k_cur >= 0) {
+        load_panel(k_cur, p_cur, stage0);
+        gather_a(k_cur, p_cur, a_q0);
+        store_panel(0, stage0);
+        load_panel(k1, p1, stage1);
+        gather_a(k1, p1, a_q1);
+    }
+    __syncthreads();
+    int buf = 0;
+    const int ncol = lane & 15;
+    auto step = [&](u32x4 (&aq)[NJ * AW], u32x4 (&st_free)[SV], u32x4 (&st_next)[SV]) __attribute__((always_inline)) {
+        int k2 = k1, p2 = p1;
+        ASR_SEQ_ADVANCE(todo1, k2, p2)
+        u32x4 a_cur[NJ * AW];
+#pragma unroll
+        for (int j = 0; j < NJ * AW; ++j) a_cur[j] = aq[j];
+        store_panel(buf ^ 1, st_next);
+        load_panel(k2, p2, st_free);
+        gather_a(k2, p2, aq);
+        float w4[4] = {0.f, 0.f, 0.f, 0.f};  // importance of this lane's four accumulator rows for slot k_cur
+        if (DUAL && has_b && p_cur == npanel - 1 && ((wmask >> k_cur) & 1)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // issued here, consumed after the MFMAs of this step
+                const int idx = s_nbr[(wave * 16 + 4 * g + i) * NBR_LD + k_cur];
+                w4[i] = *(idx >= 0 ? a.inp_importance + idx : zeros);
+            }
+        }
+        if ((wmask >> k_cur) & 1) {
+            const u32x4* sb = s_B[buf];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (MODE == ASR_CONV16_F16) {
+                    const f16x8 af = __builtin_bit_cast(f16x8, a_cur[j]);
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        const int col = nb * 16 + ncol;
+                        const f16x8 bf = __builtin_bit_cast(f16x8, sb[col * SLOTS + swz<KC>(col, 4 * j + g)]);
+                        if (IMP) {
+                            tacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[nb], 0, 0, 0);
+                        } else {
+                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nb], 0, 0, 0);
+                            if (DUAL && has_b && nb == NT - 1)
+                                tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    // exact split of the 8 gathered f32 into three bf16 fragments: a0 = rn(a), a1 = rn(a - a0),
+                    // a2 = a - a0 - a1 (exactly representable: 24 = 8 + 8 + 8 mantissa bits).  Round to nearest
+                    // (v_cvt_pk_bf16_f32, two values per instruction) keeps the residuals signed, so the dropped
+                    // product terms do not add up to a bias.
+                    unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 v = {__uint_as_float(a_cur[j * 2 + (i >> 1)][2 * (i & 1)]),
+                                         __uint_as_float(a_cur[j * 2 + (i >> 1)][2 * (i & 1) + 1])};
+                        p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                        const f32x2 r1 = {v.x - __uint_as_float(p0[i] << 16), v.y - __uint_as_float(p0[i] & 0xffff0000u)};
+                        p1[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+                        const f32x2 r2 = {r1.x - __uint_as_float(p1[i] << 16), r1.y - __uint_as_float(p1[i] & 0xffff0000u)};
+                        p2[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+                    }
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, (u32x4){p0[0], p0[1], p0[2], p0[3]});
+                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, (u32x4){p1[0], p1[1], p1[2], p1[3]});
+                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, (u32x4){p2[0], p2[1], p2[2], p2[3]});
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        const int col = nb * 16 + ncol;
+                        const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
+                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);
+                        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);
+                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);
+                        // smallest terms first
+#define ASR_SIX(ACC_)                                                         \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ACC_, 0, 0, 0);
+                        if (IMP) {
+                            ASR_SIX(tacc[nb])
+                        } else {
+                            ASR_SIX(acc[nb])
+                            if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
+                        }
+#undef ASR_SIX
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            // end of a slot: scale the slot's importance-weighted products per row and fold them in
+            if ((IMP || DUAL) && p_cur == npanel - 1) {
+                if (IMP) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w4[i] = s_w[(wave * 16 + 4 * g + i) * NBR_LD + k_cur];
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[nb][i] += w4[i] * tacc[nb][i];
+                        tacc[nb] = {0.f, 0.f, 0.f, 0.f};
+                    }
+                } else if (has_b) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc_b[i] += w4[i] * tacc[0][i];
+                    tacc[0] = {0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+        k_cur = k1;
+        p_cur = p1;
+        k1 = k2;
+        p1 = p2;
+    };
+    while (k_cur >= 0) {
+        step(a_q0, stage0, stage1);
+        if (k_cur < 0) break;
+        step(a_q1, stage1, stage0);
+    }
+#undef ASR_SEQ_ADVANCE
+
+    // epilogue (as k_sconv_mfma): acc[nb][i] is C[row = 4 g + i][col = ncol] of the wave's 16 x 16 block
+    float bv[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        const int col = n0 + nb * 16 + ncol;
+        const float* bp = (a.bias && col < ca) ? a.bias + col : zeros;
+        if (DUAL && a.bias_b && col >= ca && col < cout) bp = a.bias_b + (col - ca);
+        bv[nb] = *bp;
+    }
+    const bool res16 = MODE == ASR_CONV16_F16;  // the residual has the activations' type
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lr = wave * 16 + 4 * g + i;
+        const i64 q = s_row[lr];
+        const bool rowok = q >= 0;
+        const float norm = s_norm[lr];
+        const bool do_norm = a.normalize && norm != 0.f;
+        float res[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
+            const bool ok = a.residual && rowok && col < cout;
+            if (res16) {
+                const u16* rp = ok ? (const u16*)a.residual + q * a.residual_ld + col : (const u16*)zeros;
+                res[nb] = (float)__builtin_bit_cast(_Float16, *rp);
+            } else {
+                const float* rp = ok ? a.residual + q * a.residual_ld + col : zeros;
+                res[nb] = *rp;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
+            float v = acc[nb][i];
+            if (DUAL) {
+                const bool colb = col >= ca;
+                if (nb == NT - 1 && has_b && colb) v = acc_b[i];
+                v = (colb && do_norm) ? v / norm : v;
+            } else {
+                v = do_norm ? v / norm : v;
+            }
+            v += bv[nb];
+            if (a.relu) v = fmaxf(v, 0.f);
+            v += res[nb];
+            if (rowok && col < cout) {
+                if (out_f16)
+                    ((u16*)a.out)[q * a.out_ld + col] = f32_to_f16_bits(v);
+                else
+                    a.out[q * a.out_ld + col] = v;
+            }
+        }
+    }
+    if (a.out_importance && ychunk == 0 && tid < TM && s_row[tid] >= 0)
+        a.out_importance[s_row[tid]] = s_norm[tid];
+}
+
+}  // namespace
+
+// ==========================================================================================
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+size_t asr_conv16_packed_bytes(int mode, int K, int cin, int cout, int cout_b) {
+    const size_t planes = mode == ASR_CONV16_BF16X3 ? 3 : 1;
+    return planes * (size_t)K * round_up(cout + cout_b, 16) * round_up(cin, 32) * sizeof(u16);
+}
+
+int asr_conv16_pack(asr_hip_context* ctx, int mode, const float* wa, const float* wb, int K, int cin, int ca, int cb,
+                    void* out) {
+    if (mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv_pack: mode must be ASR_CONV16_F16 or ASR_CONV16_BF16X3");
+    if (!wa || !out || K < 1 || K > 56 || cin < 1 || ca < 1 || cb < 0 || (cb > 0 && !wb))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv_pack: bad argument");
+    const int cin_pad = round_up(cin, 32), ctot_pad = round_up(ca + cb, 16);
+    const i64 total = (i64)K * ctot_pad * cin_pad;
+    k_pack_filters<<<(unsigned)std::min<i64>((total + 255) / 256, 65535), 256, 0, ctx->stream>>>(
+            wa, wb, K, cin, ca, cb, cin_pad, ctot_pad, mode, (u16*)out);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_conv16_convert(asr_hip_context* ctx, const void* in, i64 n, void* out, int to_f16) {
+    if (n <= 0) return ASR_HIP_OK;
+    if (to_f16)
+        k_f32_to_f16<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const float*)in, n, (u16*)out);
+    else
+        k_f16_to_f32<<<grid_for(n, 256), 256, 0, ctx->stream>>>((const u16*)in, n, (float*)out);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+// a: shapes, CSR, bias, flags as for asr_conv_sparse; in ASR_CONV16_F16 mode inp_features / residual (and out
+// when out_f16) point to f16 data, leading dimensions count elements.
+int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, const void* packed, int mode,
+                      int out_f16) {
+    asr_sparse_conv_args a = *pa;
+    if (a.num_out <= 0) return ASR_HIP_OK;
+    if (mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: unknown mode");
+    if (mode == ASR_CONV16_BF16X3 && out_f16) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: bf16x3 writes f32");
+    if (a.kernel_size < 1 || a.kernel_size > 56) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: kernel_size must be 1..56");
+    const bool dual = a.cout_b > 0;
+    const bool imp = a.inp_importance || a.neighbors_importance;
+    const int esz = mode == ASR_CONV16_F16 ? 2 : 4;
+    const int gran = 16 / esz;  // elements per 16-byte gather piece
+    if (a.cin % gran != 0 || a.inp_ld % gran != 0 || (uintptr_t)a.inp_features % 16 != 0 || (uintptr_t)packed % 16 != 0)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: cin and the row stride must be multiples of %d, 16-byte rows", gran);
+    if (dual && (!a.inp_importance || a.neighbors_importance || a.cout % 16 != 8 || a.cout_b != 8 || a.residual))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL,
+                 "sparse_conv16: second filter bank needs inp_importance (per input row), cout %% 16 == 8, cout_b == 8");
+    if (a.inp_ld < a.cin || a.out_ld < a.cout + a.cout_b)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: row stride smaller than channel count");
+    const float* zeros = nullptr;
+    ASR_TRY(asr_ctx_zeros(ctx, &zeros));
+    const int cin_pad = round_up(a.cin, 32), ctot_pad = round_up(a.cout + a.cout_b, 16);
+    // column tile: the widest of 128 / 64 / 32 / 16 that divides the padded width, narrowed while the launch
+    // has too few blocks (as asr_conv_sparse)
+    int nt = 8;
+    while (nt > 1 && ctot_pad % (nt * 16) != 0) nt >>= 1;
+    const i64 tiles64 = (a.num_out + 63) / 64;
+    if (a.force_nt) {
+        if ((a.force_nt != 1 && a.force_nt != 2 && a.force_nt != 4 && a.force_nt != 8) || ctot_pad % (a.force_nt * 16) != 0)
+            ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: force_nt must be 1, 2, 4 or 8 and divide the padded width");
+        nt = a.force_nt;
+    } else {
+        while (nt > 2 && tiles64 * (ctot_pad / (nt * 16)) < ctx->opt.sconv_min_blocks) nt >>= 1;
+    }
+    const i64 tiles128 = (a.num_out + 127) / 128;
+    bool wide = tiles128 * (ctot_pad / (nt * 16)) >= ctx->opt.sconv_wide_min;
+    if (a.force_waves) {
+        if (a.force_waves != 4 && a.force_waves != 8) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: force_waves must be 4 or 8");
+        wide = a.force_waves == 8;
+    }
+    const bool kc64 = mode == ASR_CONV16_F16 && cin_pad % 64 == 0;  // f16: 64-deep panels (bf16x3 panels carry 3 planes)
+#define ASR_L16(NT_, KC_, W_, M_, I_, D_)                                                                        \
+    {                                                                                                            \
+        const i64 tiles_ = (a.num_out + W_ * 16 - 1) / (W_ * 16);                                                \
+        const i64 ny_ = ctot_pad / (NT_ * 16);                                                                   \
+        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));                                  \
+        k_sconv_mfma16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                       \
+                a, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                                       \
+    }
+#define ASR_L16_ID(NT_, KC_, W_, M_) \
+    if (dual)                        \
+        ASR_L16(NT_, KC_, W_, M_, false, true) \
+    else if (imp)                    \
+        ASR_L16(NT_, KC_, W_, M_, true, false) \
+    else                             \
+        ASR_L16(NT_, KC_, W_, M_, false, false)
+#define ASR_L16_W(NT_, KC_, M_) \
+    if (wide)                   \
+        ASR_L16_ID(NT_, KC_, 8, M_) \
+    else                        \
+        ASR_L16_ID(NT_, KC_, 4, M_)
+#define ASR_L16_NT(KC_, M_)                 \
+    switch (nt) {                           \
+        case 8: ASR_L16_W(8, KC_, M_) break; \
+        case 4: ASR_L16_W(4, KC_, M_) break; \
+        case 2: ASR_L16_W(2, KC_, M_) break; \
+        default: ASR_L16_W(1, KC_, M_) break; \
+    }
+    if (mode == ASR_CONV16_F16) {
+        if (kc64)
+            ASR_L16_NT(64, ASR_CONV16_F16)
+        else
+            ASR_L16_NT(32, ASR_CONV16_F16)
+    } else {
+        ASR_L16_NT(32, ASR_CONV16_BF16X3)
+    }
+#undef ASR_L16_NT
+#undef ASR_L16_W
+#undef ASR_L16_ID
+#undef ASR_L16
+    ASR_CHECK_LAUNCH(ctx);
+    {
+        char key[64];  // NT,KC,IMP,WAVES,DUAL,MODE (k_sconv_mfma16 instance)
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
+                 dual ? 1 : 0, mode);
+        ++ctx->sconv_launches[key];
+    }
+    return ASR_HIP_OK;
+}

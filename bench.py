@@ -29,6 +29,18 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA (v_mfma_f32_16x16x4_f32) dense peak
+MFMA_16BIT_PEAK_TFLOPS = 2500.0  # bf16 / f16 MFMA dense peak (same guide)
+# dtype of the bench line, dense MFMA peak that prices the ALGORITHMIC flops of the sparse convs, kernel name
+PRECISION_INFO = {
+    "f32": ("f32", MFMA_F32_PEAK_TFLOPS, "k_sconv_mfma", "f32-input MFMA, exact"),
+    # six bf16 MFMAs per algorithmic product: the executed work is priced at the bf16 peak
+    # f32 in / f32 out with fp32-class error: priced against the f32 matrix peak like the exact f32 kernel; the
+    # executed work (6 bf16 MFMAs per product) is reported beside it
+    "bf16x3": ("f32", MFMA_F32_PEAK_TFLOPS, "k_sconv_mfma16<bf16x3>",
+               "dtype f32: f32-input MFMA dense peak; the kernel executes 6 bf16 MFMA products per algorithmic "
+               "product (bf16 dense peak %.0f TFLOP/s)" % MFMA_16BIT_PEAK_TFLOPS),
+    "f16": ("f16", MFMA_16BIT_PEAK_TFLOPS, "k_sconv_mfma16<f16>", "f16 MFMA dense peak"),
+}
 
 
 def conv_flops(sizes, shapes):
@@ -112,6 +124,26 @@ def cpu_baseline(n_sample, seed):
                       (n_sample, dt, {k: round(v, 2) for k, v in timings.items()})}
 
 
+def exact_f32_run(weights, dev, inputs, n, steps, shapes):
+    """Outside the timed region and not part of `value`: the same cloud through the f32-input MFMA kernel
+    (v_mfma_f32_16x16x4_f32, a bit-exact fmaf chain) -- the round-1 arithmetic, for comparison."""
+    from asr_hip.pipeline import ImplicitPipeline
+    pipe = ImplicitPipeline(weights, device=dev, precision="f32")
+    pipe.forward(*inputs)
+    torch.cuda.synchronize()
+    unet = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.forward(*inputs)
+        unet += pipe.stage_ms()["unet"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    flops, launches = conv_flops(pipe.sizes, shapes)
+    tf = flops / (unet / steps * 1e-3) / 1e12
+    return {"ms_per_step": dt / steps * 1e3, "points_per_s": n * steps / dt, "unet_ms": unet / steps,
+            "kernel": "k_sconv_mfma", "achieved_tflops": tf, "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
+
+
 def mesh_stage(pipe, synth):
     """Outside the timed region and not part of `value`: the stage after the path (dual cells, dual
     contouring, component filter) on the analytic signed distance of the synthetic scene -- random
@@ -191,6 +223,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the informational two-context run (profiling)")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16"], default=os.environ.get("ASR_BENCH_PRECISION", "bf16x3"),
+                    help="arithmetic of the 53 sparse convs: bf16x3 (default) = f32 in / f32 out, every operand split "
+                         "exactly into three bf16 terms, six bf16 MFMAs per product, f32 accumulate (fp32-class "
+                         "results, same parity bound as f32); f32 = f32-input MFMA, a bit-exact fmaf chain; "
+                         "f16 = f16 activations and weights (config C5)")
+    ap.add_argument("--no-exact-f32", action="store_true",
+                    help="skip the informational re-run of the same cloud on the f32-input MFMA kernel (profiling)")
+    ap.add_argument("--density-variance", type=float, default=1.0,
+                    help="10 = the mixed-density cloud of BASELINE config C5")
     ap.add_argument("--shard", choices=["replicas", "one-scan"], default="replicas",
                     help="replicas (default): one scan per GPU, no collective, weak scaling.  one-scan: ONE cloud of "
                          "--points points sharded over the GPUs by Morton range with halo exchange (RCCL), strong scaling")
@@ -220,7 +261,8 @@ def main():
     n = args.points
     one_scan = args.shard == "one-scan"
     # one-scan: every rank holds the same cloud (seed of rank 0); replicas: one scan per rank
-    pts, nrm = synth.scan_cloud(n, seed=rank_seed(0 if one_scan else rank), device=dev)
+    pts, nrm = synth.scan_cloud(n, seed=rank_seed(0 if one_scan else rank), device=dev,
+                                density_variance=args.density_variance)
     t_knn = time.perf_counter()
     radii = synth.knn_radii_gpu(pts, 24)  # pre-filter row D.4 on the GPU, untimed input preparation
     torch.cuda.synchronize()
@@ -232,7 +274,7 @@ def main():
         sharded = ShardedImplicitPipeline(weights, dev)
         pipe = sharded.pipe
     else:
-        pipe = ImplicitPipeline(weights, device=dev)
+        pipe = ImplicitPipeline(weights, device=dev, precision=args.precision)
     shapes = synth.unet5_param_shapes(1)
 
     def barrier():
@@ -272,6 +314,9 @@ def main():
     if world == 1 and not args.no_pipelined:
         pipelined = pipelined_rate(pipe, weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(4, 2 * args.steps))
 
+    exact = None
+    if world == 1 and args.precision == "bf16x3" and not args.no_exact_f32:
+        exact = exact_f32_run(weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(args.steps, 2), shapes)
     if rank == 0:
         steps = max(args.steps, 1)
         ms = dt / steps * 1e3
@@ -279,7 +324,8 @@ def main():
         flops, launches = conv_flops(pipe.sizes, shapes)
         unet_s = stage_ms["unet"] * 1e-3
         achieved = flops / unet_s / 1e12 if unet_s > 0 else 0.0
-        tr = pmc_traffic(n)
+        tr = pmc_traffic(n) if args.precision == "f32" and args.density_variance == 1.0 else None
+        dtype, peak, kname, peak_note = PRECISION_INFO[args.precision]
         out = {
             "metric": "input points/sec to signed implicit values",
             "value": job_value(world, n, steps, dt),
@@ -291,10 +337,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": "C3: %d-point scan-like synthetic cloud per GPU, radii = 24-NN, "
-                                   "5 grid levels, UNet5 default.yaml widths, seeded random weights" % n,
+            "config": {"workload": "%s: %d-point scan-like synthetic cloud per GPU%s, radii = 24-NN, "
+                                   "5 grid levels, UNet5 default.yaml widths, seeded random weights"
+                                   % ("C5" if args.precision == "f16" and args.density_variance >= 10 else "C3", n,
+                                      " (density variance %gx)" % args.density_variance
+                                      if args.density_variance != 1.0 else ""),
+                       "precision": args.precision,
                        "points_per_gpu": n,
                        "voxels": [int(v) for v in pipe.sizes.num_voxels],
                        "pairs": [int(v) for v in pipe.sizes.num_pairs],
@@ -303,13 +353,17 @@ def main():
                        "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                        "untimed_knn24_radii_ms": round(t_knn * 1e3, 1),
                        "untimed_mesh_stage": mesh_info,
-                       "untimed_pipelined_two_contexts": pipelined},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                       "untimed_pipelined_two_contexts": pipelined,
+                       "untimed_exact_f32_kernel": exact},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
+                         "executed_bf16_mfma_tflops": 6 * achieved if args.precision == "bf16x3" else None,
+                         "executed_frac_of_bf16_peak": 6 * achieved / MFMA_16BIT_PEAK_TFLOPS
+                         if args.precision == "bf16x3" else None,
                          "traffic": tr[0] if tr else None,
                          "traffic_note": ("HBM bytes per launch, rocprofv3 PMC passes in profiles/%s" % tr[1]) if tr else None,
-                         "kernel": "k_sconv_mfma (%d launches/step, %.3f ms avg, %.1f algorithmic "
-                                   "GFLOP/step)" % (launches, stage_ms["unet"] / launches, flops / 1e9)},
+                         "kernel": "%s (%d launches/step, %.3f ms avg, %.1f algorithmic "
+                                   "GFLOP/step)" % (kname, launches, stage_ms["unet"] / launches, flops / 1e9)},
         }
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)

@@ -249,6 +249,27 @@ int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* ar
  * (template instance k_sconv_mfma<NT,KC,IMP,WAVES,DUAL> -> number of launches), NUL terminated. */
 int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t cap, int reset);
 
+/* ---- a12 on the 16-bit matrix cores (v_mfma_f32_16x16x32_{f16,bf16}) --------------------------------
+ * ASR_CONV16_F16 (BASELINE config C5, "fp16 features"): activations in HBM are f16, weights are rounded to
+ *   f16 once, products accumulate in f32.  In args, inp_features / residual / out point to f16 data (out: f32
+ *   when out_is_f16 == 0), leading dimensions count elements; importance, bias and out_importance stay f32.
+ * ASR_CONV16_BF16X3: f32 activations and weights; every operand is split exactly into three bf16 terms and
+ *   the product is evaluated with six bf16 MFMAs, f32 accumulate -- fp32-class results (error of the dropped
+ *   terms < 2^-23 per product) at 2.7x the f32 matrix peak.  args as for asr_hip_sparse_conv_f32.
+ * Both take the filters re-packed by asr_hip_sparse_conv_pack ([plane][K][cout padded to 16][cin padded to
+ * 32], 16-bit; bank b appended as columns); args->filters / filters_b are ignored, cout_b > 0 selects the
+ * two-bank form.  cin and the row strides must be multiples of 8 (f16) / 4 (f32) elements. */
+#define ASR_CONV16_F16 1
+#define ASR_CONV16_BF16X3 2
+size_t asr_hip_sparse_conv_packed_bytes(int mode, int kernel_size, int cin, int cout, int cout_b);
+int asr_hip_sparse_conv_pack(asr_hip_context* ctx, int mode, const float* filters_dev, const float* filters_b_dev,
+                             int kernel_size, int cin, int cout, int cout_b, void* packed_out_dev);
+int asr_hip_sparse_conv_f16(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed_dev,
+                            int out_is_f16);
+int asr_hip_sparse_conv_bf16x3(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed_dev);
+/* f32 <-> f16 conversion of an activation buffer (n elements) */
+int asr_hip_convert_f16(asr_hip_context* ctx, const void* in_dev, int64_t n, void* out_dev, int to_f16);
+
 /* MFMA tiling order for asr_hip_sparse_conv_f32: reorders the rows of a CSR inside segments of
  * `segment_rows` consecutive rows (0 = default) by their set of kernel slots, so that 16-row MFMA
  * tiles see few distinct slots. perm_out_dev [num_rows] goes into asr_sparse_conv_args.row_perm. */
@@ -294,6 +315,9 @@ typedef struct asr_implicit_params {
     float bb_min[3];          /* bounding box handed to CreateOctreeFromPoints              */
     float bb_max[3];
     int scale_sdf;            /* 1: values[:,0] *= voxel_size (asr.cpp:334-336)             */
+    int precision;            /* arithmetic of the 53 sparse convs: 0 = exact f32 MFMA (default),
+                                 ASR_CONV16_F16 = f16 activations + weights (config C5),
+                                 ASR_CONV16_BF16X3 = fp32-class result on the bf16 matrix cores  */
 } asr_implicit_params;
 
 /* sizes of the structures built by the last asr_hip_implicit_* call */

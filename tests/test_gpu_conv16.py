@@ -1,0 +1,174 @@
+"""GPU parity of the 16-bit matrix-core variants of row a12 (asr_hip_sparse_conv_f16 / _bf16x3;
+SpecialSparseConv.forward, /root/reference/models/common_torch.py:95-148).
+
+bf16x3 ("fp32-class results from bf16 MFMAs"): compared with the oracle at the north_star tolerance,
+1e-5, like the f32 kernel.
+f16 (BASELINE config C5, "fp16 features"): the oracle runs in its precise mode on the SAME f16-rounded
+activations and weights, so what is left is the accumulation order and, for f16 outputs, the final
+rounding: tolerance 2e-3 relative to the tensor's range for f16 outputs (f16 has 11 significant bits:
+half an ulp is 4.9e-4), 1e-5 for f32 outputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from asr_hip import synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+_close = parity.assert_close
+_close_scaled = parity.assert_close_scaled
+
+
+def _t(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def _h(a):
+    """round to f16 and back: what an f16 buffer holds"""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def geo():
+    p, q = synth.scan_cloud(20000, seed=21, device="cpu")
+    pts = p.numpy()
+    rad = synth.knn_radii(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    return parity.oracle_geometry(pts, rad, *bb)
+
+
+def _csr(item, kind, level):
+    if kind == "nb":
+        rs = item["neighbors_row_splits%d" % level]
+        return item["neighbors_index%d" % level], item["neighbors_kernel_index%d" % level], rs, len(rs) - 1
+    rs = item["up_neighbors_row_splits%d" % level]
+    return (item["up_neighbors_index%d" % level], item["up_neighbors_kernel_index%d" % level], rs,
+            len(item["voxel_sizes%d" % (level + 1)]))
+
+
+# (kind, level, K, cin, cout_a, cout_b, force_nt, force_waves)
+SHAPES = [
+    ("nb", 0, 55, 32, 56, 8, 0, 0), ("nb", 0, 55, 64, 64, 0, 4, 8), ("nb", 0, 55, 64, 32, 0, 2, 4),
+    ("nb", 1, 55, 128, 120, 8, 8, 8), ("nb", 1, 55, 128, 128, 0, 8, 4), ("nb", 1, 55, 384, 128, 0, 4, 8),
+    ("nb", 2, 55, 256, 248, 8, 8, 4), ("nb", 2, 55, 512, 256, 0, 8, 8), ("up", 1, 9, 256, 256, 0, 0, 0),
+    ("nb", 3, 55, 256, 256, 0, 2, 4), ("nb", 2, 55, 40, 16, 0, 1, 4), ("nb", 1, 55, 8, 24, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%s%d-%dx%d+%d-nt%dw%d" % (s[0], s[1], s[3], s[4], s[5], s[6], s[7]))
+def test_sparse_conv16_vs_oracle(geo, gpu, mode, shape):
+    from asr_hip import ops
+    kind, level, K, cin, ca, cb, nt, waves = shape
+    if mode == "bf16x3" and cin % 4:
+        pytest.skip("f32 rows need cin % 4 == 0")
+    idx, kidx, rs, num_inp = _csr(geo, kind, level)
+    v = len(rs) - 1
+    rng = np.random.default_rng(cin * 31 + ca + level)
+    occ = 8.0 if K == 55 else 1.0
+    f = rng.standard_normal((num_inp, cin)).astype(np.float32)
+    Wa = (rng.standard_normal((K, cin, ca)) * np.sqrt(2.0 / (occ * cin))).astype(np.float32)
+    ba = (rng.standard_normal(ca) * 0.1).astype(np.float32)
+    imp = rng.uniform(0.05, 1.0, size=num_inp).astype(np.float32)
+    nimp = imp[idx.astype(np.int64)]
+    Wb = (rng.standard_normal((K, cin, cb)) * np.sqrt(2.0 / (occ * cin))).astype(np.float32) if cb else None
+    bb = (rng.standard_normal(cb) * 0.1).astype(np.float32) if cb else None
+    f16 = mode == "f16"
+    act = torch.float16 if f16 else torch.float32
+    # what the kernel sees: f16 mode rounds activations and weights to f16
+    fq, Wa_q, Wb_q = (_h(f), _h(Wa), _h(Wb) if cb else None) if f16 else (f, Wa, Wb)
+    packed = ops.pack_filters(_t(Wa, gpu), mode, _t(Wb, gpu) if cb else None)
+    ctx = ops.context(gpu)
+    ctx.sconv_variant_counts(reset=True)
+    kw = dict(bias=_t(ba, gpu), relu=True, force_nt=nt, force_waves=waves)
+    with O.precise():
+        ref_a = np.maximum(O.sparse_conv(Wa_q, fq, idx, kidx, None, rs, False) + ba, 0)
+        if cb:
+            ref_b = np.maximum(O.sparse_conv(Wb_q, fq, idx, kidx, nimp, rs, True) + bb, 0)
+            ref = np.concatenate([ref_a, ref_b], 1)
+        else:
+            ref = ref_a
+        ref_imp = np.maximum(O.sparse_conv(Wa_q, fq, idx, kidx, nimp, rs, True) + ba, 0)
+    # f32 output: accumulation order only
+    if cb:
+        out, oimp = ops.sparse_conv16(mode, packed, K, cin, ca, _t(f, gpu).to(act), _t(idx, gpu), _t(kidx, gpu),
+                                      _t(rs, gpu), inp_importance=_t(imp, gpu), normalize=True, cout_b=cb,
+                                      bias_b=_t(bb, gpu), return_importance=True, out_dtype=torch.float32, **kw)
+        _close(oimp.cpu().numpy(), O.reduce_subarrays_sum(nimp, rs))
+    else:
+        out = ops.sparse_conv16(mode, packed, K, cin, ca, _t(f, gpu).to(act), _t(idx, gpu), _t(kidx, gpu),
+                                _t(rs, gpu), out_dtype=torch.float32, **kw)
+    assert out.dtype == torch.float32
+    _close(out.cpu().numpy(), ref)
+    key = list(ctx.sconv_variant_counts())
+    assert len(key) == 1 and key[0][5] == (1 if f16 else 2) and (nt == 0 or key[0][0] == nt)
+    if not cb:
+        # importance weighted + normalised single bank (conv1b alone), residual after the activation
+        res = rng.standard_normal((v, ca)).astype(np.float32)
+        out2, oimp = ops.sparse_conv16(mode, packed, K, cin, ca, _t(f, gpu).to(act), _t(idx, gpu), _t(kidx, gpu),
+                                       _t(rs, gpu), inp_importance=_t(imp, gpu), normalize=True,
+                                       residual=_t(res, gpu).to(act), return_importance=True,
+                                       out_dtype=torch.float32, **kw)
+        _close(out2.cpu().numpy(), ref_imp + (_h(res) if f16 else res))
+        _close(oimp.cpu().numpy(), O.reduce_subarrays_sum(nimp, rs))
+    if f16:
+        # f16 output (activations stay f16 in HBM): the f32 result rounded once
+        o16 = ops.sparse_conv16(mode, packed, K, cin, ca, _t(f, gpu).to(act), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu),
+                                inp_importance=_t(imp, gpu) if cb else None, normalize=bool(cb), cout_b=cb,
+                                bias_b=_t(bb, gpu) if cb else None, **kw)
+        assert o16.dtype == torch.float16
+        got = o16.float().cpu().numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(got - ref).max() <= 2e-3 * scale
+        # and bit-identical to rounding the kernel's own f32 result
+        assert torch.equal(o16, out.to(torch.float16))
+
+
+def test_bf16x3_split_is_exact(gpu):
+    """a = a0 + a1 + a2 exactly for every finite f32 (a0 = rn(a), a1 = rn(a - a0), a2 = the rest): a 1 x 1
+    'convolution' with one neighbour per row and an identity filter returns its input bit for bit"""
+    from asr_hip import ops
+    rng = np.random.default_rng(0)
+    v, c = 4096, 32
+    f = (rng.standard_normal((v, c)) * np.exp(rng.uniform(-20, 20, size=(v, c)))).astype(np.float32)
+    W = np.zeros((1, c, c), np.float32)
+    W[0] = np.eye(c, dtype=np.float32)
+    idx = np.arange(v, dtype=np.int32)
+    kidx = np.zeros(v, np.uint8)
+    rs = np.arange(v + 1, dtype=np.int64)
+    packed = ops.pack_filters(_t(W, gpu), "bf16x3")
+    out = ops.sparse_conv16("bf16x3", packed, 1, c, c, _t(f, gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), f.view(np.uint32))
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-5), ("f16", 5e-3)])
+def test_whole_path_precisions(gpu, precision, tol):
+    """asr_implicit_params.precision.  bf16x3: implicit values within 1e-5 of the range, like f32.
+    f16 (config C5): f16 activations through 53 layers; bound 5e-3 of the range against the exact oracle
+    (every layer rounds its output to 11 bits: 4.9e-4 per rounding; measured 1.9e-3), on the mixed-density
+    cloud of that config."""
+    from asr_hip.pipeline import ImplicitPipeline
+    p, q = synth.scan_cloud(20000, seed=41, device="cpu", density_variance=10.0)
+    pts, nrm = p.numpy(), q.numpy()
+    rad = synth.knn_radii(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    weights = synth.make_weights(channel_div=1, seed=8)
+    with O.precise():
+        ref = parity.oracle_forward(pts, nrm, rad, bb[0], bb[1], weights)
+    pipe = ImplicitPipeline(weights, device=gpu, precision=precision)
+    pipe.ctx.sconv_variant_counts(reset=True)
+    values = pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
+    counts = pipe.ctx.sconv_variant_counts()
+    assert sum(counts.values()) == 44 and all(len(k) == 6 and k[5] == (2 if precision == "bf16x3" else 1) for k in counts)
+    assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), ref["voxel_keys0"])
+    for name, got in (("code", pipe.get("code")), ("values", values)):
+        scale = max(1.0, float(np.abs(ref[name]).max()))
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - ref[name]).max())
+        print("%s %s: max err %.3e, range %.3g" % (precision, name, err, scale))
+        assert err <= tol * scale, (name, err, scale)
+    # deterministic
+    v2 = pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
+    assert torch.equal(values, v2)

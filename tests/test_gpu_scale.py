@@ -103,6 +103,13 @@ def test_one_million_points_full_width_vs_oracle(gpu):
     from sconv_instances import BENCH_INSTANCES
     wide = {i for i in BENCH_INSTANCES if i[3] == 8}
     assert wide <= seen, (wide - seen, seen)
+    # the same bound for the bf16x3 arithmetic (six bf16 MFMAs per product, fp32-class result)
+    pipe3 = ImplicitPipeline(weights, device=gpu, precision="bf16x3")
+    values = pipe3.forward(pts, nrm, radii, bb[0], bb[1])
+    for k, got in (("code", pipe3.get("code")), ("values", values)):
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - ref[k]).max())
+        print("bf16x3 %s: GPU vs exact %.3e (bound %.3e)" % (k, err, tol[k]))
+        assert err <= tol[k], (k, err, tol[k])
 
 
 def test_ten_million_points_single_layers_vs_oracle(gpu):

@@ -31,14 +31,20 @@ def _u64(t):
     return t.cpu().numpy().view(np.uint64)
 
 
-class Octree:
-    """Opaque handle returned by create_octree (module.cpp:282): sorted node and leaf keys stay on
-    the GPU together with the octree frame."""
+def get_third_party_notices():
+    """cpp/pybind/module.cpp:287-289.  The reference returns the licence texts of the libraries linked into its
+    binary (Eigen, libcuckoo, nanoflann, TBB, Open3D, PyTorch); none of those is linked into libasr_hip.so."""
+    return ("libasr_hip.so links the ROCm runtime (HIP) and uses the header-only rocPRIM (MIT licence, "
+            "Copyright (c) Advanced Micro Devices, Inc.).  PyTorch (BSD-3-Clause) provides device memory and "
+            "torch.distributed on the host side.  No code of the reference implementation or of its "
+            "third-party dependencies is included.")
 
-    _last = None
+
+class Octree:
+    """Opaque handle returned by create_octree (module.cpp:282): owns the sorted node and leaf keys (GPU
+    tensors) and the octree frame, so it stays valid however many trees are built afterwards."""
 
     def __init__(self, frame, nodes, leaves):
-        Octree._last = self
         self.frame = frame
         self.nodes = nodes
         self.leaves = leaves
@@ -111,11 +117,8 @@ def compute_aggregation_neighbors(tree, points, radii, voxel_centers, voxel_size
 
 def create_dual_vertex_indices(tree):
     """module.cpp:230-235,443-453 -> asr::CreateDualVertexIndices (cpp/lib/grid.cpp:450-459):
-    uint64 [D,8] indices into the leaves.  Must be called while `tree` is the octree built last on
-    this process' context (the node set lives there)."""
-    if tree is not Octree._last:
-        raise RuntimeError("create_dual_vertex_indices needs the most recently created octree")
-    return _ops.dual_cells(tree.leaves.device).cpu().numpy().astype(np.uint64)
+    uint64 [D,8] indices into the leaves, for any live tree (models/v0/datareader.py:224-243 keeps several)."""
+    return _ops.dual_cells(tree.leaves.device, nodes=tree.nodes, leaves=tree.leaves).cpu().numpy().astype(np.uint64)
 
 
 def create_triangle_mesh(values, dual_vertex_indices, node_positions, contouring_value_threshold=1.0):
@@ -157,9 +160,10 @@ def _load_weights(weights):
                 return {k: z[k] for k in z.files}
         try:  # the reference ships a TorchScript archive (model.pt, cpp/lib/asr.cpp:138-139)
             sd = torch.jit.load(weights, map_location="cpu")
-        except Exception:
+        except RuntimeError:  # not a TorchScript archive: a pickled state dict
             sd = torch.load(weights, map_location="cpu")
-        return dict(sd.state_dict()) if hasattr(sd, "state_dict") else sd
+        sd = dict(sd.state_dict()) if hasattr(sd, "state_dict") else dict(sd)
+        return {k: v for k, v in sd.items() if isinstance(v, torch.Tensor)}
     return weights
 
 

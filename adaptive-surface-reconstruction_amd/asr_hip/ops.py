@@ -87,16 +87,21 @@ def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
     return nodes, leaves
 
 
-def dual_cells(device, ctx=None):
-    """dual_vertex_indices [D,8] (int64) of the octree built last on this context"""
+def dual_cells(device, ctx=None, nodes=None, leaves=None):
+    """dual_vertex_indices [D,8] (int64): of the octree built last on this context, or of the octree given by
+    its sorted node / leaf key tensors (any tree that is still alive)"""
     ctx = ctx or context(device)
     d = i64(0)
-    ctx.call("asr_hip_dual_cells_count", ctypes.byref(d))
+    if nodes is not None:
+        nodes, leaves = _dev(nodes, torch.int64), _dev(leaves, torch.int64)
+        ctx.call("asr_hip_dual_cells_count_for", ptr(nodes), i64(nodes.shape[0]), ptr(leaves), i64(leaves.shape[0]),
+                 ctypes.byref(d))
+    else:
+        ctx.call("asr_hip_dual_cells_count", ctypes.byref(d))
     out = torch.empty((d.value, 8), dtype=torch.int64, device=device)
     if d.value:
         ctx.call("asr_hip_dual_cells_fill", ptr(out))
     return out
-
 
 
 def contour(values, dual_vertex_indices, node_positions, threshold=1.0, ctx=None):

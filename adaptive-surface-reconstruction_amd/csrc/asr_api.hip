@@ -244,7 +244,14 @@ int asr_hip_unordered_set_order(const uint32_t* xs, int n, uint32_t* out) {
 int asr_hip_dual_cells_count(asr_hip_context* ctx, int64_t* num_cells) {
     CTX_GUARD(ctx);
     if (!num_cells) ASR_FAIL(ctx, ASR_HIP_EINVAL, "dual_cells_count: null argument");
-    return asr_geom_dual_count(ctx, num_cells);
+    return asr_geom_dual_count(ctx, ctx->nodes, ctx->num_nodes, ctx->leaves, ctx->num_leaves, num_cells);
+}
+int asr_hip_dual_cells_count_for(asr_hip_context* ctx, const uint64_t* nodes, int64_t num_nodes,
+                                 const uint64_t* leaves, int64_t num_leaves, int64_t* num_cells) {
+    CTX_GUARD(ctx);
+    if (!num_cells || num_nodes < 0 || num_leaves < 0 || (num_leaves > 0 && (!nodes || !leaves)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "dual_cells_count_for: null argument");
+    return asr_geom_dual_count(ctx, nodes, num_nodes, leaves, num_leaves, num_cells);
 }
 int asr_hip_dual_cells_fill(asr_hip_context* ctx, int64_t* out) {
     CTX_GUARD(ctx);

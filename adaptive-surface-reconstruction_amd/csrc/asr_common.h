@@ -272,7 +272,8 @@ int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame*
 int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts, i64 n, int k,
                  const float* radii_in, float radius_fraction, int outlier_threshold, float* radii_out,
                  uint8_t* inlier_out);
-int asr_geom_dual_count(asr_hip_context* ctx, i64* num_cells);
+int asr_geom_dual_count(asr_hip_context* ctx, const u64* nodes, i64 num_nodes, const u64* leaves, i64 num_leaves,
+                        i64* num_cells);
 int asr_geom_dual_fill(asr_hip_context* ctx, i64* out);
 int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, const i64* rs,
                     i64 num_rows, const uint8_t* attr, int32_t* out_idx, i64* out_rs,

@@ -1418,6 +1418,8 @@ struct RadiusState {
     int32_t* heavy = nullptr;  // rows with more than RADIUS_LIGHT hits or RADIUS_GIANT candidates
     uint8_t* is_heavy = nullptr;
     i64 num_heavy = 0;
+    const u64* dual_leaves = nullptr;  // leaf array of the pending dual-cell count / fill pair
+    i64 dual_nl = 0;
 };
 static RadiusState& rstate(asr_hip_context* ctx) {
     if (!ctx->radius_state) ctx->radius_state = new RadiusState();
@@ -1646,10 +1648,12 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
 
 // Dual cells of the LAST octree build (ctx->nodes / ctx->leaves).  count: number of cells; fill:
 // [D,8] leaf indices, leaf order x corner order.
-int asr_geom_dual_count(asr_hip_context* ctx, i64* num_cells) {
+int asr_geom_dual_count(asr_hip_context* ctx, const u64* nodes, i64 nn, const u64* leaves, i64 nl, i64* num_cells) {
     ASR_TRY(ensure_flags(ctx));
     *num_cells = 0;
-    const i64 nn = ctx->num_nodes, nl = ctx->num_leaves;
+    RadiusState& st0 = rstate(ctx);
+    st0.dual_leaves = leaves;
+    st0.dual_nl = nl;
     if (nl <= 0) return ASR_HIP_OK;
     ctx->scratch.reset();
     HashTab t;
@@ -1660,15 +1664,15 @@ int asr_geom_dual_count(asr_hip_context* ctx, i64* num_cells) {
     int32_t* keep = t.vals;
     t.vals = arena_alloc<int32_t>(ctx->scratch, cap);  // throw-away values for the node pass
     if (!t.vals) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_map_build<<<grid_for(nn, BLK), BLK, 0, ctx->stream>>>(ctx->nodes, nn, t, ctx->d_flags);
+    k_map_build<<<grid_for(nn, BLK), BLK, 0, ctx->stream>>>(nodes, nn, t, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     t.vals = keep;
-    k_map_build<<<grid_for(nl, BLK), BLK, 0, ctx->stream>>>(ctx->leaves, nl, t, ctx->d_flags);
+    k_map_build<<<grid_for(nl, BLK), BLK, 0, ctx->stream>>>(leaves, nl, t, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     i64* counts = arena_alloc<i64>(ctx->scratch, nl + 1);
     i64* offsets = arena_alloc<i64>(ctx->scratch, nl + 1);
     if (!counts || !offsets) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_dual_count<<<grid_for(nl + 1, BLK), BLK, 0, ctx->stream>>>(ctx->leaves, nl, t, counts);
+    k_dual_count<<<grid_for(nl + 1, BLK), BLK, 0, ctx->stream>>>(leaves, nl, t, counts);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, offsets, nl + 1));
     ASR_TRY(read_i64(ctx, offsets + nl, num_cells));
@@ -1681,11 +1685,11 @@ int asr_geom_dual_count(asr_hip_context* ctx, i64* num_cells) {
 }
 int asr_geom_dual_fill(asr_hip_context* ctx, i64* out) {
     RadiusState& st = rstate(ctx);
-    const i64 nl = ctx->num_leaves;
+    const i64 nl = st.dual_nl;
     if (nl <= 0) return ASR_HIP_OK;
     if (st.v != -nl) ASR_FAIL(ctx, ASR_HIP_EINVAL, "dual_fill must follow the matching dual_count call");
     int host[16];
-    k_dual_fill<<<grid_for(nl, BLK), BLK, 0, ctx->stream>>>(ctx->leaves, nl, st.tab, (const i64*)st.start, out,
+    k_dual_fill<<<grid_for(nl, BLK), BLK, 0, ctx->stream>>>(st.dual_leaves, nl, st.tab, (const i64*)st.start, out,
                                                             ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(read_flags(ctx, host));

@@ -314,6 +314,12 @@ def main():
     if world == 1 and not args.no_pipelined:
         pipelined = pipelined_rate(pipe, weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(4, 2 * args.steps))
 
+    # raw-scan rate (outside `value`: the metric takes radii as inputs): the exact 24-NN radius
+    # estimate of the pre-filter (cpp/lib/preprocess.cpp:25-39) on the GPU, steady state (second call), + one step
+    t_knn2 = time.perf_counter()
+    synth.knn_radii_gpu(pts, 24)
+    torch.cuda.synchronize()
+    t_knn2 = time.perf_counter() - t_knn2
     exact = None
     if world == 1 and args.precision == "bf16x3" and not args.no_exact_f32:
         exact = exact_f32_run(weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(args.steps, 2), shapes)
@@ -352,6 +358,10 @@ def main():
                        "parallelism": "one scan per GPU, no collective on the data path",
                        "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                        "untimed_knn24_radii_ms": round(t_knn * 1e3, 1),
+                       "untimed_raw_scan": {"knn24_radii_ms_steady": round(t_knn2 * 1e3, 1),
+                                            "points_per_s_with_knn_radii": n / (t_knn2 + dt / steps),
+                                            "note": "pre-filter radius estimate + one step; radii are inputs of the "
+                                                    "metric, this is the rate from a raw scan"},
                        "untimed_mesh_stage": mesh_info,
                        "untimed_pipelined_two_contexts": pipelined,
                        "untimed_exact_f32_kernel": exact},

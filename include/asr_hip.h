@@ -100,6 +100,11 @@ int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out_dev, uint64_t* 
  * count returns the number of dual cells D; fill writes [D,8] leaf indices (leaf order x corner
  * order), the `dual_vertex_indices` consumed by CreateTriangleMesh (cpp/lib/asr.cpp:154,340). */
 int asr_hip_dual_cells_count(asr_hip_context* ctx, int64_t* num_cells);
+/* the same for ANY octree given by its sorted node / leaf keys (asr_hip_octree_get): the pybind Octree handle
+ * (cpp/pybind/module.cpp:230-235) stays usable however many trees were built since.  The arrays must stay valid
+ * until the fill call. */
+int asr_hip_dual_cells_count_for(asr_hip_context* ctx, const uint64_t* nodes_dev, int64_t num_nodes,
+                                 const uint64_t* leaves_dev, int64_t num_leaves, int64_t* num_cells);
 int asr_hip_dual_cells_fill(asr_hip_context* ctx, int64_t* dual_vertex_indices_out_dev);
 
 /* ---- dual contouring ("next" row D.2): asr::CreateTriangleMesh (cpp/lib/contouring.cpp:29-460) ---- */

@@ -113,7 +113,66 @@ def run(tag, n, channel_div, seed):
     print("   wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_layers(tag, n, channel_div, seed):
+    """every SpecialSparseConv call of the reference graph (models/common_torch.py:95-148, 53 calls: down3 runs
+    twice) with its own inputs and outputs, so that each call is a separate check of the sparse conv kernels:
+    layer<i>_{name, kernel_size, level_out, level_in, in, imp, out, oimp}; geometry is not stored (the oracle
+    rebuilds it from points / radii / bbox, pinned by tests/golden/micro_trees.py and the other fixtures)."""
+    from models.common_torch import SpecialSparseConv  # reference, unchanged
+    pts, nrm = synth.scan_cloud(n, seed=seed, device="cpu")
+    points, normals = pts.numpy(), nrm.numpy()
+    radii = synth.knn_radii(points, 24)
+    bb_min, bb_max = synth.bounding_box(points, 0.1)
+    item, _ = build_item(points, normals, radii, bb_min, bb_max)
+    weights = synth.make_weights(channel_div, seed=seed)
+    model = UNet5(channel_div=channel_div, with_importance="all", normalized_channels=8,
+                  residual_skip_connection=True).eval()
+    sd = model.state_dict()
+    for name, w in weights.items():
+        if name.startswith("dense_decoder"):
+            continue
+        sd[name].copy_(torch.from_numpy(w))
+    v = [len(item["voxel_sizes%d" % i]) for i in range(5)]
+    assert len(set(v)) == 5, v  # levels are told apart by their row counts
+    calls = []
+
+    def hook(name):
+        def f(mod, args, kwargs, out):  # the model calls the layers with a mix of positional / keyword arguments
+            names = ("inp_features", "neighbors_index", "neighbors_kernel_index", "neighbors_row_splits",
+                     "inp_importance")
+            a = dict(zip(names, args))
+            a.update(kwargs)
+            feats, rs, imp = a["inp_features"], a["neighbors_row_splits"], a.get("inp_importance")
+            calls.append(dict(name=name, kernel_size=int(mod.kernel_size), level_out=v.index(rs.shape[0] - 1),
+                              level_in=v.index(feats.shape[0]), inp=feats.numpy().copy(),
+                              imp=imp.numpy().copy() if imp is not None else np.zeros(0, np.float32),
+                              out=out[0].numpy().copy(), oimp=out[1].numpy().copy()))
+        return f
+
+    for name, mod in model.named_modules():
+        if isinstance(mod, SpecialSparseConv):
+            mod.register_forward_hook(hook(name), with_kwargs=True)
+    data = {k: torch.from_numpy(np.ascontiguousarray(val)) for k, val in item.items() if not k.startswith("voxel_keys")}
+    with torch.no_grad():
+        feats1, importance = model.aggregate(data)
+        model.unet((feats1, importance), data)
+    assert len(calls) == 53, len(calls)
+    save = {"points": points, "normals": normals, "radii": radii, "bb_min": bb_min, "bb_max": bb_max,
+            "channel_div": np.int32(channel_div), "seed": np.int32(seed), "num_layers": np.int32(len(calls)),
+            "voxels": np.array(v, np.int64)}
+    for i, c in enumerate(calls):
+        save["layer%d_name" % i] = np.array(c["name"])
+        save["layer%d_meta" % i] = np.array([c["kernel_size"], c["level_out"], c["level_in"]], np.int32)
+        for k in ("inp", "imp", "out", "oimp"):
+            save["layer%d_%s" % (i, k)] = c[k]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "unet_%s.npz" % tag)
+    np.savez_compressed(path, **save)
+    print(tag, "V", v, "layers", len(calls), "wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    run("d4_3k", 3000, 4, 1)
-    run("d1_2k", 2000, 1, 2)
+    if len(sys.argv) < 2 or sys.argv[1] != "layers":
+        run("d4_3k", 3000, 4, 1)
+        run("d1_2k", 2000, 1, 2)
+    run_layers("layers_d4_1k", 1000, 4, 3)

@@ -175,6 +175,28 @@ def oracle_forward(points, normals, radii, bb_min, bb_max, weights, scale_sdf=Tr
     return out
 
 
+def save_torchscript_weights(weights, path):
+    """a TorchScript archive whose state_dict carries the tensor names of the reference's model.pt
+    (/root/reference/models/v0/convert_tf2torchscript.py:85-122, loaded at cpp/lib/asr.cpp:138-139):
+    nested parameter-holder modules, scripted and saved"""
+    import torch
+
+    class Holder(torch.nn.Module):
+        pass
+
+    root = Holder()
+    for name, arr in weights.items():
+        parts = name.split(".")
+        m = root
+        for part in parts[:-1]:
+            if not hasattr(m, part):
+                m.add_module(part, Holder())
+            m = getattr(m, part)
+        m.register_parameter(parts[-1], torch.nn.Parameter(torch.from_numpy(np.array(arr, np.float32)),
+                                                           requires_grad=False))
+    torch.jit.script(root).save(path)
+
+
 # ---- contouring test field ------------------------------------------------------------------------
 SPHERE_MESH_PIN = (1113, 2258, "ce9b39826aeff585")
 

@@ -100,3 +100,24 @@ def test_options_without_a_gpu():
     lib = _lib.load()
     assert lib.asr_hip_context_set_option(None, b"overlap", ctypes.c_int64(0)) == 1
     assert lib.asr_hip_context_device(None) == -1
+
+
+def test_model_pt_loader_reads_a_torchscript_archive(tmp_path):
+    """the reference ships its weights as a TorchScript file (cpp/lib/asr.cpp:138-139); the module's loader
+    takes such an archive, a pickled state dict or an .npz and returns the same name -> tensor table"""
+    import torch
+    import parity
+    import adaptivesurfacereconstruction as asr
+    w = synth.make_weights(4, seed=5)
+    path = str(tmp_path / "model.pt")
+    parity.save_torchscript_weights(w, path)
+    got = asr._load_weights(path)
+    assert set(got) == set(w) and len(got) == 109
+    assert all(np.array_equal(got[k].numpy(), w[k]) for k in w)
+    torch.save({k: torch.from_numpy(v) for k, v in w.items()}, str(tmp_path / "sd.pt"))
+    got = asr._load_weights(str(tmp_path / "sd.pt"))
+    assert all(np.array_equal(got[k].numpy(), w[k]) for k in w)
+    np.savez(str(tmp_path / "w.npz"), **w)
+    got = asr._load_weights(str(tmp_path / "w.npz"))
+    assert all(np.array_equal(got[k], w[k]) for k in w)
+    assert "rocPRIM" in asr.get_third_party_notices() and asr.get_version_str().startswith("0.2.0")

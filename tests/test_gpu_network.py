@@ -260,6 +260,65 @@ def test_whole_path_against_reference_model_fixture(golden_dir, gpu, tag):
     assert all(v >= 0 for v in ms.values())
 
 
+def test_model_pt_archive_reproduces_the_fixture(golden_dir, gpu, tmp_path):
+    """weights delivered as the reference delivers them -- a TorchScript archive with the state_dict names of
+    UNet5 (cpp/lib/asr.cpp:138-139) -- loaded by the module's loader, give the fixture's values"""
+    import adaptivesurfacereconstruction as asr
+    from asr_hip.pipeline import ImplicitPipeline
+    fx = np.load(os.path.join(golden_dir, "unet_d1_2k.npz"))
+    path = str(tmp_path / "model.pt")
+    parity.save_torchscript_weights(synth.make_weights(int(fx["channel_div"]), seed=int(fx["seed"])), path)
+    pipe = ImplicitPipeline(asr._load_weights(path), device=gpu)
+    values = pipe.forward(_t(fx["points"], gpu), _t(fx["normals"], gpu), _t(fx["radii"], gpu), fx["bb_min"], fx["bb_max"])
+    _close(values.cpu().numpy(), fx["out_values"])
+
+
+@pytest.mark.parametrize("kernel", ["f32", "bf16x3"])
+def test_every_layer_of_the_reference_graph_separately(gpu, kernel):
+    """the 53 SpecialSparseConv calls of the reference's UNet5 graph (tests/golden/unet_layers_d4_1k.npz, recorded
+    from the reference's own model code), each one through the HIP sparse conv with the call's own inputs:
+    within 1e-5 of the recorded output, for the f32-input MFMA kernel and for the bf16x3 kernel"""
+    import layer_fixture
+    from asr_hip import ops
+    for l in layer_fixture.load():
+        idx, kidx, rs = (_t(a, gpu) for a in l["csr"])
+        imp = _t(l["imp"], gpu) if l["imp"] is not None else None
+        cin, cout = l["kernel"].shape[1:]
+        if kernel == "f32" or cin % 4:
+            r = ops.sparse_conv(_t(l["kernel"], gpu), _t(l["inp"], gpu), idx, kidx, rs, inp_importance=imp,
+                                normalize=l["normalize"], bias=_t(l["bias"], gpu), relu=True,
+                                return_importance=imp is not None)
+        else:
+            packed = ops.pack_filters(_t(l["kernel"], gpu), "bf16x3")
+            r = ops.sparse_conv16("bf16x3", packed, l["K"], cin, cout, _t(l["inp"], gpu), idx, kidx, rs,
+                                  inp_importance=imp, normalize=l["normalize"], bias=_t(l["bias"], gpu), relu=True,
+                                  return_importance=imp is not None)
+        out, oimp = r if imp is not None else (r, None)
+        _close(out.cpu().numpy(), l["out"])
+        if oimp is not None:
+            _close(oimp.cpu().numpy(), l["oimp"])
+
+
+def test_octree_handles_are_self_contained(gpu):
+    """module.cpp:230-235: create_dual_vertex_indices works on any live tree, however many were built since
+    (models/v0/datareader.py:224-243,802 keeps trees across calls)"""
+    import adaptivesurfacereconstruction as asr
+    trees, want = [], []
+    for seed in (1, 2, 3):
+        p, _ = synth.scan_cloud(3000 + 500 * seed, seed=seed, device="cpu")
+        pts = p.numpy()
+        rad = synth.knn_radii(pts, 24)
+        bb = synth.bounding_box(pts, 0.1)
+        trees.append(asr.create_octree(pts, rad, bb[0], bb[1]))
+        o = O.Oracle()
+        o.build_octree(pts, rad, *bb)
+        o.create_grids(1)
+        want.append(o.create_dual_vertex_indices())
+    for tree, w in zip(trees, want):  # oldest first, after all three were built
+        got = asr.create_dual_vertex_indices(tree)
+        assert got.dtype == np.uint64 and np.array_equal(got, w.astype(np.uint64))
+
+
 def test_whole_path_against_oracle_fresh_cloud(gpu):
     from asr_hip.pipeline import ImplicitPipeline
     p, q = synth.scan_cloud(20000, seed=21, device="cpu", density_variance=10.0)

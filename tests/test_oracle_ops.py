@@ -119,3 +119,20 @@ def test_network_restatement_matches_reference_model_fixture(golden_dir, tag):
     geo = parity.oracle_geometry(fx["points"], fx["radii"], fx["bb_min"], fx["bb_max"])
     for k in item:
         assert np.array_equal(geo[k], item[k]), k
+
+
+def test_every_layer_of_the_reference_graph_separately():
+    """53 SpecialSparseConv calls recorded from the reference's own model code: the oracle reproduces each
+    one from the call's own inputs (bit for bit: the fixture was made with the oracle's ops under the
+    reference's glue, so this pins shapes, CSR choice, importance indexing and bias / ReLU per layer)"""
+    import layer_fixture
+    layers = layer_fixture.load()
+    assert len(layers) == 53 and sum(l["name"] == "sparseconv_down3.conv1a" for l in layers) == 2
+    for l in layers:
+        idx, kidx, rs = l["csr"]
+        nimp = l["imp"][idx.astype(np.int64)] if l["imp"] is not None else None
+        out = O.sparse_conv(l["kernel"], l["inp"], idx, kidx, nimp, rs, l["normalize"])
+        out = np.maximum(out + l["bias"], 0)
+        assert np.array_equal(out, l["out"]), l["name"]
+        if nimp is not None:
+            assert np.array_equal(O.reduce_subarrays_sum(nimp, rs), l["oimp"]), l["name"]

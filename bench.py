@@ -87,7 +87,7 @@ def job_value(world, points_per_rank, steps, dt):
     return world * points_per_rank * steps / dt
 
 
-def pmc_traffic(points):
+def pmc_traffic(points, precision="f32"):
     """HBM bytes per sparse-conv launch from the committed rocprofv3 PMC passes of this very command
     (profiles/r*_pmc_traffic.json, produced by scripts/make_profiles.sh); PMC counters cannot be
     collected from inside the timed process.  None when no matching profile is committed."""
@@ -98,7 +98,7 @@ def pmc_traffic(points):
             d = json.load(open(path))
         except Exception:
             continue
-        if d.get("points", 10_000_000) == points:
+        if d.get("points", 10_000_000) == points and d.get("precision", "f32") == precision:
             best = (d["hbm_bytes_per_launch"], os.path.basename(path))
     return best
 
@@ -330,7 +330,7 @@ def main():
         flops, launches = conv_flops(pipe.sizes, shapes)
         unet_s = stage_ms["unet"] * 1e-3
         achieved = flops / unet_s / 1e12 if unet_s > 0 else 0.0
-        tr = pmc_traffic(n) if args.precision == "f32" and args.density_variance == 1.0 else None
+        tr = pmc_traffic(n, args.precision) if args.density_variance == 1.0 else None
         dtype, peak, kname, peak_note = PRECISION_INFO[args.precision]
         out = {
             "metric": "input points/sec to signed implicit values",

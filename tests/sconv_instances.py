@@ -15,6 +15,25 @@ BENCH_INSTANCES = {
 }
 
 
+# k_sconv_mfma16 instances of the default bench (bf16x3 arithmetic): (NT, KC, IMP, WAVES, DUAL, MODE) as the
+# library's launch counters report them (template order is <NT, KC, WAVES, MODE, IMP, DUAL>)
+BENCH_INSTANCES16 = {
+    (4, 32, 0, 8, 1, 2), (4, 32, 0, 8, 0, 2), (8, 32, 0, 8, 1, 2), (8, 32, 0, 8, 0, 2), (4, 32, 0, 4, 1, 2),
+    (4, 32, 0, 4, 0, 2), (2, 32, 0, 4, 1, 2), (2, 32, 0, 4, 0, 2), (2, 32, 0, 8, 0, 2),
+}
+
+
+def instances16_in_trace(path):
+    out = set()
+    with open(path) as f:
+        for line in f:
+            m = re.match(r"k_sconv_mfma16<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", line)
+            if m:
+                out.add((int(m.group(1)), int(m.group(2)), int(m.group(5) == "true"), int(m.group(3)),
+                         int(m.group(6) == "true"), int(m.group(4))))
+    return out
+
+
 def instances_in_trace(path):
     """set of instances named in a profiles/*_sconv_trace.csv (scripts/layer_table.py input)"""
     out = set()
@@ -27,6 +46,9 @@ def instances_in_trace(path):
     return out
 
 
-def latest_trace():
+def latest_trace(kind="f32"):
+    """newest committed 10 M-point trace that contains launches of the f32 kernel / of the 16-bit kernel"""
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_10m_sconv_trace.csv")))
+    probe = instances_in_trace if kind == "f32" else instances16_in_trace
+    files = [f for f in files if probe(f)]
     return files[-1] if files else None

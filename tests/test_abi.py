@@ -90,9 +90,12 @@ def test_bench_instance_list_matches_committed_profile():
     """tests/sconv_instances.py (the instances the GPU parity tests force) == the k_sconv_mfma
     instances in the newest committed 10 M-point kernel trace of bench.py"""
     import sconv_instances as si
-    path = si.latest_trace()
+    path = si.latest_trace("f32")
     assert path is not None
     assert si.instances_in_trace(path) == si.BENCH_INSTANCES, path
+    path = si.latest_trace("16")   # the default bench runs the bf16x3 arithmetic on k_sconv_mfma16
+    assert path is not None
+    assert si.instances16_in_trace(path) == si.BENCH_INSTANCES16, path
 
 
 def test_options_without_a_gpu():

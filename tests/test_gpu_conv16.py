@@ -55,7 +55,16 @@ SHAPES = [
     ("nb", 1, 55, 128, 120, 8, 8, 8), ("nb", 1, 55, 128, 128, 0, 8, 4), ("nb", 1, 55, 384, 128, 0, 4, 8),
     ("nb", 2, 55, 256, 248, 8, 8, 4), ("nb", 2, 55, 512, 256, 0, 8, 8), ("up", 1, 9, 256, 256, 0, 0, 0),
     ("nb", 3, 55, 256, 256, 0, 2, 4), ("nb", 2, 55, 40, 16, 0, 1, 4), ("nb", 1, 55, 8, 24, 0, 0, 0),
+    # the remaining instances of the 10 M-point bench (tests/sconv_instances.py BENCH_INSTANCES16)
+    ("nb", 0, 55, 32, 56, 8, 4, 8), ("nb", 3, 55, 256, 248, 8, 4, 4), ("nb", 3, 55, 256, 256, 0, 4, 4),
+    ("nb", 0, 55, 32, 32, 0, 2, 8), ("nb", 4, 55, 256, 248, 8, 2, 4),
 ]
+
+
+def test_shapes_cover_the_bench_instances():
+    from sconv_instances import BENCH_INSTANCES16
+    forced = {(s[6], 32, 0, s[7], int(s[5] > 0), 2) for s in SHAPES if s[6] and s[7]}
+    assert BENCH_INSTANCES16 <= forced, BENCH_INSTANCES16 - forced
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f16"])

@@ -774,7 +774,8 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         }
     } joiner{worker};
 
-    // grids (cpp/lib/grid.cpp:245-314)
+    // grids (cpp/lib/grid.cpp:245-314); the MFMA tiling orders of all 13 CSRs are computed in one batch at the end
+    std::vector<asr_row_group_job> rg_jobs;
     for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
         GridDev& g = ctx->grids[i];
         if (i > 0) g = GridDev();
@@ -801,10 +802,8 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
             prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
             if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            ASR_TRY(asr_geom_row_groups(ctx, prev.up_kidx, prev.up_rs, prev.v, ASR_ROW_GROUP_SEGMENT,
-                                        prev.perm_up, 9));
-            ASR_TRY(asr_geom_row_groups(ctx, prev.down_kidx, prev.down_rs, g.v, ASR_ROW_GROUP_SEGMENT,
-                                        prev.perm_down, 9));
+            rg_jobs.push_back({prev.up_kidx, prev.up_rs, prev.v, 9, prev.perm_up});
+            rg_jobs.push_back({prev.down_kidx, prev.down_rs, g.v, 9, prev.perm_down});
             std::string s = std::to_string(i - 1);
             name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
             name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
@@ -825,7 +824,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
                                          &g.p));
         g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
         if (!g.perm_nb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_row_groups(ctx, g.nkidx, g.nrs, g.v, ASR_ROW_GROUP_SEGMENT, g.perm_nb, 55));
+        rg_jobs.push_back({g.nkidx, g.nrs, g.v, 55, g.perm_nb});
         ctx->sizes.num_voxels[i] = g.v;
         ctx->sizes.num_pairs[i] = g.p;
         std::string s = std::to_string(i);
@@ -837,6 +836,8 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         name_it(ctx, "neighbors_row_splits" + s, g.nrs, 8 * (g.v + 1));
         name_it(ctx, "tiling" + s, g.perm_nb, 4 * g.v);
     }
+    ctx->scratch.reset();
+    ASR_TRY(asr_geom_row_groups_batch(ctx, rg_jobs.data(), (int)rg_jobs.size(), ASR_ROW_GROUP_SEGMENT));
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     if (overlap)

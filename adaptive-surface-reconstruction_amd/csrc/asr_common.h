@@ -252,6 +252,14 @@ int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* 
                              i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs);
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
                         int32_t* perm_out, int kbits);
+struct asr_row_group_job {
+    const uint8_t* kidx;
+    const i64* rs;
+    i64 v;
+    int kbits;
+    int32_t* perm_out;
+};
+int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg);
 int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_out);
 int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out_keys, i64 v_out,
                           int32_t* up_idx, uint8_t* up_kidx, i64* up_rs);

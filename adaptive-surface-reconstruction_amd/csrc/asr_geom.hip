@@ -285,7 +285,11 @@ __device__ inline int neighbor_candidate(const HashTab& t, u64 key, int x, int y
     }
 }
 
-__global__ void k_neighbors_count(const u64* keys, i64 v, HashTab t, i64* counts, u64* masks) {
+// The hits of the counting pass are parked (neighbour index + slot, NB_STAGE per row) so that the fill pass is a
+// copy for all but the few rows with more neighbours: the 8..13 hash probes per voxel are not repeated.
+constexpr int NB_STAGE = 16;
+__global__ void k_neighbors_count(const u64* keys, i64 v, HashTab t, i64* counts, u64* masks, int32_t* stage_idx,
+                                  uint8_t* stage_slot) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i > v) return;
     if (i == v) {
@@ -297,13 +301,20 @@ __global__ void k_neighbors_count(const u64* keys, i64 v, HashTab t, i64* counts
     asr_key_coord(key, x, y, z, lev);
     u64 m = 0;
     int n = 1;
+#define ASR_NB_HIT(c_, idx_, slot_)                                   \
+    {                                                                 \
+        m |= u64(1) << (c_);                                          \
+        if (stage_idx && n - 1 < NB_STAGE) {                          \
+            stage_idx[i * NB_STAGE + (n - 1)] = (idx_);               \
+            stage_slot[i * NB_STAGE + (n - 1)] = (uint8_t)(slot_);    \
+        }                                                             \
+        ++n;                                                          \
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        int slot;
-        if (neighbor_candidate(t, key, x, y, z, lev, c, slot) >= 0) {
-            m |= u64(1) << c;
-            ++n;
-        }
+        int slot = 0;
+        const int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
+        if (idx >= 0) ASR_NB_HIT(c, idx, slot)
     }
     // The voxels of a grid are disjoint cells: where the same-level neighbour across a face exists,
     // neither its four children nor its parent can, so those five probes are skipped (36 -> ~13 probes
@@ -312,26 +323,33 @@ __global__ void k_neighbors_count(const u64* keys, i64 v, HashTab t, i64* counts
     for (int c = 6; c < 36; ++c) {
         const int face = c < 30 ? (c - 6) >> 2 : c - 30;
         if ((m >> face) & 1) continue;
-        int slot;
-        if (neighbor_candidate(t, key, x, y, z, lev, c, slot) >= 0) {
-            m |= u64(1) << c;
-            ++n;
-        }
+        int slot = 0;
+        const int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
+        if (idx >= 0) ASR_NB_HIT(c, idx, slot)
     }
+#undef ASR_NB_HIT
     counts[i] = n;
     if (masks) masks[i] = m;
 }
 __global__ void k_neighbors_fill(const u64* keys, i64 v, HashTab t, const i64* rs, const u64* masks,
-                                 int32_t* nidx, uint8_t* nkidx) {
+                                 const int32_t* stage_idx, const uint8_t* stage_slot, int32_t* nidx, uint8_t* nkidx) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i >= v) return;
-    u64 key = keys[i];
-    int x, y, z, lev;
-    asr_key_coord(key, x, y, z, lev);
     i64 o = rs[i];
+    const int n = (int)(rs[i + 1] - o);
     nidx[o] = (int32_t)i;
     nkidx[o] = 0;
     ++o;
+    if (stage_idx && n - 1 <= NB_STAGE) {  // the candidate order of the counting pass is ascending slot order
+        for (int j = 0; j < n - 1; ++j) {
+            nidx[o + j] = stage_idx[i * NB_STAGE + j];
+            nkidx[o + j] = stage_slot[i * NB_STAGE + j];
+        }
+        return;
+    }
+    u64 key = keys[i];
+    int x, y, z, lev;
+    asr_key_coord(key, x, y, z, lev);
     u64 m = masks ? masks[i] : ~u64(0);
     for (int c = 0; c < 36; ++c) {
         if (!((m >> c) & 1)) continue;
@@ -1072,6 +1090,76 @@ __global__ void k_segment_of(const int32_t* rows, i64 v, i64 seg, int32_t* out) 
 }
 
 // ------------------------------------------------------------------------------------------
+// batched row regrouping: the 13 CSRs of a grid hierarchy (5 neighbour lists, 4 up lists, 4 inverted up lists)
+// in ONE radix sort + one chunk sort instead of 13 x (2..3 sorts) -- on the small levels each rocPRIM sort is
+// a dozen launches of a few microseconds.  Rows of all jobs live in one index space, every job padded to a
+// multiple of 128 rows; key = job (4 bits) | segment (6 bits) | slot mask without bit 0 (54 bits): the stable
+// sort leaves each job's rows contiguous, ordered by (segment, mask, row) exactly like asr_geom_row_groups.
+// ------------------------------------------------------------------------------------------
+constexpr int RG_MAX_JOBS = 16;
+struct RowGroupBatch {
+    int n;
+    i64 base[RG_MAX_JOBS + 1];  // first padded row of each job (multiples of 128); base[n] = total
+    i64 v[RG_MAX_JOBS];
+    const uint8_t* kidx[RG_MAX_JOBS];
+    const i64* rs[RG_MAX_JOBS];
+    int32_t* out[RG_MAX_JOBS];
+};
+__device__ inline int rg_job_of(const RowGroupBatch& b, i64 e) {
+    int j = 0;
+    while (j + 1 < b.n && e >= b.base[j + 1]) ++j;
+    return j;
+}
+__global__ void k_rg_keys(RowGroupBatch b, i64 seg, u64* keys, u64* masks, int32_t* ids) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (e >= b.base[b.n]) return;
+    const int j = rg_job_of(b, e);
+    const i64 r = e - b.base[j];
+    u64 m = 0, key;
+    if (r < b.v[j]) {
+        const i64* rs = b.rs[j];
+        const uint8_t* kidx = b.kidx[j];
+        for (i64 p = rs[r]; p < rs[r + 1]; ++p) m |= u64(1) << (kidx[p] & 63);
+        key = ((u64)j << 60) | ((u64)(r / seg) << 54) | ((m >> 1) & ((u64(1) << 54) - 1));
+    } else {
+        key = ((u64)j << 60) | (u64(63) << 54) | ((u64(1) << 54) - 1);  // padding: last inside the job
+    }
+    keys[e] = key;
+    masks[e] = m;
+    ids[e] = (int32_t)e;
+}
+// 128-row chunks of the sorted order: cost = slots in the union of the rows' masks (as k_tile_cost / k_chunk_key)
+__global__ void k_rg_chunk_keys(RowGroupBatch b, i64 seg, const int32_t* sorted_ids, const u64* masks, int32_t* ckey,
+                                int32_t* cid) {
+    const i64 c = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;  // one wave per chunk
+    const int lane = threadIdx.x & 63;
+    if (c * 128 >= b.base[b.n]) return;
+    const int j = rg_job_of(b, c * 128);
+    const i64 r0 = c * 128 - b.base[j];
+    u64 m0 = masks[sorted_ids[c * 128 + lane]], m1 = masks[sorted_ids[c * 128 + 64 + lane]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m0 |= __shfl_xor(m0, o, 64);
+        m1 |= __shfl_xor(m1, o, 64);
+    }
+    if (lane == 0) {
+        int cost = __popcll(m0) + __popcll(m1);  // the two 64-row tiles of the chunk, like k_chunk_key
+        if (r0 + 128 > b.v[j]) cost = 0;         // the partial chunk stays last
+        ckey[c] = (int32_t)(((i64)j << 13) | ((r0 / seg) << 7) | (127 - cost));
+        cid[c] = (int32_t)c;
+    }
+}
+__global__ void k_rg_apply(RowGroupBatch b, const int32_t* sorted_ids, const int32_t* order, int lpt) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (e >= b.base[b.n]) return;
+    const int j = rg_job_of(b, e);
+    const i64 r = e - b.base[j];
+    if (r >= b.v[j]) return;
+    const i64 src = lpt ? (i64)order[e >> 7] * 128 + (e & 127) : e;
+    b.out[j][r] = (int32_t)(sorted_ids[src] - b.base[j]);
+}
+
+// ------------------------------------------------------------------------------------------
 // dual cells ("next" row D.1): CreateDualVertexIndices, cpp/lib/grid.cpp:316-459 with the vertex /
 // adjacent-node key algebra of cpp/lib/octreebase.h:86-118.  One thread per leaf, 8 corners each.
 // ------------------------------------------------------------------------------------------
@@ -1270,7 +1358,7 @@ int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* 
     ASR_TRY(build_key_map(ctx, keys, v, t));
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, nullptr);
+    k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, nullptr, nullptr, nullptr);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
     ASR_TRY(read_i64(ctx, rs + v, num_pairs));
@@ -1281,7 +1369,7 @@ int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const 
     if (v <= 0) return ASR_HIP_OK;
     HashTab t;
     ASR_TRY(build_key_map(ctx, keys, v, t));
-    k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, nullptr, idx, kidx);
+    k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, nullptr, nullptr, nullptr, idx, kidx);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }
@@ -1293,15 +1381,17 @@ int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* 
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     u64* masks = arena_alloc<u64>(ctx->scratch, v);
     i64* rs = arena_alloc<i64>(out_arena, v + 1);
-    if (!counts || !masks || !rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, masks);
+    int32_t* st_idx = arena_alloc<int32_t>(ctx->scratch, (size_t)v * NB_STAGE);
+    uint8_t* st_slot = arena_alloc<uint8_t>(ctx->scratch, (size_t)v * NB_STAGE);
+    if (!counts || !masks || !rs || !st_idx || !st_slot) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, masks, st_idx, st_slot);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
     ASR_TRY(read_i64(ctx, rs + v, num_pairs));
     int32_t* idx = arena_alloc<int32_t>(out_arena, *num_pairs);
     uint8_t* kidx = arena_alloc<uint8_t>(out_arena, *num_pairs);
     if (!idx || !kidx) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, masks, idx, kidx);
+    k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, masks, st_idx, st_slot, idx, kidx);
     ASR_CHECK_LAUNCH(ctx);
     *rs_out = rs;
     *idx_out = idx;
@@ -1359,6 +1449,59 @@ int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs
         k_chunk_apply<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(perm_m, cid_s, v, perm_out);
         ASR_CHECK_LAUNCH(ctx);
     }
+    return ASR_HIP_OK;
+}
+
+// all CSRs of one hierarchy in one pass (see k_rg_keys); falls back to the per-CSR routine for shapes the
+// packed key cannot hold
+int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg) {
+    if (seg < 128) seg = 128;
+    bool fits = n <= RG_MAX_JOBS && seg % 128 == 0;
+    for (int j = 0; j < n && fits; ++j) fits = jobs[j].v / seg < 63 && jobs[j].v < (i64(1) << 31);
+    if (!fits) {
+        for (int j = 0; j < n; ++j)
+            ASR_TRY(asr_geom_row_groups(ctx, jobs[j].kidx, jobs[j].rs, jobs[j].v, seg, jobs[j].perm_out, jobs[j].kbits));
+        return ASR_HIP_OK;
+    }
+    RowGroupBatch b;
+    b.n = 0;
+    i64 total = 0;
+    for (int j = 0; j < n; ++j) {
+        if (jobs[j].v <= 0) continue;
+        b.base[b.n] = total;
+        b.v[b.n] = jobs[j].v;
+        b.kidx[b.n] = jobs[j].kidx;
+        b.rs[b.n] = jobs[j].rs;
+        b.out[b.n] = jobs[j].perm_out;
+        total += (jobs[j].v + 127) / 128 * 128;
+        ++b.n;
+    }
+    if (b.n == 0) return ASR_HIP_OK;
+    b.base[b.n] = total;
+    if (total >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "row_groups: too many rows");
+    u64* keys = arena_alloc<u64>(ctx->scratch, total);
+    u64* keys_s = arena_alloc<u64>(ctx->scratch, total);
+    u64* masks = arena_alloc<u64>(ctx->scratch, total);
+    int32_t* ids = arena_alloc<int32_t>(ctx->scratch, total);
+    int32_t* ids_s = arena_alloc<int32_t>(ctx->scratch, total);
+    const i64 nc = total / 128;
+    int32_t* ckey = arena_alloc<int32_t>(ctx->scratch, nc);
+    int32_t* ckey_s = arena_alloc<int32_t>(ctx->scratch, nc);
+    int32_t* cid = arena_alloc<int32_t>(ctx->scratch, nc);
+    int32_t* cid_s = arena_alloc<int32_t>(ctx->scratch, nc);
+    if (!keys || !keys_s || !masks || !ids || !ids_s || !ckey || !ckey_s || !cid || !cid_s)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_rg_keys<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, seg, keys, masks, ids);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, keys, keys_s, ids, ids_s, total, 64)));
+    const int lpt = ctx->opt.row_lpt != 0;
+    if (lpt) {
+        k_rg_chunk_keys<<<grid_for(nc * 64, BLK), BLK, 0, ctx->stream>>>(b, seg, ids_s, masks, ckey, cid);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, ckey, ckey_s, cid, cid_s, nc, 17)));
+    }
+    k_rg_apply<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, ids_s, cid_s, lpt);
+    ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }
 
@@ -1454,7 +1597,10 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     if (n > 0) {
         k_point_codes<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, n, codes_u, ids_u, ctx->d_flags);
         ASR_CHECK_LAUNCH(ctx);
-        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes_u, codes, ids_u, ids, n, 63)));
+        // the cell tables only cover levels lmin..lmax: the points need to be grouped by their level-lmax cell, the
+        // order inside such a cell is free (stable: input order) -- sort the top 3*lmax bits of the 63-bit code only
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes_u, codes, ids_u, ids, n, 63,
+                                          3 * (ASR_MAX_LEVEL - std::max(lmax, 1)))));
         k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted, st.rank);
         ASR_CHECK_LAUNCH(ctx);
     }

@@ -37,16 +37,17 @@ static inline int sort_keys(asr_hip_context* ctx, Arena& arena, const u64* in, u
                                                 ctx->stream));
     return ASR_HIP_OK;
 }
+// stable LSD radix sort on key bits [begin_bit, end_bit)
 template <class K, class V>
 static inline int sort_pairs(asr_hip_context* ctx, Arena& arena, const K* kin, K* kout, const V* vin, V* vout,
-               i64 n, int end_bit) {
+               i64 n, int end_bit, int begin_bit = 0) {
     if (n <= 0) return ASR_HIP_OK;
     size_t tb = 0;
-    ASR_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, (size_t)n, 0,
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_pairs(nullptr, tb, kin, kout, vin, vout, (size_t)n, begin_bit,
                                                  end_bit, ctx->stream));
     void* tmp = arena.alloc(tb ? tb : 256);
     if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (size_t)n, 0,
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_pairs(tmp, tb, kin, kout, vin, vout, (size_t)n, begin_bit,
                                                  end_bit, ctx->stream));
     return ASR_HIP_OK;
 }

@@ -299,6 +299,28 @@ def test_every_layer_of_the_reference_graph_separately(gpu, kernel):
             _close(oimp.cpu().numpy(), l["oimp"])
 
 
+def test_batched_tiling_orders_equal_the_per_csr_routine(gpu):
+    """implicit_build computes the MFMA tiling orders of all 13 CSRs in one batched sort; each must equal
+    asr_hip_row_groups on that CSR alone (and be a permutation of the rows)"""
+    from asr_hip import ops
+    from asr_hip.pipeline import ImplicitPipeline
+    p, q = synth.scan_cloud(40000, seed=12, device=gpu)
+    rad = synth.knn_radii_gpu(p, 24)
+    bb = synth.bounding_box(p, 0.1)
+    pipe = ImplicitPipeline(synth.make_weights(4, seed=1), device=gpu)
+    for seg in (0, 4096):
+        if seg:
+            pipe.ctx.set_option("row_segment", seg)
+        pipe.build(p, rad, bb[0], bb[1])
+        for i in range(5):
+            names = [("tiling%d" % i, "neighbors")] + ([("tiling_up%d" % i, "up_neighbors"), ("tiling_down%d" % i, "down_neighbors")] if i < 4 else [])
+            for tname, pre in names:
+                got = pipe.get(tname)
+                want = ops.row_groups(pipe.get("%s_kernel_index%d" % (pre, i)), pipe.get("%s_row_splits%d" % (pre, i)), seg)
+                assert torch.equal(got, want), (tname, seg)
+                assert torch.equal(torch.sort(got.long()).values, torch.arange(got.numel(), device=gpu))
+
+
 def test_octree_handles_are_self_contained(gpu):
     """module.cpp:230-235: create_dual_vertex_indices works on any live tree, however many were built since
     (models/v0/datareader.py:224-243,802 keeps trees across calls)"""

@@ -38,6 +38,7 @@ const OptEntry k_options[] = {
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"overlap", "ASR_OVERLAP", &AsrOptions::overlap},
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
+        {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
 };
 }  // namespace
 

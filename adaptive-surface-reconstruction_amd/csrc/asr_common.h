@@ -97,6 +97,7 @@ struct AsrOptions {
     i64 row_segment = 524288;     // rows are regrouped inside segments of this many consecutive rows
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
+    i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
 };
 

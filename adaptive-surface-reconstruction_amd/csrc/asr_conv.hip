@@ -225,6 +225,182 @@ __global__ __launch_bounds__(1024, 8) void k_cconv(const float* __restrict__ fil
 }
 
 // ------------------------------------------------------------------------------------------
+// a10 with the contraction on the matrix cores (whole-path layout: Morton-ordered 32-byte records, cin = 4,
+// cout <= 32).  A wave owns GROUPS of 16 consecutive voxels: it accumulates B[cell][4] of each voxel as above
+// (lane = filter cell), parks the 16 x 256 matrix in LDS, and contracts it with the 256 x cout filter matrix in
+// 128 v_mfma_f32_16x16x4_f32 (exact f32): out[16 voxels][cout] -- instead of 64 ds_read_b128 + 64 v_pk_fma per
+// voxel on the VALU / LDS pipes.  The filter fragments (128 floats per lane) stay in registers for the whole
+// (persistent) kernel.  k order: MFMA step (j, t) of k-lane g contracts k = 16 j + 4 g + t on both operands, so the
+// A fragment of four steps is one ds_read_b128; the LDS rows are 264 floats apart (conflict-free for that read).
+// With only two waves per SIMD the row_splits -> index -> record load chain of a voxel is software pipelined
+// over the 16 voxels of a group: indices of voxel u+2 and records of voxel u+1 are in flight while voxel u is
+// accumulated.
+// ------------------------------------------------------------------------------------------
+constexpr int CCG = 16;        // voxels per group
+constexpr int CCG_LD = 264;    // floats per LDS row of the group matrix
+// SORTED: neighbours are positions into the 32-byte records `rec`; else `rec` is unused and positions / features
+// come from the AoS arrays inp_pos [N,3] / inp_feat [N,4] at original indices (the generic operator boundary):
+// same arithmetic, so both layouts give identical bits.
+template <bool SORTED>
+__global__ __launch_bounds__(512, 2) void k_cconv_mfma(
+        const float* __restrict__ filters, const float* __restrict__ out_pos, const float* __restrict__ extents,
+        const float4* __restrict__ rec, const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
+        const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
+        const i64* __restrict__ rs, i64 num_out, int cout, int normalize, const float* __restrict__ bias, int relu,
+        float* __restrict__ out, i64 heavy_rows) {
+    __shared__ __attribute__((aligned(16))) float s_bt[8][CCG][CCG_LD];
+    __shared__ __attribute__((aligned(16))) float4 s_pair[8][128];
+    __shared__ float s_norm[8][CCG];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const float cxf = (float)(lane & 3), cyf = (float)((lane >> 2) & 3), czf = (float)(lane >> 4);
+    // filter fragments: wreg[T][j][t] = W[k = 16 j + 4 g + t][o = 16 T + n], W = filters viewed as [256][cout]
+    float wreg[2][16][4];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = 16 * T + n;
+                wreg[T][j][t] = o < cout ? filters[(i64)(16 * j + 4 * g + t) * cout + o] : 0.f;
+            }
+    float bias_o[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) bias_o[T] = (bias && 16 * T + n < cout) ? bias[16 * T + n] : 0.f;
+
+    const i64 groups = (num_out + CCG - 1) / CCG;
+    const i64 wave0 = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
+    const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 grp = wave0; grp < groups; grp += nwaves) {
+        const i64 q0 = grp * CCG;
+        // row bounds / centre / extent of the group's voxels: lane u holds voxel u
+        int mb = 0, mcnt = 0;  // first pair (relative to the group's first pair) and pair count
+        float mox = 0.f, moy = 0.f, moz = 0.f, msc = 0.f;
+        const i64 pbase = rs[q0];
+        if (lane < CCG && q0 + lane < num_out) {
+            const i64 b = rs[q0 + lane], e = rs[q0 + lane + 1];
+            mb = (int)(b - pbase);
+            mcnt = (int)(e - b);
+            mox = out_pos[3 * (q0 + lane)];
+            moy = out_pos[3 * (q0 + lane) + 1];
+            moz = out_pos[3 * (q0 + lane) + 2];
+            msc = 2.f * (1.f / extents[q0 + lane]);
+        }
+        // pipeline stages: first batch (<= 64 pairs) of a voxel
+        auto load1 = [&](int u, int& idx, float& w) __attribute__((always_inline)) {
+            const int b = __builtin_amdgcn_readlane(mb, u), cnt = __builtin_amdgcn_readlane(mcnt, u);
+            const bool on = lane < cnt && cnt <= heavy_rows;
+            const i64 p = pbase + b + lane;
+            idx = on ? nidx[p] : 0;
+            w = on ? (nimp ? nimp[p] : 1.f) : 0.f;
+        };
+        auto load2 = [&](int idx, float4& P, float4& F) __attribute__((always_inline)) {
+            if (SORTED) {
+                P = rec[2 * (i64)idx];
+                F = rec[2 * (i64)idx + 1];
+            } else {
+                P = make_float4(inp_pos[3 * (i64)idx], inp_pos[3 * (i64)idx + 1], inp_pos[3 * (i64)idx + 2], 0.f);
+                F = make_float4(inp_feat[4 * (i64)idx], inp_feat[4 * (i64)idx + 1], inp_feat[4 * (i64)idx + 2],
+                                inp_feat[4 * (i64)idx + 3]);
+            }
+        };
+        int i1 = 0;
+        float w1 = 0.f;
+        float4 P2, F2;
+        float w2;
+        load1(0, i1, w1);
+        load2(i1, P2, F2);
+        w2 = w1;
+        load1(1, i1, w1);
+#pragma unroll 1
+        for (int u = 0; u < CCG; ++u) {
+            const float4 Pc = P2, Fc = F2;
+            const float wc = w2;
+            if (u + 1 < CCG) {  // records of voxel u+1, indices of voxel u+2: in flight during this voxel
+                load2(i1, P2, F2);
+                w2 = w1;
+            }
+            if (u + 2 < CCG) load1(u + 2, i1, w1);
+            const int cnt_all = __builtin_amdgcn_readlane(mcnt, u);
+            const bool heavy = cnt_all > heavy_rows;
+            const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mox), u));
+            const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(moy), u));
+            const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(moz), u));
+            const float sc2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(msc), u));
+            float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
+            if (!heavy && cnt_all > 0) {
+                const int b = __builtin_amdgcn_readlane(mb, u);
+                for (int p0 = 0; p0 < cnt_all; p0 += 64) {
+                    const int cnt = cnt_all - p0 < 64 ? cnt_all - p0 : 64;
+                    float4 P = Pc, F = Fc;
+                    float w = wc;
+                    if (p0 > 0) {  // rows of more than 64 pairs: further batches are loaded on the spot
+                        const bool on = lane < cnt;
+                        const i64 p = pbase + b + p0 + lane;
+                        const int idx = on ? nidx[p] : 0;
+                        w = on ? (nimp ? nimp[p] : 1.f) : 0.f;
+                        load2(idx, P, F);
+                    }
+                    float ux, uy, uz;
+                    cconv_pair_coords((P.x - ox) * sc2, (P.y - oy) * sc2, (P.z - oz) * sc2, ux, uy, uz);
+                    norm_lane += w;
+                    __builtin_amdgcn_wave_barrier();
+                    s_pair[wib][2 * lane] = make_float4(ux, uy, uz, w * F.x);
+                    s_pair[wib][2 * lane + 1] = make_float4(w * F.y, w * F.z, w * F.w, 0.f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+                    for (int j = 0; j < cnt; ++j) {
+                        const float4 a = s_pair[wib][2 * j], bq = s_pair[wib][2 * j + 1];
+                        const float wx = fminf(fmaxf(1.f - fabsf(a.x - cxf), 0.f), 1.f);
+                        const float wy = fminf(fmaxf(1.f - fabsf(a.y - cyf), 0.f), 1.f);
+                        const float wz = fminf(fmaxf(1.f - fabsf(a.z - czf), 0.f), 1.f);
+                        const float wt = wx * wy * wz;
+                        B0 += wt * a.w;
+                        B1 += wt * bq.x;
+                        B2 += wt * bq.y;
+                        B3 += wt * bq.z;
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(&s_bt[wib][u][4 * lane]) = make_float4(B0, B1, B2, B3);
+            const float norm = wave_sum_dpp(norm_lane);
+            if (lane == 0) s_norm[wib][u] = heavy ? -1.f : norm;  // -1: written by k_cconv_heavy
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 a4 = *reinterpret_cast<const float4*>(&s_bt[wib][n][16 * j + 4 * g]);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wreg[0][j][t], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wreg[1][j][t], acc1, 0, 0, 0);
+            }
+        }
+        // acc[r] = out[voxel 4 g + r][o = 16 T + n]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int vx = 4 * g + r;
+            const i64 q = q0 + vx;
+            const float norm = s_norm[wib][vx];
+            if (q >= num_out || norm < 0.f) continue;
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const int o = 16 * T + n;
+                float v = T == 0 ? acc0[r] : acc1[r];
+                if (normalize && norm != 0.f) v = v / norm;
+                v += bias_o[T];
+                if (relu) v = fmaxf(v, 0.f);
+                if (o < cout) out[q * cout + o] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the group matrix is re-used by the next group
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // a10, long rows: a coarse voxel next to the surface can have tens of thousands of neighbours
 // while the mean is ~15.  Rows above CCONV_HEAVY pairs are collected and handled by one
 // 1024-thread block each: the 16 waves take interleaved 64-pair batches, partial B sums are
@@ -814,7 +990,17 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
         ASR_LAUNCH_CCONV_HEAVY_S(C_, true) \
     else                                  \
         ASR_LAUNCH_CCONV_HEAVY_S(C_, false)
-    if (cout <= 8)
+    if (cin == 4 && cout <= 32 && !ctx->opt.cconv_valu) {
+        // contraction on the matrix cores: one persistent 8-wave block per CU (152 KB of LDS)
+        if (sorted4)
+            k_cconv_mfma<true><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, (const float4*)inp_pos, nullptr,
+                                                             nullptr, nidx, nimp, rs, num_out, cout, normalize, bias,
+                                                             relu, out, CCONV_HEAVY);
+        else
+            k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, nullptr, inp_pos, inp_feat,
+                                                              nidx, nimp, rs, num_out, cout, normalize, bias, relu,
+                                                              out, CCONV_HEAVY);
+    } else if (cout <= 8)
         ASR_LAUNCH_CCONV(8)
     else if (cout <= 32)
         ASR_LAUNCH_CCONV(32)

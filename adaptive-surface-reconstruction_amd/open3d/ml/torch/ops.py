@@ -75,6 +75,64 @@ _lib.impl("continuous_conv", _continuous_conv_gpu, "CUDA")
 _lib.impl("invert_neighbors_list", _invert_gpu, "CUDA")
 _lib.impl("reduce_subarrays_sum", _reduce_gpu, "CUDA")
 
+# ---- backward passes ("next" row f4): training on the MI355X ---------------------------------------------
+# open3d::sparse_conv, out[q] = (1/n_q) sum_p imp_p W[k_p]^T f[idx_p]  (models/common_torch.py:133-142):
+#   d f[i]  = sum over the pairs p that read input i of (imp_p / n_q(p)) W[k_p] g[q(p)]: the SAME gather-GEMM on the
+#             transposed graph (inverted neighbour list, filters transposed per slot) -- run by the forward HIP kernel;
+#   d W[k]  = F_k^T G_k with F_k / G_k the (importance scaled) input rows / output gradients of the pairs that use
+#             slot k: 55 plain GEMMs (library GEMM through torch.matmul).
+# Importance arrays come from the geometry (scale compatibility x window), not from learnable tensors: no gradient.
+def _sparse_conv_setup(ctx, inputs, output):
+    (filters, inp_features, _, neighbors_index, neighbors_kernel_index, neighbors_importance, neighbors_row_splits,
+     normalize, _) = inputs
+    ctx.save_for_backward(filters, inp_features, neighbors_index, neighbors_kernel_index, neighbors_importance,
+                          neighbors_row_splits)
+    ctx.normalize = bool(normalize)
+
+
+def _sparse_conv_backward(ctx, grad):
+    filters, f, idx, kidx, nimp, rs = ctx.saved_tensors
+    K = filters.shape[0]
+    v, n_in = rs.shape[0] - 1, f.shape[0]
+    grad = grad.contiguous()
+    has_imp = nimp.numel() > 0
+    lens = rs[1:] - rs[:-1]
+    row = torch.repeat_interleave(torch.arange(v, device=f.device), lens)      # output row of every pair
+    if ctx.normalize and has_imp:
+        norm = torch.ops.open3d.reduce_subarrays_sum(nimp, rs)
+        grad = grad / torch.where(norm != 0, norm, torch.ones_like(norm))[:, None]
+    g_filters = g_feats = None
+    if ctx.needs_input_grad[1]:
+        # transposed graph: rows = input points, entries in the order open3d::invert_neighbors_list produces
+        order = torch.argsort(idx.long(), stable=True)
+        inv_rs = torch.zeros(n_in + 1, dtype=torch.int64, device=f.device)
+        inv_rs[1:] = torch.cumsum(torch.bincount(idx.long(), minlength=n_in), 0)
+        g_feats = _hip().sparse_conv(filters.transpose(1, 2).contiguous(), grad, row[order].to(torch.int32),
+                                     kidx[order], inv_rs, neighbors_importance=nimp[order] if has_imp else None)
+    if ctx.needs_input_grad[0]:
+        g_filters = torch.zeros_like(filters)
+        src = f.index_select(0, idx.long())
+        if has_imp:
+            src = src * nimp[:, None]
+        slot = kidx.long()
+        for k in torch.unique(slot).tolist():
+            sel = torch.nonzero(slot == k).reshape(-1)
+            g_filters[k] = src.index_select(0, sel).t() @ grad.index_select(0, row.index_select(0, sel))
+    return g_filters, g_feats, None, None, None, None, None, None, None
+
+
+def _reduce_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1])
+
+
+def _reduce_backward(ctx, grad):
+    (rs,) = ctx.saved_tensors
+    return torch.repeat_interleave(grad, rs[1:] - rs[:-1]), None
+
+
+torch.library.register_autograd("open3d::sparse_conv", _sparse_conv_backward, setup_context=_sparse_conv_setup)
+torch.library.register_autograd("open3d::reduce_subarrays_sum", _reduce_backward, setup_context=_reduce_setup)
+
 sparse_conv = torch.ops.open3d.sparse_conv
 continuous_conv = torch.ops.open3d.continuous_conv
 reduce_subarrays_sum = torch.ops.open3d.reduce_subarrays_sum

@@ -715,6 +715,50 @@ static void sparse_conv_t(const float* filters, const float* feat, i64 feat_ld, 
         }
     }
 }
+// The same operator evaluated the way Open3D v0.14.1 does on the CPU ([upstream-memory], SURVEY 6 "dense-B
+// evaluation"): per block of 32 output voxels a dense matrix B[32][K*cin] is filled with the (importance scaled)
+// neighbour features at their slots, zeros elsewhere, and multiplied with the filter matrix [K*cin][cout] -- K*cin
+// deep for every voxel although only ~8 of the 55 slots are occupied.  Used for the cpu_baseline of bench.py
+// (what the reference's CPU path costs); results equal sparse_conv_t<float> up to the order of the fp32 sums.
+static void sparse_conv_dense(const float* filters, const float* feat, i64 feat_ld, const int32_t* nidx,
+                              const uint8_t* nk, const float* nimp, const i64* rs, i64 v, int K, int cin,
+                              int cout, int normalize, float* out, i64 out_ld) {
+    const int BLOCK = 32;
+    const size_t depth = (size_t)K * cin;
+#pragma omp parallel
+    {
+        std::vector<float> B((size_t)BLOCK * depth);
+        std::vector<float> norm(BLOCK);
+#pragma omp for schedule(dynamic, 4)
+        for (i64 q0 = 0; q0 < v; q0 += BLOCK) {
+            const int nb = (int)std::min<i64>(BLOCK, v - q0);
+            std::fill(B.begin(), B.end(), 0.f);
+            for (int r = 0; r < nb; ++r) {
+                norm[r] = 0.f;
+                for (i64 p = rs[q0 + r]; p < rs[q0 + r + 1]; ++p) {
+                    const float w = nimp ? nimp[p] : 1.f;
+                    norm[r] += w;
+                    const float* f = feat + i64(nidx[p]) * feat_ld;
+                    float* b = &B[(size_t)r * depth + (size_t)nk[p] * cin];
+                    for (int ic = 0; ic < cin; ++ic) b[ic] = w * f[ic];
+                }
+            }
+            for (int r = 0; r < nb; ++r) {  // dense GEMM row by row: out[r] = B[r] * filters
+                float* o = out + (q0 + r) * out_ld;
+                for (int oc = 0; oc < cout; ++oc) o[oc] = 0.f;
+                const float* b = &B[(size_t)r * depth];
+                for (size_t d = 0; d < depth; ++d) {
+                    const float a = b[d];
+                    const float* wr = filters + d * cout;
+                    for (int oc = 0; oc < cout; ++oc) o[oc] += wr[oc] * a;
+                }
+                if (normalize && norm[r] != 0.f)
+                    for (int oc = 0; oc < cout; ++oc) o[oc] /= norm[r];
+            }
+        }
+    }
+}
+static int g_dense = 0;
 static int g_precise = 0;
 static int& precise_flag() { return g_precise; }
 static void sparse_conv(const float* filters, const float* feat, i64 feat_ld, const int32_t* nidx,
@@ -724,6 +768,14 @@ static void sparse_conv(const float* filters, const float* feat, i64 feat_ld, co
         sparse_conv_t<double>(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
     else
         sparse_conv_t<float>(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
+}
+static void sparse_conv_k(const float* filters, const float* feat, i64 feat_ld, const int32_t* nidx,
+                          const uint8_t* nk, const float* nimp, const i64* rs, i64 v, int K, int cin,
+                          int cout, int normalize, float* out, i64 out_ld) {
+    if (g_dense && !g_precise)
+        sparse_conv_dense(filters, feat, feat_ld, nidx, nk, nimp, rs, v, K, cin, cout, normalize, out, out_ld);
+    else
+        sparse_conv(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
 }
 
 
@@ -1154,6 +1206,14 @@ void orc_sparse_conv(const float* filters, const float* feat, i64 feat_ld, const
                      int cout, int normalize, float* out, i64 out_ld) {
     sparse_conv(filters, feat, feat_ld, nidx, nk, nimp, rs, v, cin, cout, normalize, out, out_ld);
 }
+// with the kernel size: takes the dense (Open3D-style) evaluation when orc_set_dense(1) is active
+void orc_sparse_conv_k(const float* filters, int K, const float* feat, i64 feat_ld, const int32_t* nidx,
+                       const uint8_t* nk, const float* nimp, const i64* rs, i64 v, int cin,
+                       int cout, int normalize, float* out, i64 out_ld) {
+    sparse_conv_k(filters, feat, feat_ld, nidx, nk, nimp, rs, v, K, cin, cout, normalize, out, out_ld);
+}
+void orc_set_dense(int on) { g_dense = on; }
+int orc_get_dense() { return g_dense; }
 // nsearch.cpp:30-51 KDTree::ComputeKRadius, brute force: radius_i = sqrt of the k-th smallest
 // squared distance (the point itself included), squared distances as in sqdist() above.
 void orc_knn_radius(const float* pts, i64 n, int k, float* out) {

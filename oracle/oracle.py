@@ -185,6 +185,21 @@ class Oracle:
         return idx, dist, rs, compat
 
 
+class dense:
+    """context manager: sparse_conv evaluated the way Open3D's CPU op does (a dense [32][K*cin] matrix per block
+    of 32 voxels times the filter matrix -- 55*cin deep for every voxel although ~8 slots are occupied).
+    The cpu_baseline of bench.py runs under it: that is what the reference's CPU path costs."""
+
+    def __enter__(self):
+        self._old = lib().orc_get_dense()
+        lib().orc_set_dense(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_dense(self._old)
+        return False
+
+
 class precise:
     """context manager: the floating point ops (continuous_conv, sparse_conv, decode) accumulate in
     double and round once -- the value every fp32 summation order approximates.  Checker for the
@@ -238,9 +253,8 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
     if neighbors_importance is not None and len(neighbors_importance):
         nimp = _f32(neighbors_importance)
     out = np.zeros((v, cout), np.float32)
-    lib().orc_sparse_conv(_p(filters), _p(inp_features), i64(cin), _p(nidx), _p(nk), _p(nimp),
-                          _p(rs), i64(v), int(cin), int(cout), int(bool(normalize)), _p(out),
-                          i64(cout))
+    lib().orc_sparse_conv_k(_p(filters), int(filters.shape[0]), _p(inp_features), i64(cin), _p(nidx), _p(nk),
+                            _p(nimp), _p(rs), i64(v), int(cin), int(cout), int(bool(normalize)), _p(out), i64(cout))
     return out
 
 

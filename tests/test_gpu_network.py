@@ -321,6 +321,48 @@ def test_batched_tiling_orders_equal_the_per_csr_routine(gpu):
                 assert torch.equal(torch.sort(got.long()).values, torch.arange(got.numel(), device=gpu))
 
 
+def test_sparse_conv_backward_against_torch_autograd(geo, gpu):
+    """"next" row f4: gradients of open3d::sparse_conv / reduce_subarrays_sum (models/common_torch.py:127-142) with
+    respect to features and filters, against torch autograd over a dense fp64 restatement of the same sum"""
+    import open3d.ml.torch as ml3d
+    pts, nrm, rad, bb, item = geo
+    rng = np.random.default_rng(17)
+    for level, cin, cout, with_imp in ((2, 8, 12, True), (3, 16, 8, False)):
+        idx, kidx, rs = (item["neighbors_index%d" % level], item["neighbors_kernel_index%d" % level],
+                         item["neighbors_row_splits%d" % level])
+        v = len(rs) - 1
+        f0 = rng.standard_normal((v, cin)).astype(np.float32)
+        W0 = (rng.standard_normal((55, cin, cout)) * 0.2).astype(np.float32)
+        imp = rng.uniform(0.1, 1.0, size=len(idx)).astype(np.float32)
+        gout = rng.standard_normal((v, cout)).astype(np.float32)
+        empty = torch.empty((0,), dtype=torch.float32, device=gpu)
+        f = _t(f0, gpu).requires_grad_(True)
+        W = _t(W0, gpu).requires_grad_(True)
+        nimp = _t(imp, gpu) if with_imp else empty
+        out = ml3d.ops.sparse_conv(filters=W, inp_features=f, inp_importance=empty, neighbors_index=_t(idx, gpu),
+                                   neighbors_kernel_index=_t(kidx, gpu), neighbors_importance=nimp,
+                                   neighbors_row_splits=_t(rs, gpu), normalize=with_imp)
+        out.backward(_t(gout, gpu))
+        # dense fp64 reference on the CPU
+        fr = torch.from_numpy(f0).double().requires_grad_(True)
+        Wr = torch.from_numpy(W0).double().requires_grad_(True)
+        row = torch.repeat_interleave(torch.arange(v), torch.from_numpy(np.diff(rs)))
+        w = torch.from_numpy(imp).double() if with_imp else torch.ones(len(idx), dtype=torch.float64)
+        contrib = torch.einsum("pc,pco->po", fr[torch.from_numpy(idx).long()] * w[:, None], Wr[torch.from_numpy(kidx).long()])
+        ref = torch.zeros((v, cout), dtype=torch.float64).index_add(0, row, contrib)
+        if with_imp:
+            ref = ref / torch.zeros(v, dtype=torch.float64).index_add(0, row, w)[:, None]
+        _close(out.detach().cpu().numpy(), ref.detach().numpy())
+        ref.backward(torch.from_numpy(gout).double())
+        _close(f.grad.cpu().numpy(), fr.grad.numpy(), 2e-5, 2e-5)
+        _close(W.grad.cpu().numpy(), Wr.grad.numpy(), 2e-5, 2e-5)
+    vals = _t(rng.uniform(0, 1, size=len(idx)).astype(np.float32), gpu).requires_grad_(True)
+    s = ml3d.ops.reduce_subarrays_sum(vals, _t(rs, gpu))
+    s.backward(torch.arange(v, dtype=torch.float32, device=gpu))
+    assert torch.equal(vals.grad, torch.repeat_interleave(torch.arange(v, dtype=torch.float32, device=gpu),
+                                                          _t(np.diff(rs), gpu)))
+
+
 def test_octree_handles_are_self_contained(gpu):
     """module.cpp:230-235: create_dual_vertex_indices works on any live tree, however many were built since
     (models/v0/datareader.py:224-243,802 keeps trees across calls)"""

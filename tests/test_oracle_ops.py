@@ -136,3 +136,23 @@ def test_every_layer_of_the_reference_graph_separately():
         assert np.array_equal(out, l["out"]), l["name"]
         if nimp is not None:
             assert np.array_equal(O.reduce_subarrays_sum(nimp, rs), l["oimp"]), l["name"]
+
+
+def test_dense_open3d_style_evaluation_equals_the_pairwise_one():
+    """O.dense(): the [32][K*cin] x [K*cin][cout] evaluation Open3D's CPU op performs (bench.py's cpu_baseline runs
+    under it) gives the pairwise result up to the order of the fp32 sums"""
+    rng = np.random.default_rng(1)
+    v, cin, cout = 700, 12, 20
+    lens = rng.integers(1, 12, size=v)
+    rs = np.zeros(v + 1, np.int64)
+    rs[1:] = np.cumsum(lens)
+    idx = rng.integers(0, v, size=rs[-1]).astype(np.int32)
+    kidx = np.concatenate([np.sort(rng.choice(55, size=l, replace=False)) for l in lens]).astype(np.uint8)
+    f = rng.standard_normal((v, cin)).astype(np.float32)
+    W = rng.standard_normal((55, cin, cout)).astype(np.float32)
+    imp = rng.uniform(0.1, 1, size=rs[-1]).astype(np.float32)
+    for nimp, normalize in ((None, False), (imp, True)):
+        a = O.sparse_conv(W, f, idx, kidx, nimp, rs, normalize)
+        with O.dense():
+            b = O.sparse_conv(W, f, idx, kidx, nimp, rs, normalize)
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())

@@ -106,7 +106,7 @@ EXPORTS = [
     "asr_hip_unordered_set_order", "asr_density_inlier",
     "asr_hip_grid_neighbors_count", "asr_hip_grid_neighbors_fill", "asr_hip_grid_coarsen_count",
     "asr_hip_grid_coarsen_fill", "asr_hip_voxel_info", "asr_hip_multi_radius_search_count",
-    "asr_hip_multi_radius_search_fill", "asr_hip_knn_radius", "asr_hip_radius_neighbor_count", "asr_hip_continuous_conv_f32",
+    "asr_hip_multi_radius_search_fill", "asr_hip_knn_radius", "asr_hip_radius_neighbor_count", "asr_hip_continuous_conv_f32", "asr_hip_continuous_conv_basis_f32",
     "asr_hip_aggregation_importance", "asr_hip_sparse_conv_f32", "asr_hip_invert_neighbors_list", "asr_hip_row_groups",
     "asr_hip_reduce_subarrays_sum", "asr_hip_decode_mlp", "asr_hip_implicit_build",
     "asr_hip_implicit_network", "asr_hip_implicit_forward", "asr_hip_implicit_get",

@@ -266,6 +266,31 @@ def continuous_conv(filters, out_positions, extents, inp_positions, inp_features
     return out
 
 
+def continuous_conv_basis(out_positions, extents, inp_positions, inp_features, neighbors_index,
+                          neighbors_importance, neighbors_row_splits):
+    """per-output interpolation matrices [V, 64*cin] and importance sums [V] of the continuous conv (cin = 4):
+    the filter gradient is basis^T (grad / norm) (asr_hip_continuous_conv_basis_f32)"""
+    out_positions = _dev(out_positions, torch.float32)
+    v = out_positions.shape[0]
+    extents = _dev(extents, torch.float32).reshape(-1)
+    if extents.shape[0] == 1 and v != 1:
+        extents = extents.expand(v).contiguous()
+    inp_positions = _dev(inp_positions, torch.float32)
+    inp_features = _dev(inp_features, torch.float32)
+    cin = inp_features.shape[1]
+    nidx = _dev(neighbors_index, torch.int32)
+    rs = _dev(neighbors_row_splits, torch.int64)
+    nimp = None
+    if neighbors_importance is not None and neighbors_importance.numel():
+        nimp = _dev(neighbors_importance, torch.float32)
+    basis = torch.empty((v, 64 * cin), dtype=torch.float32, device=out_positions.device)
+    norm = torch.empty(v, dtype=torch.float32, device=out_positions.device)
+    dev = _same_device(out_positions, extents, inp_positions, inp_features, nidx, rs, nimp)
+    context(dev).call("asr_hip_continuous_conv_basis_f32", ptr(out_positions), ptr(extents), ptr(inp_positions),
+                      ptr(inp_features), ptr(nidx), ptr(nimp), ptr(rs), i64(v), int(cin), ptr(basis), ptr(norm))
+    return basis, norm
+
+
 def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
                 neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False,
                 residual=None, out=None, return_importance=False, algo=0,

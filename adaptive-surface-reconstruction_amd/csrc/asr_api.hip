@@ -355,6 +355,16 @@ int asr_hip_continuous_conv_f32(asr_hip_context* ctx, const float* filters, cons
     return asr_conv_cconv(ctx, filters, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs, num_out,
                           cin, cout, normalize, bias, relu, out);
 }
+int asr_hip_continuous_conv_basis_f32(asr_hip_context* ctx, const float* out_pos, const float* extents,
+                                      const float* inp_pos, const float* inp_feat, const int32_t* nidx,
+                                      const float* nimp, const int64_t* rs, int64_t num_out, int cin, float* basis_out,
+                                      float* norm_out) {
+    CTX_GUARD(ctx);
+    if (cin != 4) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv_basis: cin must be 4");
+    if (num_out > 0 && (!out_pos || !extents || !inp_pos || !inp_feat || !rs || !basis_out || !norm_out))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv_basis: null argument");
+    return asr_conv_cconv_basis(ctx, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs, num_out, basis_out, norm_out);
+}
 int asr_hip_aggregation_importance(asr_hip_context* ctx, const float* compat, const float* dist,
                                    int64_t n, float* out) {
     CTX_GUARD(ctx);

@@ -304,6 +304,9 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
                    const float* extents, const float* inp_pos, const float* inp_feat,
                    const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
                    int cout, int normalize, const float* bias, int relu, float* out, int sorted4 = 0);
+int asr_conv_cconv_basis(asr_hip_context* ctx, const float* out_pos, const float* extents, const float* inp_pos,
+                         const float* inp_feat, const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out,
+                         float* basis_out, float* norm_out);
 int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* args);
 // asr_conv16.hip: 16-bit matrix-core variants (f16 activations / exact bf16x3 split)
 size_t asr_conv16_packed_bytes(int mode, int K, int cin, int cout, int cout_b);

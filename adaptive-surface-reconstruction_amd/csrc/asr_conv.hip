@@ -247,7 +247,9 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
         const float4* __restrict__ rec, const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
         const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
         const i64* __restrict__ rs, i64 num_out, int cout, int normalize, const float* __restrict__ bias, int relu,
-        float* __restrict__ out, i64 heavy_rows) {
+        float* __restrict__ out, i64 heavy_rows, float* __restrict__ basis_out, float* __restrict__ norm_out) {
+    // basis_out != null ("next" row f4, filter gradient): only the per-voxel matrices B[v][256] and the importance sums
+    // are written; the contraction happens in the caller (dW = B^T g)
     __shared__ __attribute__((aligned(16))) float s_bt[8][CCG][CCG_LD];
     __shared__ __attribute__((aligned(16))) float4 s_pair[8][128];
     __shared__ float s_norm[8][CCG];
@@ -366,7 +368,12 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
             *reinterpret_cast<float4*>(&s_bt[wib][u][4 * lane]) = make_float4(B0, B1, B2, B3);
             const float norm = wave_sum_dpp(norm_lane);
             if (lane == 0) s_norm[wib][u] = heavy ? -1.f : norm;  // -1: written by k_cconv_heavy
+            if (basis_out && q0 + u < num_out) {
+                *reinterpret_cast<float4*>(&basis_out[(q0 + u) * 256 + 4 * lane]) = make_float4(B0, B1, B2, B3);
+                if (lane == 0) norm_out[q0 + u] = norm;
+            }
         }
+        if (basis_out) continue;
         __builtin_amdgcn_wave_barrier();
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -995,11 +1002,11 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
         if (sorted4)
             k_cconv_mfma<true><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, (const float4*)inp_pos, nullptr,
                                                              nullptr, nidx, nimp, rs, num_out, cout, normalize, bias,
-                                                             relu, out, CCONV_HEAVY);
+                                                             relu, out, CCONV_HEAVY, nullptr, nullptr);
         else
             k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, nullptr, inp_pos, inp_feat,
                                                               nidx, nimp, rs, num_out, cout, normalize, bias, relu,
-                                                              out, CCONV_HEAVY);
+                                                              out, CCONV_HEAVY, nullptr, nullptr);
     } else if (cout <= 8)
         ASR_LAUNCH_CCONV(8)
     else if (cout <= 32)
@@ -1017,6 +1024,21 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
 #undef ASR_LAUNCH_CCONV_HEAVY
 #undef ASR_LAUNCH_CCONV_S
 #undef ASR_LAUNCH_CCONV_HEAVY_S
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+// per-voxel interpolation matrices B[v][64 cells][4 channels] (un-normalised) and importance sums of the continuous
+// conv: what the filter gradient contracts with (dW[cell][c][o] = sum_v B[v][cell][c] g[v][o] / norm[v])
+int asr_conv_cconv_basis(asr_hip_context* ctx, const float* out_pos, const float* extents, const float* inp_pos,
+                         const float* inp_feat, const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out,
+                         float* basis_out, float* norm_out) {
+    if (num_out <= 0) return ASR_HIP_OK;
+    const float* zeros = nullptr;
+    ASR_TRY(asr_ctx_zeros(ctx, &zeros));  // stands in for the (unused) filter matrix
+    k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(zeros, out_pos, extents, nullptr, inp_pos, inp_feat, nidx, nimp,
+                                                      rs, num_out, 0, 0, nullptr, 0, nullptr,
+                                                      (i64)0x7fffffff, basis_out, norm_out);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }

@@ -130,6 +130,33 @@ def _reduce_backward(ctx, grad):
     return torch.repeat_interleave(grad, rs[1:] - rs[:-1]), None
 
 
+# open3d::continuous_conv: gradient with respect to the filters (the aggregation block's inputs are data: normals and a
+# constant, net_definitions_torch.py:640-653).  dW[cell][c][o] = sum_v B[v][cell][c] g[v][o] / norm[v] with the
+# per-voxel interpolation matrices B from the HIP kernel (asr_hip_continuous_conv_basis_f32) and one library GEMM.
+def _cconv_setup(ctx, inputs, output):
+    (filters, out_positions, extents, _, inp_positions, inp_features, _, neighbors_index, neighbors_importance,
+     neighbors_row_splits, _, _, normalize, _, _) = inputs
+    ctx.save_for_backward(filters, out_positions, extents, inp_positions, inp_features, neighbors_index,
+                          neighbors_importance, neighbors_row_splits)
+    ctx.normalize = bool(normalize)
+
+
+def _cconv_backward(ctx, grad):
+    filters, out_positions, extents, inp_positions, inp_features, nidx, nimp, rs = ctx.saved_tensors
+    if ctx.needs_input_grad[5] or ctx.needs_input_grad[4] or ctx.needs_input_grad[1]:
+        raise RuntimeError("continuous_conv: only the gradient with respect to the filters is implemented")
+    g_filters = None
+    if ctx.needs_input_grad[0]:
+        basis, norm = _hip().continuous_conv_basis(out_positions, extents, inp_positions, inp_features, nidx,
+                                                   nimp if nimp.numel() else None, rs)
+        g = grad.contiguous()
+        if ctx.normalize:
+            g = g / torch.where(norm != 0, norm, torch.ones_like(norm))[:, None]
+        g_filters = (basis.t() @ g).reshape(filters.shape)
+    return (g_filters,) + (None,) * 14
+
+
+torch.library.register_autograd("open3d::continuous_conv", _cconv_backward, setup_context=_cconv_setup)
 torch.library.register_autograd("open3d::sparse_conv", _sparse_conv_backward, setup_context=_sparse_conv_setup)
 torch.library.register_autograd("open3d::reduce_subarrays_sum", _reduce_backward, setup_context=_reduce_setup)
 

@@ -200,6 +200,14 @@ int asr_hip_continuous_conv_f32(asr_hip_context* ctx, const float* filters_dev,
                                 const int64_t* neighbors_row_splits_dev, int64_t num_out,
                                 int cin, int cout, int normalize, const float* bias_dev,
                                 int relu, float* out_dev);
+/* Backward support ("next" row f4): per-output interpolation matrices basis_out [num_out, 4*4*4*cin] (filter cell
+ * major, un-normalised: sum_p importance_p * trilinear_weight(cell, p) * feature_p[c]) and importance sums norm_out
+ * [num_out]; the filter gradient is dW = basis^T (g / norm).  cin must be 4. */
+int asr_hip_continuous_conv_basis_f32(asr_hip_context* ctx, const float* out_positions_dev, const float* extents_dev,
+                                      const float* inp_positions_dev, const float* inp_features_dev,
+                                      const int32_t* neighbors_index_dev, const float* neighbors_importance_dev,
+                                      const int64_t* neighbors_row_splits_dev, int64_t num_out, int cin,
+                                      float* basis_out_dev, float* norm_out_dev);
 /* neighbors_importance = compat * clamp((1-d)^3,0,1) (models/common_torch.py:21-22,
  * net_definitions_torch.py:107) */
 int asr_hip_aggregation_importance(asr_hip_context* ctx, const float* compat_dev,

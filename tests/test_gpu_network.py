@@ -363,6 +363,37 @@ def test_sparse_conv_backward_against_torch_autograd(geo, gpu):
                                                           _t(np.diff(rs), gpu)))
 
 
+def test_continuous_conv_filter_gradient(geo, gpu):
+    """"next" row f4: the continuous conv is linear in its filters, so <dL/dW, D> must equal L(W + D) - L(W) for any
+    direction D (L = sum(out * g)); the gradient comes from the HIP basis kernel + one GEMM"""
+    import open3d.ml.torch as ml3d
+    pts, nrm, rad, bb, item = geo
+    rng = np.random.default_rng(23)
+    feats = _t(np.concatenate([nrm, np.ones((len(pts), 1), np.float32)], 1), gpu)
+    nimp = _t(rng.uniform(0.1, 1, size=len(item["aggregation_neighbors_index"])).astype(np.float32), gpu)
+    args = dict(out_positions=_t(item["voxel_centers0"], gpu), extents=_t(item["voxel_sizes0"], gpu),
+                offset=torch.zeros(3, device=gpu), inp_positions=_t(pts, gpu), inp_features=feats,
+                inp_importance=torch.empty((0,), device=gpu), neighbors_index=_t(item["aggregation_neighbors_index"], gpu),
+                neighbors_importance=nimp, neighbors_row_splits=_t(item["aggregation_row_splits"], gpu),
+                align_corners=True, coordinate_mapping="ball_to_cube_radial", interpolation="linear")
+    for normalize in (True, False):
+        W = _t((rng.standard_normal((4, 4, 4, 4, 32)) * 0.3).astype(np.float32), gpu).requires_grad_(True)
+        D = _t((rng.standard_normal((4, 4, 4, 4, 32)) * 0.3).astype(np.float32), gpu)
+        g = _t(rng.standard_normal((len(item["voxel_sizes0"]), 32)).astype(np.float32), gpu)
+        out = ml3d.ops.continuous_conv(filters=W, normalize=normalize, **args)
+        (out * g).sum().backward()
+        with torch.no_grad():
+            l0 = (out.double() * g.double()).sum()
+            l1 = (ml3d.ops.continuous_conv(filters=W + D, normalize=normalize, **args).double() * g.double()).sum()
+            want = float(l1 - l0)
+            got = float((W.grad.double() * D.double()).sum())
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (normalize, got, want)
+    with pytest.raises(RuntimeError):  # gradients with respect to the point features are not implemented
+        f = feats.clone().requires_grad_(True)
+        a2 = dict(args, inp_features=f)
+        ml3d.ops.continuous_conv(filters=W.detach(), normalize=True, **a2).sum().backward()
+
+
 def test_octree_handles_are_self_contained(gpu):
     """module.cpp:230-235: create_dual_vertex_indices works on any live tree, however many were built since
     (models/v0/datareader.py:224-243,802 keeps trees across calls)"""

@@ -28,14 +28,32 @@ struct HashTab {
     u64 mask;
 };
 
+// Probe sequence of a key.  Locality preserving: the low 6 bits of a location code (two levels of child index = the
+// position inside a 4 x 4 x 4 block of cells) are kept, only the block id is scrambled.  The keys of one block land in
+// one 64-slot bucket (512 B) at distinct slots, and the probes a voxel makes for its face neighbours -- or a wave of
+// Morton-ordered voxels makes together -- stay in a few cache lines instead of one random line per probe.  A
+// collision (another block hashed to the same bucket) moves to the SAME position of another bucket (double
+// hashing over buckets): stepping to the next slot instead would run through the neighbouring keys of both
+// blocks (measured: 5x slower than plain hashing).  cap is a power of two >= 64, the bucket step is odd.
+struct TabProbe {
+    u64 bucket, step, low, bmask;
+    __device__ inline u64 slot() const { return ((bucket & bmask) << 6) | low; }
+    __device__ inline void next() { bucket += step; }
+};
+__device__ inline TabProbe tab_probe(const HashTab& t, u64 key) {
+    const u64 h = asr_hash64(key >> 6);
+    return TabProbe{h, (h >> 32) | 1, key & 63, t.mask >> 6};
+}
+
 __device__ inline u64 ld_agent(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // returns 1 = inserted, 0 = existed, -1 = table full; slot_out = slot of the key
 __device__ inline int tab_insert(const HashTab& t, u64 key, u64* slot_out = nullptr) {
-    u64 slot = asr_hash64(key) & t.mask;
-    for (u64 probe = 0; probe <= t.mask; ++probe) {
+    TabProbe pr = tab_probe(t, key);
+    for (u64 probe = 0; probe <= pr.bmask; ++probe, pr.next()) {
+        const u64 slot = pr.slot();
         u64 cur = ld_agent(&t.keys[slot]);
         if (cur == 0) {
             cur = atomicCAS((unsigned long long*)&t.keys[slot], 0ull, (unsigned long long)key);
@@ -48,38 +66,37 @@ __device__ inline int tab_insert(const HashTab& t, u64 key, u64* slot_out = null
             if (slot_out) *slot_out = slot;
             return 0;
         }
-        slot = (slot + 1) & t.mask;
     }
     return -1;
 }
 // lookup after the building kernel finished (plain loads)
 __device__ inline bool tab_contains(const HashTab& t, u64 key) {
-    u64 slot = asr_hash64(key) & t.mask;
-    for (u64 probe = 0; probe <= t.mask; ++probe) {
-        u64 cur = t.keys[slot];
+    TabProbe pr = tab_probe(t, key);
+    for (u64 probe = 0; probe <= pr.bmask; ++probe, pr.next()) {
+        const u64 slot = pr.slot();
+        const u64 cur = t.keys[slot];
         if (cur == key) return true;
         if (cur == 0) return false;
-        slot = (slot + 1) & t.mask;
     }
     return false;
 }
 __device__ inline int tab_find(const HashTab& t, u64 key) {
-    u64 slot = asr_hash64(key) & t.mask;
-    for (u64 probe = 0; probe <= t.mask; ++probe) {
-        u64 cur = t.keys[slot];
+    TabProbe pr = tab_probe(t, key);
+    for (u64 probe = 0; probe <= pr.bmask; ++probe, pr.next()) {
+        const u64 slot = pr.slot();
+        const u64 cur = t.keys[slot];
         if (cur == key) return t.vals[slot];
         if (cur == 0) return -1;
-        slot = (slot + 1) & t.mask;
     }
     return -1;
 }
 __device__ inline i64 tab_find_slot(const HashTab& t, u64 key) {
-    u64 slot = asr_hash64(key) & t.mask;
-    for (u64 probe = 0; probe <= t.mask; ++probe) {
-        u64 cur = t.keys[slot];
+    TabProbe pr = tab_probe(t, key);
+    for (u64 probe = 0; probe <= pr.bmask; ++probe, pr.next()) {
+        const u64 slot = pr.slot();
+        const u64 cur = t.keys[slot];
         if (cur == key) return (i64)slot;
         if (cur == 0) return -1;
-        slot = (slot + 1) & t.mask;
     }
     return -1;
 }
@@ -225,13 +242,13 @@ __global__ void k_balance_insert(HashTab t, u64* list, int lo, int ngroups, cons
     if (key == 0) return;
     insert_with_ancestors(t, key, cnt, list, list_cap);
 }
-// leaves = nodes without first child (InitAttributesAndLeaves, octree.cpp:208-228)
-__global__ void k_collect_leaves(HashTab t, const u64* nodes, i64 n, u64* leaves, int* cnt) {
+// leaves = nodes without first child (InitAttributesAndLeaves, octree.cpp:208-228): flags over the SORTED node
+// array, compacted in order (the leaves come out sorted: no second radix sort)
+__global__ void k_leaf_flags(HashTab t, const u64* nodes, i64 n, uint8_t* flags) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    u64 k = i < n ? nodes[i] : 0;
-    bool leaf = k != 0 && !((__clzll((long long)k) > 1) && tab_contains(t, k << 3));
-    int pl = block_append(leaf, &cnt[4]);
-    if (leaf) leaves[pl] = k;
+    if (i >= n) return;
+    const u64 k = nodes[i];
+    flags[i] = (k != 0 && !((__clzll((long long)k) > 1) && tab_contains(t, k << 3))) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1179,12 +1196,12 @@ __device__ inline u64 dev_morton_sub(u64 a, u64 b) {
 }
 // map: node key -> leaf index, or -1 for inner nodes; returns -2 when the key is no node
 __device__ inline int node_lookup(const HashTab& t, u64 key) {
-    u64 slot = asr_hash64(key) & t.mask;
-    for (u64 probe = 0; probe <= t.mask; ++probe) {
-        u64 cur = t.keys[slot];
+    TabProbe pr = tab_probe(t, key);
+    for (u64 probe = 0; probe <= pr.bmask; ++probe, pr.next()) {
+        const u64 slot = pr.slot();
+        const u64 cur = t.keys[slot];
         if (cur == key) return t.vals[slot];
         if (cur == 0) return -2;
-        slot = (slot + 1) & t.mask;
     }
     return -2;
 }
@@ -1274,9 +1291,10 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
     ASR_TRY(ensure_flags(ctx));
     if (max_depth > ASR_MAX_LEVEL) max_depth = ASR_MAX_LEVEL;
     if (max_depth < 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "max_depth must be >= 0");
-    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 4 * n));
+    // nodes of a scan are ~0.3 n; the table must stay at most half full (cap / 2 list entries), else retry 4x larger
+    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 2 * n));
     int host[16];
-    for (int attempt = 0; attempt < 6; ++attempt, cap <<= 2) {
+    for (int attempt = 0; attempt < 7; ++attempt, cap <<= 2) {
         ctx->scratch.reset();
         HashTab t;
         ASR_TRY(make_table(ctx, ctx->scratch, cap, false, t));
@@ -1319,18 +1337,28 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
             ASR_HIP_CHECK(ctx, hipMemcpyAsync(list + host[0], &one, sizeof(u64), hipMemcpyHostToDevice,
                                               ctx->stream));
         }
-        u64* leaves_u = arena_alloc<u64>(ctx->scratch, num_nodes);
-        if (!leaves_u) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_collect_leaves<<<grid_for(num_nodes, BLK), BLK, 0, ctx->stream>>>(t, list, num_nodes, leaves_u,
-                                                                           ctx->d_flags);
-        ASR_CHECK_LAUNCH(ctx);
-        ASR_TRY(read_flags(ctx, host));
-        i64 num_leaves = host[4];
         ctx->nodes = arena_alloc<u64>(ctx->persist, num_nodes);
-        ctx->leaves = arena_alloc<u64>(ctx->persist, num_leaves);
-        if (!ctx->nodes || !ctx->leaves) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        u64* leaves_tmp = arena_alloc<u64>(ctx->scratch, num_nodes);
+        uint8_t* lflag = arena_alloc<uint8_t>(ctx->scratch, num_nodes);
+        i64* d_num = arena_alloc<i64>(ctx->scratch, 1);
+        if (!ctx->nodes || !leaves_tmp || !lflag || !d_num) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(sort_keys(ctx, ctx->scratch, list, ctx->nodes, num_nodes));
-        ASR_TRY(sort_keys(ctx, ctx->scratch, leaves_u, ctx->leaves, num_leaves));
+        k_leaf_flags<<<grid_for(num_nodes, BLK), BLK, 0, ctx->stream>>>(t, ctx->nodes, num_nodes, lflag);
+        ASR_CHECK_LAUNCH(ctx);
+        {
+            size_t tb = 0;
+            ASR_HIP_CHECK(ctx, rocprim::select(nullptr, tb, ctx->nodes, lflag, leaves_tmp, d_num, (size_t)num_nodes,
+                                               ctx->stream));
+            void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+            if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_HIP_CHECK(ctx, rocprim::select(tmp, tb, ctx->nodes, lflag, leaves_tmp, d_num, (size_t)num_nodes,
+                                               ctx->stream));
+        }
+        i64 num_leaves = 0;
+        ASR_TRY(read_i64(ctx, d_num, &num_leaves));
+        ctx->leaves = arena_alloc<u64>(ctx->persist, num_leaves);
+        if (!ctx->leaves) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->leaves, leaves_tmp, 8 * num_leaves, hipMemcpyDeviceToDevice, ctx->stream));
         ctx->num_nodes = num_nodes;
         ctx->num_leaves = num_leaves;
         return ASR_HIP_OK;

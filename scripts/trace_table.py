@@ -11,7 +11,14 @@ t0, t1 = int(last[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in l
 agg = collections.OrderedDict()
 busy = 0
 for r in last:
-    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:90]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    if "rocprim" in n:  # keep the algorithm name and the key / value types
+        import re
+        m = re.search(r"wrapped_(\w+?)_config|detail::(\w+)_kernel", n)
+        kt = re.search(r"(unsigned long|int|long|unsigned char|unsigned int)\*?,\s*(unsigned long|int|long|rocprim::[\w:]+)", n)
+        n = "rocprim " + (m.group(1) or m.group(2) if m else "?") + (" <%s>" % kt.group(1) if kt else "")
+    else:
+        n = n.split("(")[0][:90]
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     a = agg.setdefault(n, [0, 0.0])
     a[0] += 1

@@ -218,39 +218,64 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
     u32x4 stage0[SV], stage1[SV];
     u32x4 a_q0[NJ * AW], a_q1[NJ * AW];
 
-    auto load_panel = [&](const int qk, const int qp, u32x4 (&st)[SV]) __attribute__((always_inline)) {
+    // Both operand streams go through raw buffer loads: the address of a piece is a per-thread byte offset
+    // that does not change from step to step (VGPR), plus a wave-uniform offset of the step (SGPR), plus an
+    // immediate -- no per-step vector address arithmetic next to the MFMAs.  Offsets beyond the buffer read as
+    // zero, which is how absent neighbours (OOB_OFF) and unused staging pieces load their zeros.
+    constexpr unsigned OOB_OFF = 0xFFFFE000u;
+    constexpr int RSRC_FLAGS = 0x00020000;
+    const __amdgpu_buffer_rsrc_t rs_w =
+            __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, (int)(PLANES * plane_stride * 2), RSRC_FLAGS);
+    unsigned w_off[SV];  // byte offset of this thread's pieces inside a (slot 0, panel 0) weight panel
+    int w_lds[SV];       // their swizzled position in the LDS panel
 #pragma unroll
-        for (int s = 0; s < SV; ++s) {
-            const int e = tid + s * NTHR;               // piece index: (plane, column, slot)
-            const int pl = e / PLANE_PIECES;
-            const int rem = e % PLANE_PIECES;
-            const int col = rem / SLOTS, slot = rem % SLOTS;
-            const int c = qp * KC + 8 * slot;
-            const bool ok = qk >= 0 && c < cin_pad && (SV_EXACT || e < PV);
-            const u16* src = packed + pl * plane_stride + ((i64)(qk < 0 ? 0 : qk) * ctot_pad + n0 + col) * cin_pad + c;
-            st[s] = *reinterpret_cast<const u32x4*>(ok ? (const void*)src : (const void*)zeros);
-        }
+    for (int s = 0; s < SV; ++s) {
+        const int e = tid + s * NTHR;  // piece index: (plane, column, slot)
+        const int pl = e / PLANE_PIECES;
+        const int rem = e % PLANE_PIECES;
+        const int col = rem / SLOTS, slot = rem % SLOTS;
+        const bool ok = SV_EXACT || e < PV;
+        w_off[s] = ok ? (unsigned)((pl * plane_stride + (i64)(n0 + col) * cin_pad + 8 * slot) * 2) : OOB_OFF;
+        w_lds[s] = ok ? pl * PLANE_PIECES + col * SLOTS + swz<KC>(col, slot) : -1;
+    }
+    auto load_panel = [&](const int qk, const int qp, u32x4 (&st)[SV]) __attribute__((always_inline)) {
+        const int soff = ((qk < 0 ? 0 : qk) * ctot_pad * cin_pad + qp * KC) * 2;
+#pragma unroll
+        for (int s = 0; s < SV; ++s) st[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)w_off[s], soff, 0);
     };
     auto store_panel = [&](int buf, const u32x4 (&st)[SV]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < SV; ++s) {
-            const int e = tid + s * NTHR;
-            const int pl = e / PLANE_PIECES;
-            const int rem = e % PLANE_PIECES;
-            const int col = rem / SLOTS, slot = rem % SLOTS;
-            if (SV_EXACT || e < PV) s_B[buf][pl * PLANE_PIECES + col * SLOTS + swz<KC>(col, slot)] = st[s];
-        }
+        for (int s = 0; s < SV; ++s)
+            if (SV_EXACT || w_lds[s] >= 0) s_B[buf][w_lds[s]] = st[s];
     };
-    int cache_k = -2;
-    const char* cache_row = (const char*)zeros;
-    bool cache_valid = false;
     constexpr int ESZ = MODE == ASR_CONV16_F16 ? 2 : 4;  // bytes per activation element
+    // feature rows: buffer addressing when the matrix spans less than 4 GB, 64-bit pointers otherwise
+    const i64 a_span = a.num_inp > 0 ? ((a.num_inp - 1) * a.inp_ld + cin) * ESZ : 0;
+    const bool a_big = a_span > (i64)(OOB_OFF - 4096);
+    const __amdgpu_buffer_rsrc_t rs_a =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.inp_features, 0, a_big ? 0 : (int)(unsigned)a_span, RSRC_FLAGS);
+    const bool cin_tail = cin % KC != 0;  // the last panel reads pieces beyond the row: they must be zero
+    int cache_k = -2;
+    unsigned cache_off = OOB_OFF;                   // byte offset of the lane's neighbour row + its 8 g columns
+    const char* cache_row = (const char*)zeros;     // a_big only
+    bool cache_valid = false;
     auto gather_a = [&](const int qk, const int qp, u32x4 (&aq)[NJ * AW]) __attribute__((always_inline)) {
         if (qk != cache_k) {
             cache_k = qk;
             const int idx = qk < 0 ? -1 : s_nbr[lrow * NBR_LD + qk];
             cache_valid = idx >= 0;
-            cache_row = (const char*)a.inp_features + (i64)(cache_valid ? idx : 0) * a.inp_ld * ESZ;
+            cache_off = cache_valid ? (unsigned)idx * (unsigned)(a.inp_ld * ESZ) + (unsigned)(8 * g * ESZ) : OOB_OFF;
+            if (a_big) cache_row = (const char*)a.inp_features + (i64)(cache_valid ? idx : 0) * a.inp_ld * ESZ;
+        }
+        if (!a_big && !cin_tail) {
+            const int soff = qp * KC * ESZ;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int h = 0; h < AW; ++h)
+                    aq[j * AW + h] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off + (32 * j + 4 * h) * ESZ,
+                                                                           soff, 0);
+            return;
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -259,8 +284,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
             for (int h = 0; h < AW; ++h) {
                 // cin % 8 == 0 (f16) / cin % 4 == 0 (f32): a 16-byte piece is inside or outside the row
                 const int cc = c + 4 * h;
-                const void* src = (cache_valid && cc < cin) ? (const void*)(cache_row + (i64)cc * ESZ) : (const void*)zeros;
-                aq[j * AW + h] = *reinterpret_cast<const u32x4*>(src);
+                if (a_big) {
+                    const void* src = (cache_valid && cc < cin) ? (const void*)(cache_row + (i64)cc * ESZ) : (const void*)zeros;
+                    aq[j * AW + h] = *reinterpret_cast<const u32x4*>(src);
+                } else {
+                    const unsigned vo = cc < cin ? cache_off + (unsigned)((32 * j + 4 * h) * ESZ) : OOB_OFF;
+                    aq[j * AW + h] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)vo, qp * KC * ESZ, 0);
+                }
             }
         }
     };
@@ -282,27 +312,55 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
     auto step = [&](u32x4 (&aq)[NJ * AW], u32x4 (&st_free)[SV], u32x4 (&st_next)[SV]) __attribute__((always_inline)) {
         int k2 = k1, p2 = p1;
         ASR_SEQ_ADVANCE(todo1, k2, p2)
-        u32x4 a_cur[NJ * AW];
-#pragma unroll
-        for (int j = 0; j < NJ * AW; ++j) a_cur[j] = aq[j];
         store_panel(buf ^ 1, st_next);
         load_panel(k2, p2, st_free);
-        gather_a(k2, p2, aq);
+        const bool active = (wmask >> k_cur) & 1;
         float w4[4] = {0.f, 0.f, 0.f, 0.f};  // importance of this lane's four accumulator rows for slot k_cur
-        if (DUAL && has_b && p_cur == npanel - 1 && ((wmask >> k_cur) & 1)) {
+        if (DUAL && has_b && p_cur == npanel - 1 && active) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // issued here, consumed after the MFMAs of this step
                 const int idx = s_nbr[(wave * 16 + 4 * g + i) * NBR_LD + k_cur];
                 w4[i] = *(idx >= 0 ? a.inp_importance + idx : zeros);
             }
         }
-        if ((wmask >> k_cur) & 1) {
+        // The A fragments of this step are taken out of aq BEFORE the gather of step + 2 is issued into the
+        // same registers (no register rotation, the gather stays two steps ahead).
+        u32x4 fa[NJ][PLANES];
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (MODE == ASR_CONV16_F16) {
+                    fa[j][0] = aq[j];
+                } else {
+                    // exact split of the 8 gathered f32 into three bf16 fragments: a0 = rn(a), a1 = rn(a - a0),
+                    // a2 = a - a0 - a1 (exactly representable: 24 = 8 + 8 + 8 mantissa bits).  Round to nearest
+                    // (v_cvt_pk_bf16_f32, two values per instruction) keeps the residuals signed, so the dropped
+                    // product terms do not add up to a bias.
+                    unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 v = {__uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1)]),
+                                         __uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1) + 1])};
+                        p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                        const f32x2 r1 = {v.x - __uint_as_float(p0[i] << 16), v.y - __uint_as_float(p0[i] & 0xffff0000u)};
+                        p1[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+                        const f32x2 r2 = {r1.x - __uint_as_float(p1[i] << 16), r1.y - __uint_as_float(p1[i] & 0xffff0000u)};
+                        p2[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+                    }
+                    fa[j][0] = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+                    fa[j][PLANES > 1 ? 1 : 0] = (u32x4){p1[0], p1[1], p1[2], p1[3]};
+                    fa[j][PLANES > 2 ? 2 : 0] = (u32x4){p2[0], p2[1], p2[2], p2[3]};
+                }
+            }
+        }
+        gather_a(k2, p2, aq);
+        if (active) {
             const u32x4* sb = s_B[buf];
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if constexpr (MODE == ASR_CONV16_F16) {
-                    const f16x8 af = __builtin_bit_cast(f16x8, a_cur[j]);
+                    const f16x8 af = __builtin_bit_cast(f16x8, fa[j][0]);
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) {
                         const int col = nb * 16 + ncol;
@@ -316,24 +374,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
                         }
                     }
                 } else {
-                    // exact split of the 8 gathered f32 into three bf16 fragments: a0 = rn(a), a1 = rn(a - a0),
-                    // a2 = a - a0 - a1 (exactly representable: 24 = 8 + 8 + 8 mantissa bits).  Round to nearest
-                    // (v_cvt_pk_bf16_f32, two values per instruction) keeps the residuals signed, so the dropped
-                    // product terms do not add up to a bias.
-                    unsigned p0[4], p1[4], p2[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x2 v = {__uint_as_float(a_cur[j * 2 + (i >> 1)][2 * (i & 1)]),
-                                         __uint_as_float(a_cur[j * 2 + (i >> 1)][2 * (i & 1) + 1])};
-                        p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-                        const f32x2 r1 = {v.x - __uint_as_float(p0[i] << 16), v.y - __uint_as_float(p0[i] & 0xffff0000u)};
-                        p1[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-                        const f32x2 r2 = {r1.x - __uint_as_float(p1[i] << 16), r1.y - __uint_as_float(p1[i] & 0xffff0000u)};
-                        p2[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-                    }
-                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, (u32x4){p0[0], p0[1], p0[2], p0[3]});
-                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, (u32x4){p1[0], p1[1], p1[2], p1[3]});
-                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, (u32x4){p2[0], p2[1], p2[2], p2[3]});
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[j][0]);
+                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 1 ? 1 : 0]);
+                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 2 ? 2 : 0]);
 #pragma unroll
                     for (int nb = 0; nb < NT; ++nb) {
                         const int col = nb * 16 + ncol;

@@ -162,29 +162,42 @@ def mesh_stage(pipe, synth):
             "triangles": int(t.shape[0]), "field": "analytic scene sdf on grid 0"}
 
 
-def pipelined_rate(pipe, weights, dev, inputs, n, steps):
+def pipelined_rate(pipe, weights, dev, inputs, n, steps, depth=2):
     """Outside the timed region and not part of `value`: throughput when consecutive clouds are pipelined
-    over two contexts / streams, so that the geometry build of cloud i+1 (latency-bound small kernels)
-    overlaps the network of cloud i.  Same work per cloud as a serial step."""
+    over `depth` contexts, each with its own stream, arena and host thread, so that the geometry build of
+    one cloud (latency-bound small kernels, host read-backs of sizes) overlaps the network of another.
+    Same work per cloud as a serial step."""
+    import threading
     from asr_hip.pipeline import ImplicitPipeline
-    pipes = [pipe, ImplicitPipeline(weights, device=dev)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    pipes = [pipe] + [ImplicitPipeline(weights, device=dev) for _ in range(depth - 1)]
+    streams = [torch.cuda.Stream() for _ in range(depth)]
     for s_ in streams:
         s_.wait_stream(torch.cuda.current_stream())
+    out = [None] * depth
+
+    def worker(t, k):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[t]):
+            for _ in range(k):
+                out[t] = pipes[t].forward(*inputs)
+        streams[t].synchronize()
 
     def run(k):
-        for i in range(k):
-            with torch.cuda.stream(streams[i % 2]):
-                v = pipes[i % 2].forward(*inputs)
+        ths = [threading.Thread(target=worker, args=(t, k)) for t in range(depth)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
         torch.cuda.synchronize()
-        return v
 
-    run(2)
+    run(1)
+    per = max(1, steps // depth)
     t0 = time.perf_counter()
-    v = run(steps)
+    run(per)
     dt = time.perf_counter() - t0
-    assert bool(torch.isfinite(v).all())
-    return {"points_per_s": n * steps / dt, "ms_per_cloud": dt / steps * 1e3, "depth": 2, "clouds": steps}
+    assert all(bool(torch.isfinite(v).all()) for v in out)
+    clouds = per * depth
+    return {"points_per_s": n * clouds / dt, "ms_per_cloud": dt / clouds * 1e3, "depth": depth, "clouds": clouds}
 
 
 def one_scan_line(args, world, n, dt, sharded):
@@ -314,7 +327,8 @@ def main():
     mesh_info = mesh_stage(pipe, synth) if rank == 0 else None
     pipelined = None
     if world == 1 and not args.no_pipelined:
-        pipelined = pipelined_rate(pipe, weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(4, 2 * args.steps))
+        pipelined = [pipelined_rate(pipe, weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(6, 2 * args.steps), d)
+                     for d in (2, 3)]
 
     # raw-scan rate (outside `value`: the metric takes radii as inputs): the exact 24-NN radius
     # estimate of the pre-filter (cpp/lib/preprocess.cpp:25-39) on the GPU, steady state (second call), + one step

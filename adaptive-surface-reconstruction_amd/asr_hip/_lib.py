@@ -61,6 +61,7 @@ class SparseConvArgs(ctypes.Structure):
         ("cout_b", ctypes.c_int),
         ("force_nt", ctypes.c_int),
         ("force_waves", ctypes.c_int),
+        ("plan", ctypes.c_void_p),
     ]
 
 
@@ -101,6 +102,7 @@ EXPORTS = [
     "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_set_option", "asr_hip_context_get_option",
     "asr_hip_sparse_conv_variant_counts", "asr_hip_sparse_conv_packed_bytes", "asr_hip_sparse_conv_pack",
     "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_convert_f16",
+    "asr_hip_sparse_conv_plan_create", "asr_hip_sparse_conv_plan_destroy", "asr_hip_sparse_conv_plan_bytes",
     "asr_octree_frame_init", "asr_hip_point_keys", "asr_hip_octree_build", "asr_hip_octree_get", "asr_hip_dual_cells_count", "asr_hip_dual_cells_count_for", "asr_hip_dual_cells_fill",
     "asr_hip_contour_count", "asr_hip_contour_fill", "asr_hip_components_count", "asr_hip_components_fill",
     "asr_hip_unordered_set_order", "asr_density_inlier",
@@ -191,7 +193,8 @@ class Context:
 
     def sconv_variant_counts(self, reset=False):
         """{(NT, KC, IMP, WAVES, DUAL): launches} of k_sconv_mfma since the last reset; launches of the 16-bit
-        kernel k_sconv_mfma16 have a sixth field, the mode (1 = f16, 2 = bf16x3)"""
+        kernels have a sixth field, the mode (1 = f16, 2 = bf16x3), and a seventh: 1 = k_sconv_plan16 (plan-driven),
+        0 = k_sconv_mfma16 (neighbour table in LDS)"""
         buf = ctypes.create_string_buffer(4096)
         self.call("asr_hip_sparse_conv_variant_counts", buf, ctypes.c_size_t(4096), int(bool(reset)))
         out = {}

@@ -381,13 +381,47 @@ def pack_filters(filters, mode, filters_b=None):
     return out
 
 
+class ConvPlan:
+    """Row-group plan of one neighbour list (asr_hip_sparse_conv_plan_create): build once, pass as plan= to every
+    sparse_conv16 over the same (neighbour arrays, row_perm, num_rows).  Keeps the arrays it was built from alive."""
+
+    def __init__(self, kernel_size, neighbors_index, neighbors_kernel_index, neighbors_row_splits, row_perm=None,
+                 num_rows=None):
+        self.nidx = _dev(neighbors_index, torch.int32)
+        self.nk = _dev(neighbors_kernel_index, torch.uint8)
+        self.rs = _dev(neighbors_row_splits, torch.int64)
+        self.perm = _dev(row_perm, torch.int32) if row_perm is not None else None
+        self.num_rows = self.rs.shape[0] - 1 if num_rows is None else int(num_rows)
+        self.kernel_size = int(kernel_size)
+        self.ctx = context(_same_device(self.nidx, self.nk, self.rs, self.perm))
+        h = ctypes.c_void_p(0)
+        self.ctx.call("asr_hip_sparse_conv_plan_create", ptr(self.nidx), ptr(self.nk), ptr(self.rs),
+                      ptr(self.perm) if self.perm is not None else ctypes.c_void_p(0), i64(self.num_rows),
+                      ctypes.c_int(self.kernel_size), ctypes.byref(h))
+        self.handle = h
+
+    def nbytes(self):
+        f = self.ctx.lib.asr_hip_sparse_conv_plan_bytes
+        f.restype = ctypes.c_size_t
+        return int(f(self.handle))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                self.ctx.lib.asr_hip_sparse_conv_plan_destroy(h)
+            except Exception:
+                pass
+
+
 def sparse_conv16(mode, packed, kernel_size, cin, cout, inp_features, neighbors_index, neighbors_kernel_index,
                   neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False, residual=None,
                   out=None, out_dtype=None, return_importance=False, neighbors_importance=None, row_perm=None,
-                  num_rows=None, cout_b=0, bias_b=None, force_nt=0, force_waves=0):
+                  num_rows=None, cout_b=0, bias_b=None, force_nt=0, force_waves=0, plan=None):
     """SpecialSparseConv.forward on the 16-bit matrix cores (asr_hip_sparse_conv_f16 / _bf16x3).
     mode "f16": inp_features / residual are float16 tensors, out is float16 (default) or float32;
-    mode "bf16x3": float32 in and out, fp32-class result.  packed: pack_filters(filters, mode[, filters_b])."""
+    mode "bf16x3": float32 in and out, fp32-class result.  packed: pack_filters(filters, mode[, filters_b]).
+    plan: ConvPlan of this list (one is built for the call otherwise)."""
     m = _lib.PRECISIONS[mode]
     act = torch.float16 if mode == "f16" else torch.float32
     inp_features = _dev(inp_features, act)
@@ -432,6 +466,11 @@ def sparse_conv16(mode, packed, kernel_size, cin, cout, inp_features, neighbors_
     a.out_importance = oimp.data_ptr() if oimp is not None else None
     a.row_perm = perm.data_ptr() if perm is not None else None
     a.force_nt, a.force_waves = int(force_nt), int(force_waves)
+    if plan is not None:
+        if plan.rs.data_ptr() != rs.data_ptr() or plan.nidx.data_ptr() != nidx.data_ptr() or \
+                (plan.perm.data_ptr() if plan.perm is not None else None) != (perm.data_ptr() if perm is not None else None):
+            raise RuntimeError("sparse_conv16: the plan belongs to other neighbour arrays")
+        a.plan = plan.handle
     ctx = context(_same_device(packed, inp_features, nidx, nk, rs, imp, nimp, b, bb, res, out, perm))
     if mode == "f16":
         ctx.call("asr_hip_sparse_conv_f16", ctypes.byref(a), ptr(packed), int(out.dtype == torch.float16))

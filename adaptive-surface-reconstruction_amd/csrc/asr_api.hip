@@ -36,6 +36,7 @@ const OptEntry k_options[] = {
         {"sconv_dry", "ASR_SCONV_DRY", &AsrOptions::sconv_dry},
         {"row_segment", "ASR_ROW_SEGMENT", &AsrOptions::row_segment},
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
+        {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
         {"overlap", "ASR_OVERLAP", &AsrOptions::overlap},
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
@@ -396,15 +397,57 @@ static int check_conv16_args(asr_hip_context* ctx, const asr_sparse_conv_args* a
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: null argument");
     return ASR_HIP_OK;
 }
+struct asr_hip_conv_plan {
+    Arena mem;
+    asr_conv_plan p;
+};
+int asr_hip_sparse_conv_plan_create(asr_hip_context* ctx, const int32_t* nidx, const uint8_t* kidx, const int64_t* rs,
+                                    const int32_t* row_perm, int64_t num_out, int kernel_size,
+                                    asr_hip_conv_plan** plan_out) {
+    CTX_GUARD(ctx);
+    if (!plan_out) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv_plan_create: null plan_out");
+    *plan_out = nullptr;
+    if (num_out < 0 || kernel_size < 1 || kernel_size > 56 || (num_out > 0 && (!nidx || !kidx || !rs)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv_plan_create: bad argument");
+    asr_hip_conv_plan* pl = new asr_hip_conv_plan();
+    pl->mem.min_slab = size_t(1) << 20;
+    ctx->scratch.reset();
+    const int rc = asr_geom_conv_plan_build(ctx, pl->mem, nidx, kidx, rs, row_perm, num_out, kernel_size, &pl->p);
+    if (rc != ASR_HIP_OK) {
+        pl->mem.release();
+        delete pl;
+        return rc;
+    }
+    *plan_out = pl;
+    return ASR_HIP_OK;
+}
+void asr_hip_sparse_conv_plan_destroy(asr_hip_conv_plan* plan) {
+    if (!plan) return;
+    plan->mem.release();
+    delete plan;
+}
+size_t asr_hip_sparse_conv_plan_bytes(const asr_hip_conv_plan* plan) { return plan ? plan->mem.reserved() : 0; }
+
+// 16-bit entry points: the caller's plan, or a temporary one in the scratch arena
+static int conv16_entry(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed, int mode, int out_f16) {
+    ASR_TRY(check_conv16_args(ctx, a, packed));
+    if (a->plan) return asr_conv_sparse16(ctx, a, packed, mode, out_f16, &a->plan->p);
+    asr_conv_plan tmp;
+    const bool want = ctx->opt.sconv_plan && !a->neighbors_importance && a->num_out > 0 && a->algo != 1;
+    if (want) {
+        ctx->scratch.reset();
+        ASR_TRY(asr_geom_conv_plan_build(ctx, ctx->scratch, a->neighbors_index, a->neighbors_kernel_index,
+                                         a->neighbors_row_splits, a->row_perm, a->num_out, a->kernel_size, &tmp));
+    }
+    return asr_conv_sparse16(ctx, a, packed, mode, out_f16, want ? &tmp : nullptr);
+}
 int asr_hip_sparse_conv_f16(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed, int out_is_f16) {
     CTX_GUARD(ctx);
-    ASR_TRY(check_conv16_args(ctx, a, packed));
-    return asr_conv_sparse16(ctx, a, packed, ASR_CONV16_F16, out_is_f16 ? 1 : 0);
+    return conv16_entry(ctx, a, packed, ASR_CONV16_F16, out_is_f16 ? 1 : 0);
 }
 int asr_hip_sparse_conv_bf16x3(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed) {
     CTX_GUARD(ctx);
-    ASR_TRY(check_conv16_args(ctx, a, packed));
-    return asr_conv_sparse16(ctx, a, packed, ASR_CONV16_BF16X3, 0);
+    return conv16_entry(ctx, a, packed, ASR_CONV16_BF16X3, 0);
 }
 int asr_hip_convert_f16(asr_hip_context* ctx, const void* in, int64_t n, void* out, int to_f16) {
     CTX_GUARD(ctx);
@@ -525,7 +568,9 @@ struct Net {
         if (precision == 0) return asr_conv_sparse(ctx, &a);
         const void* pk = nullptr;
         ASR_TRY(packed(ka, kb, &pk));
-        return asr_conv_sparse16(ctx, &a, pk, precision, precision == ASR_CONV16_F16 && !out_f32);
+        auto pl = ctx->conv_plans.find(a.neighbors_row_splits);
+        return asr_conv_sparse16(ctx, &a, pk, precision, precision == ASR_CONV16_F16 && !out_f32,
+                                 pl == ctx->conv_plans.end() ? nullptr : &pl->second);
     }
 
     int get(const std::string& name, int ndim, const asr_weight** out) {
@@ -849,6 +894,41 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     }
     ctx->scratch.reset();
     ASR_TRY(asr_geom_row_groups_batch(ctx, rg_jobs.data(), (int)rg_jobs.size(), ASR_ROW_GROUP_SEGMENT));
+    // row-group plans of every list for the 16-bit kernels: all counting passes first, one read-back of the
+    // pool sizes, then the fills
+    ctx->conv_plans.clear();
+    if (prm->precision != 0 && ctx->opt.sconv_plan) {
+        struct Job {
+            const int32_t* idx;
+            const uint8_t* kidx;
+            const i64* rs;
+            const int32_t* perm;
+            i64 rows;
+            int K;
+        };
+        std::vector<Job> jobs;
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+            GridDev& g = ctx->grids[i];
+            jobs.push_back({g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, 55});
+            if (i + 1 < ASR_NUM_GRIDS) {
+                GridDev& c = ctx->grids[i + 1];
+                jobs.push_back({g.up_idx, g.up_kidx, g.up_rs, g.perm_up, g.v, 9});
+                jobs.push_back({g.down_idx, g.down_kidx, g.down_rs, g.perm_down, c.v, 9});
+            }
+        }
+        std::vector<i64> blocks(jobs.size(), 0);
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            asr_conv_plan& pl = ctx->conv_plans[jobs[j].rs];
+            ASR_TRY(asr_geom_conv_plan_count(ctx, ctx->persist, jobs[j].idx, jobs[j].kidx, jobs[j].rs, jobs[j].perm,
+                                             jobs[j].rows, jobs[j].K, &pl));
+            if (pl.offs)
+                ASR_HIP_CHECK(ctx, hipMemcpyAsync(&blocks[j], pl.offs + pl.groups_pad, sizeof(i64),
+                                                  hipMemcpyDeviceToHost, ctx->stream));
+        }
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t j = 0; j < jobs.size(); ++j)
+            ASR_TRY(asr_geom_conv_plan_fill(ctx, ctx->persist, &ctx->conv_plans[jobs[j].rs], blocks[j]));
+    }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     if (overlap)

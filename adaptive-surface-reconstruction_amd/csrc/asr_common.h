@@ -95,16 +95,42 @@ struct AsrOptions {
     i64 sconv_wide_min = 2048;    // 8-wave (128-row) blocks when they still give this many blocks
     i64 sconv_dry = 0;            // measurement aid: 1 = prologue + epilogue, 2 = no wave-level slot skip, 3 = prologue
     i64 row_segment = 524288;     // rows are regrouped inside segments of this many consecutive rows
+    i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
 };
 
+// Row-group plan of a neighbour list for the plan-driven 16-bit sparse conv (asr_conv16.hip): per 16
+// consecutive rows (row_perm order) the set of kernel slots in use and, slot by slot, the 16 neighbour indices.
+struct asr_conv_plan_view {
+    const uint4* hdr;      // [groups_pad] {slot mask lo, hi, first pool block, 0}
+    const int32_t* pool;   // [blocks][16], -1: no neighbour
+    i64 groups;            // ceil(num_out / 16)
+    unsigned pool_bytes;
+};
+struct asr_conv_plan {
+    uint4* hdr = nullptr;
+    int32_t* pool = nullptr;
+    i64 groups = 0, groups_pad = 0, blocks = 0;
+    i64* offs = nullptr;  // [groups_pad + 1] first pool block of every group; offs[groups_pad] = blocks (device)
+    // the list it was built from
+    const int32_t* nidx = nullptr;
+    const uint8_t* kidx = nullptr;
+    const i64* rs = nullptr;
+    const int32_t* perm = nullptr;
+    i64 num_out = 0;
+    int K = 0;
+    bool usable() const { return hdr && blocks * 64 < (i64(1) << 32) - 65536; }
+    asr_conv_plan_view view() const { return {hdr, pool, groups, (unsigned)(blocks * 64)}; }
+};
+
 struct asr_hip_context {
     hipStream_t stream = nullptr;
     std::string err;
     AsrOptions opt;
+    std::map<const void*, asr_conv_plan> conv_plans;  // row splits pointer -> plan of that list (implicit_build)
     std::map<std::string, i64> sconv_launches;  // "NT,KC,IMP,WAVES,DUAL" -> launches (asr_hip_sparse_conv_variant_counts)
     ArenaMark build_mark;                         // persist arena right after implicit_build
     bool build_mark_ok = false;
@@ -309,12 +335,20 @@ int asr_conv_cconv_basis(asr_hip_context* ctx, const float* out_pos, const float
                          float* basis_out, float* norm_out);
 int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* args);
 // asr_conv16.hip: 16-bit matrix-core variants (f16 activations / exact bf16x3 split)
+// two phases so that callers with several lists pay one host read-back: count enqueues the slot-set pass and
+// the scan (the block total lands in plan->offs[groups_pad]); fill allocates the pool and writes it
+int asr_geom_conv_plan_count(asr_hip_context* ctx, Arena& keep, const int32_t* nidx, const uint8_t* kidx, const i64* rs,
+                             const int32_t* perm, i64 num_out, int K, asr_conv_plan* plan);
+int asr_geom_conv_plan_fill(asr_hip_context* ctx, Arena& keep, asr_conv_plan* plan, i64 blocks);
+int asr_geom_conv_plan_build(asr_hip_context* ctx, Arena& keep, const int32_t* nidx, const uint8_t* kidx, const i64* rs,
+                             const int32_t* perm, i64 num_out, int K, asr_conv_plan* plan);  // count + read-back + fill
+
 size_t asr_conv16_packed_bytes(int mode, int K, int cin, int cout, int cout_b);
 int asr_conv16_pack(asr_hip_context* ctx, int mode, const float* wa, const float* wb, int K, int cin, int ca, int cb,
                     void* out);
 int asr_conv16_convert(asr_hip_context* ctx, const void* in, i64 n, void* out, int to_f16);
 int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed, int mode,
-                      int out_f16);
+                      int out_f16, const asr_conv_plan* plan);
 int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gidx, const i64* rs,
                     i64 rows, float* out);
 int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const float* w1,

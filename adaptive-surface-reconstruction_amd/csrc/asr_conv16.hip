@@ -14,6 +14,8 @@
 // contiguous and padded to 32, so that a B fragment (8 consecutive k of one column) is one 16-byte piece in
 // HBM, in the LDS panel and in the register.  Same tiling / slot-skipping / two-filter-bank scheme as
 // k_sconv_mfma (asr_conv.hip); reference semantics: models/common_torch.py:95-148.
+#include <type_traits>
+
 #include "asr_common.h"
 
 namespace {
@@ -42,9 +44,18 @@ __device__ inline u16 f32_to_f16_bits(float x) {
 // weight packing: filters [K, cin, cout] (+ bank b [K, cin, cout_b], appended as columns) ->
 // packed [planes][K][ctot_pad][cin_pad] 16-bit, zero padded
 // ------------------------------------------------------------------------------------------
+template <int KC>
+__device__ inline int swz(int col, int slot) {  // 16-byte piece index inside a panel row, swizzled
+    if (KC == 32) return slot ^ ((0x6C >> (2 * ((col >> 2) & 3))) & 3);
+    return slot ^ ((col >> 1) & 7);
+}
+
+// kc = panel depth the kernels will use for this tensor (asr_conv16_panel_depth); element (k, column, c) of
+// plane pl goes to  pl * plane + ((k * npanel + c / kc) * ctot_pad + column) * kc + swizzled(c % kc)
 __global__ void k_pack_filters(const float* __restrict__ wa, const float* __restrict__ wb, int K, int cin, int ca,
-                               int cb, int cin_pad, int ctot_pad, int mode, u16* __restrict__ out) {
+                               int cb, int cin_pad, int ctot_pad, int mode, int kc, u16* __restrict__ out) {
     const i64 total = (i64)K * ctot_pad * cin_pad;
+    const int npanel = cin_pad / kc;
     for (i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
         const int c = (int)(e % cin_pad);
         const int col = (int)((e / cin_pad) % ctot_pad);
@@ -56,16 +67,19 @@ __global__ void k_pack_filters(const float* __restrict__ wa, const float* __rest
             else if (col < ca + cb)
                 w = wb[((i64)k * cin + c) * cb + (col - ca)];
         }
+        const int pn = c / kc, cc = c % kc;
+        const int piece = kc == 32 ? swz<32>(col & 127, cc >> 3) : swz<64>(col & 127, cc >> 3);
+        const i64 o = (((i64)k * npanel + pn) * ctot_pad + col) * kc + piece * 8 + (cc & 7);
         if (mode == ASR_CONV16_F16) {
-            out[e] = f32_to_f16_bits(w);
+            out[o] = f32_to_f16_bits(w);
         } else {  // exact three-way bf16 split, round to nearest (w = b0 + b1 + b2)
             const u16 b0 = f32_to_bf16_bits(w);
             const float r1 = w - __uint_as_float((unsigned)b0 << 16);
             const u16 b1 = f32_to_bf16_bits(r1);
             const float r2 = r1 - __uint_as_float((unsigned)b1 << 16);
-            out[e] = b0;
-            out[total + e] = b1;
-            out[2 * total + e] = f32_to_bf16_bits(r2);
+            out[o] = b0;
+            out[total + o] = b1;
+            out[2 * total + o] = f32_to_bf16_bits(r2);
         }
     }
 }
@@ -89,12 +103,6 @@ __global__ void k_f16_to_f32(const u16* __restrict__ in, i64 n, float* __restric
 // temporary accumulator that is scaled and added when the slot is finished -- exact f32 scaling in both
 // modes, no second A operand.
 // ------------------------------------------------------------------------------------------
-template <int KC>
-__device__ inline int swz(int col, int slot) {  // 16-byte piece index inside a panel row, swizzled
-    if (KC == 32) return slot ^ ((0x6C >> (2 * ((col >> 2) & 3))) & 3);
-    return slot ^ ((col >> 1) & 7);
-}
-
 template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16(
         asr_sparse_conv_args a, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
@@ -235,11 +243,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
         const int rem = e % PLANE_PIECES;
         const int col = rem / SLOTS, slot = rem % SLOTS;
         const bool ok = SV_EXACT || e < PV;
-        w_off[s] = ok ? (unsigned)((pl * plane_stride + (i64)(n0 + col) * cin_pad + 8 * slot) * 2) : OOB_OFF;
-        w_lds[s] = ok ? pl * PLANE_PIECES + col * SLOTS + swz<KC>(col, slot) : -1;
+        // packed panels are stored in LDS order (swizzle included): memory piece = LDS piece
+        w_off[s] = ok ? (unsigned)((pl * plane_stride + (i64)(n0 + col) * KC + 8 * slot) * 2) : OOB_OFF;
+        w_lds[s] = ok ? e : -1;
     }
     auto load_panel = [&](const int qk, const int qp, u32x4 (&st)[SV]) __attribute__((always_inline)) {
-        const int soff = ((qk < 0 ? 0 : qk) * ctot_pad * cin_pad + qp * KC) * 2;
+        const int soff = (((qk < 0 ? 0 : qk) * npanel + qp) * ctot_pad * KC) * 2;
 #pragma unroll
         for (int s = 0; s < SV; ++s) st[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)w_off[s], soff, 0);
     };
@@ -491,10 +500,382 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
         a.out_importance[s_row[tid]] = s_norm[tid];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Row-group plan of a neighbour list (asr_conv16_plan_*): the CSR is re-laid once per list into the order the
+// kernel below streams it.  16 consecutive rows (in row_perm order) form a group; its header holds the set of
+// kernel slots any of its rows uses and the position of its first block in the pool; the pool holds, for every
+// slot of the set in ascending order, the 16 neighbour indices (-1: this row has no neighbour in the slot).
+// Row regrouping makes the groups nearly homogeneous, so the pool is about as large as the CSR itself.
+// ------------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------------
+// The plan-driven kernel: same tiles, panels, arithmetic and epilogue as k_sconv_mfma16, but
+//   * no neighbour table in LDS and no CSR parsing per block: a wave reads its group header with scalar loads
+//     and the 16 indices of a slot with one 64-byte load, prefetched one slot ahead;
+//   * weight panels go global -> LDS directly (buffer_load ... lds, 1 KB per wave instruction; the packed
+//     tensor is stored in LDS order), no staging registers;
+//   * LDS holds only the two panel buffers, so three 8-wave blocks fit a CU.
+// Row weights (conv1b: importance of the neighbour) are read per (row, slot) through the plan as well.
+// ------------------------------------------------------------------------------------------
+template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) void k_sconv_plan16(
+        asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
+        const float* __restrict__ zeros) {
+    constexpr int TM = WAVES * 16;
+    constexpr int NCOL = NT * 16;
+    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : 1;
+    constexpr int SLOTS = KC / 8;
+    constexpr int NJ = KC / 32;
+    constexpr int PV = PLANES * NCOL * SLOTS;  // 16-byte pieces per panel
+    constexpr int PLANE_PIECES = NCOL * SLOTS;
+    constexpr int NCHUNK = PV / 64;            // 1 KB pieces of a panel, one per wave instruction
+    constexpr int CHUNKS_PER_PLANE = PLANE_PIECES / 64;
+    constexpr int SV = (NCHUNK + WAVES - 1) / WAVES;
+    constexpr int AW = MODE == ASR_CONV16_F16 ? 1 : 2;
+    constexpr int ESZ = MODE == ASR_CONV16_F16 ? 2 : 4;
+    constexpr bool ROWW = IMP || DUAL;  // per (row, slot) weights
+    // two separate arrays: the compiler then knows that a panel DMA into one does not feed reads of the other
+    __shared__ __attribute__((aligned(16))) u32x4 s_B0[PV];
+    __shared__ __attribute__((aligned(16))) u32x4 s_B1[PV];
+    __shared__ unsigned long long s_wm[WAVES];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nY = ctot_pad / NCOL;
+    i64 tile = blockIdx.x;
+    int ychunk = 0;
+    if (nY > 1) {  // column chunks of one row tile on one XCD, consecutive dispatch slots (see k_sconv_mfma)
+        const i64 r8 = blockIdx.x >> 3;
+        ychunk = (int)(r8 % nY);
+        tile = (r8 / nY) * 8 + (blockIdx.x & 7);
+    }
+    const i64 row0 = tile * TM;
+    if (row0 >= a.num_out) return;
+    const int n0 = ychunk * NCOL;
+    const int K = a.kernel_size;
+    const int cin = a.cin;
+    const int ca = a.cout;
+    const int cout = a.cout + (DUAL ? a.cout_b : 0);
+    const bool has_b = DUAL && ychunk == nY - 1;
+    const bool roww = IMP || has_b;
+    const int r = lane & 15, g = lane >> 4;
+    const int ncol = r;
+
+    // group header: wave-uniform
+    const i64 grp = tile * WAVES + wave;
+    uint4 h = make_uint4(0, 0, 0, 0);
+    if (grp < plan.groups) h = plan.hdr[grp];
+    const unsigned long long wmask =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.x) |
+             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.y) << 32)) & ((1ull << K) - 1);
+    const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane((int)h.z);
+    if (lane == 0) s_wm[wave] = wmask;
+    // output rows of this lane's four accumulator rows (-1: beyond the list)
+    int q4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 lr = row0 + wave * 16 + 4 * g + i;
+        q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
+    }
+    __syncthreads();
+    unsigned long long bmask = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) bmask |= s_wm[w];
+    bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
+
+    f32x4 acc[NT];
+    f32x4 tacc[IMP ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (IMP ? NT : 1); ++t) tacc[t] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_b = {0.f, 0.f, 0.f, 0.f};
+    float norm4[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int npanel = (cin + KC - 1) / KC;
+    const i64 plane_stride = (i64)K * ctot_pad * cin_pad;
+
+#define ASR_SEQ_ADVANCE(todo, k, p)                          \
+    if ((k) >= 0 && ++(p) == npanel) {                       \
+        (p) = 0;                                             \
+        (todo) &= (todo)-1;                                  \
+        (k) = (todo) ? __builtin_ctzll(todo) : -1;           \
+    }
+    constexpr unsigned OOB_OFF = 0xFFFFE000u;
+    constexpr int RSRC_FLAGS = 0x00020000;
+    const __amdgpu_buffer_rsrc_t rs_w =
+            __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, (int)(PLANES * plane_stride * 2), RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_p =
+            __builtin_amdgcn_make_buffer_rsrc((void*)plan.pool, 0, (int)plan.pool_bytes, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(ROWW ? a.inp_importance : zeros), 0, ROWW ? (int)(unsigned)(a.num_inp * 4) : 4, RSRC_FLAGS);
+    // weight panel -> LDS: chunk c = s * WAVES + wave (1 KB) of the panel, lane l moves its 16-byte piece
+    unsigned w_off[SV];
+#pragma unroll
+    for (int s = 0; s < SV; ++s) {
+        const int c = s * WAVES + wave;
+        const int pl = c / CHUNKS_PER_PLANE, ci = c % CHUNKS_PER_PLANE;
+        w_off[s] = c < NCHUNK ? (unsigned)((pl * plane_stride + (i64)n0 * KC) * 2 + ci * 1024 + lane * 16) : OOB_OFF;
+    }
+    auto dma_panel = [&](const int qk, const int qp, auto bufc) __attribute__((always_inline)) {
+        const int soff = (((qk < 0 ? 0 : qk) * npanel + qp) * ctot_pad * KC) * 2;
+        u32x4* dst = decltype(bufc)::value ? s_B1 : s_B0;
+#pragma unroll
+        for (int s = 0; s < SV; ++s) {
+            const int c = s * WAVES + wave;
+            if (NCHUNK % WAVES == 0 || c < NCHUNK)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)&dst[c * 64], 16,
+                                                         (int)w_off[s], soff, 0, 0);
+        }
+    };
+    // neighbour index of this lane's row for slot k (wave-uniform k): one 64-byte block of the pool.  The load
+    // is issued whether or not the wave has the slot (offset beyond the pool -> 0), so that every step has the
+    // same sequence of memory instructions; has_slot() tells the two apart.
+    auto has_slot = [&](const int k) __attribute__((always_inline)) -> bool { return k >= 0 && ((wmask >> k) & 1); };
+    auto pool_off = [&](const int k) __attribute__((always_inline)) -> unsigned {
+        const int kk = k < 0 ? 0 : k;
+        return (woff + (unsigned)__popcll(wmask & ((1ull << kk) - 1))) * 64u;
+    };
+    auto load_idx = [&](const int k) __attribute__((always_inline)) -> int {
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, has_slot(k) ? r * 4 : (int)OOB_OFF, (int)pool_off(k), 0);
+    };
+    auto load_idx4 = [&](const int k) __attribute__((always_inline)) -> u32x4 {  // rows 4 g .. 4 g + 3
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_p, has_slot(k) ? g * 16 : (int)OOB_OFF, (int)pool_off(k), 0);
+    };
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.inp_features, 0, (int)(unsigned)(a.num_inp > 0 ? ((a.num_inp - 1) * a.inp_ld + cin) * ESZ : 0),
+            RSRC_FLAGS);
+    int cache_k = -2;
+    unsigned cache_off = OOB_OFF;
+    int pref_idx = -1;  // index for the slot after the one being gathered, in flight
+    // (the launcher sends matrices of 4 GB and more and cin that is not a multiple of KC to k_sconv_mfma16)
+    auto gather_a = [&](const int qk, const int qp, u32x4 (&aq)[NJ * AW], const bool first) __attribute__((always_inline)) {
+        const bool sw = qk != cache_k;
+        int idx = pref_idx;
+        if (first) idx = load_idx(qk);
+        const unsigned long long rest = qk < 0 ? 0ull : (bmask >> qk) >> 1;
+        const int kn = rest ? qk + 1 + __builtin_ctzll(rest) : -1;
+        const int nxt = load_idx(kn);  // every step; consumed when the gather moves on to slot kn
+        if (sw) {
+            cache_k = qk;
+            const bool valid = has_slot(qk) && idx >= 0;
+            cache_off = valid ? (unsigned)idx * (unsigned)(a.inp_ld * ESZ) + (unsigned)(8 * g * ESZ) : OOB_OFF;
+        }
+        pref_idx = nxt;
+        const int soff = qp * KC * ESZ;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int hh = 0; hh < AW; ++hh)
+                aq[j * AW + hh] =
+                        __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off + (32 * j + 4 * hh) * ESZ, soff, 0);
+    };
+
+    u32x4 a_q0[NJ * AW], a_q1[NJ * AW];
+    unsigned long long todo1 = bmask;
+    int k_cur = bmask ? __builtin_ctzll(bmask) : -1, p_cur = 0;
+    int k1 = k_cur, p1 = 0;
+    ASR_SEQ_ADVANCE(todo1, k1, p1)
+    u32x4 idx4_cur = {~0u, ~0u, ~0u, ~0u}, idx4_next = {~0u, ~0u, ~0u, ~0u};
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    if (k_cur >= 0) {
+        dma_panel(k_cur, p_cur, B0());
+        if (ROWW && roww) idx4_next = load_idx4(k_cur);
+        gather_a(k_cur, p_cur, a_q0, true);
+        gather_a(k1, p1, a_q1, false);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    auto step = [&](u32x4 (&aq)[NJ * AW], auto bufc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        int k2 = k1, p2 = p1;
+        ASR_SEQ_ADVANCE(todo1, k2, p2)
+        // panel of the next step straight into the other LDS buffer (every wave is past the barrier that ended
+        // its reads).  Issued before every other load of this step: the wait at the end of the step counts on it.
+        dma_panel(k1, p1, std::integral_constant<int, BUF ^ 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        const bool active = (wmask >> k_cur) & 1;
+        float w4[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool slot_end = p_cur == npanel - 1;
+        if (ROWW && roww) {  // the same loads in every step (see load_idx)
+            if (p_cur == 0) idx4_cur = idx4_next;
+            const u32x4 nx = load_idx4(k1);
+            if (p1 == 0) idx4_next = nx;  // first step of the next slot is the next step
+#pragma unroll
+            for (int i = 0; i < 4; ++i)  // idx -1 (or a wave without the slot) -> beyond the buffer -> 0
+                w4[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_i, (int)(idx4_cur[i] * 4u), 0, 0));
+        }
+        u32x4 fa[NJ][PLANES];
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (MODE == ASR_CONV16_F16) {
+                    fa[j][0] = aq[j];
+                } else {
+                    unsigned p0[4], p1v[4], p2v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 v = {__uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1)]),
+                                         __uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1) + 1])};
+                        p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+                        const f32x2 r1 = {v.x - __uint_as_float(p0[i] << 16), v.y - __uint_as_float(p0[i] & 0xffff0000u)};
+                        p1v[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+                        const f32x2 r2 = {r1.x - __uint_as_float(p1v[i] << 16), r1.y - __uint_as_float(p1v[i] & 0xffff0000u)};
+                        p2v[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+                    }
+                    fa[j][0] = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+                    fa[j][PLANES > 1 ? 1 : 0] = (u32x4){p1v[0], p1v[1], p1v[2], p1v[3]};
+                    fa[j][PLANES > 2 ? 2 : 0] = (u32x4){p2v[0], p2v[1], p2v[2], p2v[3]};
+                }
+            }
+        }
+        gather_a(k2, p2, aq, false);
+        if (active) {
+            const u32x4* sb = BUF ? s_B1 : s_B0;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (MODE == ASR_CONV16_F16) {
+                    const f16x8 af = __builtin_bit_cast(f16x8, fa[j][0]);
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        const int col = nb * 16 + ncol;
+                        const f16x8 bf = __builtin_bit_cast(f16x8, sb[col * SLOTS + swz<KC>(col, 4 * j + g)]);
+                        if (IMP) {
+                            tacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[nb], 0, 0, 0);
+                        } else {
+                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nb], 0, 0, 0);
+                            if (DUAL && has_b && nb == NT - 1)
+                                tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);
+                        }
+                    }
+                } else {
+                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[j][0]);
+                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 1 ? 1 : 0]);
+                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 2 ? 2 : 0]);
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+                        const int col = nb * 16 + ncol;
+                        const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
+                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);
+                        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);
+                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);
+#define ASR_SIX(ACC_)                                                         \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ACC_, 0, 0, 0);    \
+    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ACC_, 0, 0, 0);
+                        if (IMP) {
+                            ASR_SIX(tacc[nb])
+                        } else {
+                            ASR_SIX(acc[nb])
+                            if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
+                        }
+#undef ASR_SIX
+                    }
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (ROWW && roww && slot_end) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) norm4[i] += w4[i];
+                if (IMP) {
+#pragma unroll
+                    for (int nb = 0; nb < NT; ++nb) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[nb][i] += w4[i] * tacc[nb][i];
+                        tacc[nb] = {0.f, 0.f, 0.f, 0.f};
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc_b[i] += w4[i] * tacc[0][i];
+                    tacc[0] = {0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        // the panel DMA of this step has landed once at most the NJ*AW gather loads issued after it are in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ * AW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        k_cur = k1;
+        p_cur = p1;
+        k1 = k2;
+        p1 = p2;
+    };
+    while (k_cur >= 0) {
+        step(a_q0, B0());
+        if (k_cur < 0) break;
+        step(a_q1, B1());
+    }
+#undef ASR_SEQ_ADVANCE
+
+    // epilogue: acc[nb][i] is C[row = 4 g + i][col = ncol] of the wave's 16 x 16 block
+    float bv[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        const int col = n0 + nb * 16 + ncol;
+        const float* bp = (a.bias && col < ca) ? a.bias + col : zeros;
+        if (DUAL && a.bias_b && col >= ca && col < cout) bp = a.bias_b + (col - ca);
+        bv[nb] = *bp;
+    }
+    const bool res16 = MODE == ASR_CONV16_F16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 q = q4[i];
+        const bool rowok = q >= 0;
+        const float norm = norm4[i];
+        const bool do_norm = a.normalize && norm != 0.f;
+        float res[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
+            const bool ok = a.residual && rowok && col < cout;
+            if (res16) {
+                const u16* rp = ok ? (const u16*)a.residual + q * a.residual_ld + col : (const u16*)zeros;
+                res[nb] = (float)__builtin_bit_cast(_Float16, *rp);
+            } else {
+                const float* rp = ok ? a.residual + q * a.residual_ld + col : zeros;
+                res[nb] = *rp;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
+            float v = acc[nb][i];
+            if (DUAL) {
+                const bool colb = col >= ca;
+                if (nb == NT - 1 && has_b && colb) v = acc_b[i];
+                v = (colb && do_norm) ? v / norm : v;
+            } else {
+                v = do_norm ? v / norm : v;
+            }
+            v += bv[nb];
+            if (a.relu) v = fmaxf(v, 0.f);
+            v += res[nb];
+            if (rowok && col < cout) {
+                if (out_f16)
+                    ((u16*)a.out)[q * a.out_ld + col] = f32_to_f16_bits(v);
+                else
+                    a.out[q * a.out_ld + col] = v;
+            }
+        }
+        if (ROWW && a.out_importance && ncol == 0 && rowok && (DUAL ? has_b : ychunk == 0)) a.out_importance[q] = norm;
+    }
+}
+
 }  // namespace
 
 // ==========================================================================================
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// f16 tensors whose padded cin is a multiple of 64 use 64-deep panels (bf16x3 panels carry three planes)
+static inline int panel_depth(int mode, int cin) { return mode == ASR_CONV16_F16 && round_up(cin, 32) % 64 == 0 ? 64 : 32; }
 
 size_t asr_conv16_packed_bytes(int mode, int K, int cin, int cout, int cout_b) {
     const size_t planes = mode == ASR_CONV16_BF16X3 ? 3 : 1;
@@ -510,7 +891,7 @@ int asr_conv16_pack(asr_hip_context* ctx, int mode, const float* wa, const float
     const int cin_pad = round_up(cin, 32), ctot_pad = round_up(ca + cb, 16);
     const i64 total = (i64)K * ctot_pad * cin_pad;
     k_pack_filters<<<(unsigned)std::min<i64>((total + 255) / 256, 65535), 256, 0, ctx->stream>>>(
-            wa, wb, K, cin, ca, cb, cin_pad, ctot_pad, mode, (u16*)out);
+            wa, wb, K, cin, ca, cb, cin_pad, ctot_pad, mode, panel_depth(mode, cin), (u16*)out);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }
@@ -528,7 +909,7 @@ int asr_conv16_convert(asr_hip_context* ctx, const void* in, i64 n, void* out, i
 // a: shapes, CSR, bias, flags as for asr_conv_sparse; in ASR_CONV16_F16 mode inp_features / residual (and out
 // when out_f16) point to f16 data, leading dimensions count elements.
 int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, const void* packed, int mode,
-                      int out_f16) {
+                      int out_f16, const asr_conv_plan* plan) {
     asr_sparse_conv_args a = *pa;
     if (a.num_out <= 0) return ASR_HIP_OK;
     if (mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3)
@@ -567,14 +948,28 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
         if (a.force_waves != 4 && a.force_waves != 8) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: force_waves must be 4 or 8");
         wide = a.force_waves == 8;
     }
-    const bool kc64 = mode == ASR_CONV16_F16 && cin_pad % 64 == 0;  // f16: 64-deep panels (bf16x3 panels carry 3 planes)
+    const bool kc64 = panel_depth(mode, a.cin) == 64;
+    // the plan-driven kernel covers everything but per-entry importance and neighbour-count normalisation
+    const bool use_plan = plan && plan->usable() && ctx->opt.sconv_plan && !a.neighbors_importance &&
+                          !(a.normalize && !imp) && !(a.out_importance && !imp) &&
+                          a.num_inp * a.inp_ld * esz < (i64(1) << 32) - 65536 && a.cin % (kc64 ? 64 : 32) == 0;
+    asr_conv_plan_view pv = {nullptr, nullptr, 0, 0};
+    if (use_plan) {
+        if (plan->num_out != a.num_out || plan->K < a.kernel_size || plan->perm != a.row_perm)
+            ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: the plan was built for another list");
+        pv = plan->view();
+    }
 #define ASR_L16(NT_, KC_, W_, M_, I_, D_)                                                                        \
     {                                                                                                            \
         const i64 tiles_ = (a.num_out + W_ * 16 - 1) / (W_ * 16);                                                \
         const i64 ny_ = ctot_pad / (NT_ * 16);                                                                   \
         dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));                                  \
-        k_sconv_mfma16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                       \
-                a, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                                       \
+        if (use_plan)                                                                                            \
+            k_sconv_plan16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                   \
+                    a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                               \
+        else                                                                                                     \
+            k_sconv_mfma16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                   \
+                    a, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                                   \
     }
 #define ASR_L16_ID(NT_, KC_, W_, M_) \
     if (dual)                        \
@@ -609,9 +1004,9 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
 #undef ASR_L16
     ASR_CHECK_LAUNCH(ctx);
     {
-        char key[64];  // NT,KC,IMP,WAVES,DUAL,MODE (k_sconv_mfma16 instance)
-        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
-                 dual ? 1 : 0, mode);
+        char key[64];  // NT,KC,IMP,WAVES,DUAL,MODE,PLAN (k_sconv_mfma16 / k_sconv_plan16 instance)
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
+                 dual ? 1 : 0, mode, use_plan ? 1 : 0);
         ++ctx->sconv_launches[key];
     }
     return ASR_HIP_OK;

@@ -1901,3 +1901,96 @@ int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, co
     }
     return ASR_HIP_OK;
 }
+
+// ==========================================================================================
+// row-group plans for the plan-driven sparse conv (layout: asr_common.h, consumer: asr_conv16.hip)
+// ==========================================================================================
+namespace {
+__global__ void k_plan_masks(const uint8_t* __restrict__ kidx, const i64* __restrict__ rs,
+                             const int32_t* __restrict__ perm, i64 num_out, int K, i64 groups_pad,
+                             uint4* __restrict__ hdr, i64* __restrict__ counts) {
+    const i64 row = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    unsigned long long m = 0;
+    if (row < num_out) {
+        const i64 q = perm ? perm[row] : row;
+        for (i64 p = rs[q], pe = rs[q + 1]; p < pe; ++p) {
+            const int k = kidx[p];
+            if (k < K) m |= 1ull << k;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m |= __shfl_xor(m, o, 64);
+    const i64 grp = row >> 4;
+    if ((threadIdx.x & 15) == 0 && grp < groups_pad) {
+        hdr[grp] = make_uint4((unsigned)m, (unsigned)(m >> 32), 0u, 0u);
+        counts[grp] = (i64)__popcll(m);
+    }
+}
+
+__global__ void k_plan_fill(const int32_t* __restrict__ nidx, const uint8_t* __restrict__ kidx,
+                            const i64* __restrict__ rs, const int32_t* __restrict__ perm, i64 num_out, int K,
+                            i64 groups_pad, const i64* __restrict__ offs, uint4* __restrict__ hdr, int32_t* __restrict__ pool) {
+    const i64 row = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    const i64 grp = row >> 4;
+    if (grp >= groups_pad) return;
+    const unsigned off = (unsigned)offs[grp];
+    if ((row & 15) == 0) hdr[grp].z = off;
+    if (row >= num_out) return;
+    const uint2 h = *reinterpret_cast<const uint2*>(&hdr[grp]);
+    const unsigned long long m = (unsigned long long)h.x | ((unsigned long long)h.y << 32);
+    const i64 q = perm ? perm[row] : row;
+    for (i64 p = rs[q], pe = rs[q + 1]; p < pe; ++p) {
+        const int k = kidx[p];
+        if (k >= K) continue;
+        const int j = __popcll(m & ((1ull << k) - 1));
+        pool[((i64)off + j) * 16 + (row & 15)] = nidx[p];
+    }
+}
+
+
+}  // namespace
+
+int asr_geom_conv_plan_count(asr_hip_context* ctx, Arena& keep, const int32_t* nidx, const uint8_t* kidx, const i64* rs,
+                             const int32_t* perm, i64 num_out, int K, asr_conv_plan* plan) {
+    *plan = asr_conv_plan();
+    plan->nidx = nidx;
+    plan->kidx = kidx;
+    plan->rs = rs;
+    plan->perm = perm;
+    plan->num_out = num_out;
+    plan->K = K;
+    if (num_out <= 0) return ASR_HIP_OK;
+    plan->groups = (num_out + 15) / 16;
+    plan->groups_pad = (plan->groups + 15) / 16 * 16;  // whole 256-row tiles
+    plan->hdr = (uint4*)keep.alloc(plan->groups_pad * sizeof(uint4));
+    plan->offs = (i64*)keep.alloc((plan->groups_pad + 1) * sizeof(i64));
+    i64* counts = (i64*)ctx->scratch.alloc((plan->groups_pad + 1) * sizeof(i64));
+    if (!plan->hdr || !plan->offs || !counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(counts + plan->groups_pad, 0, sizeof(i64), ctx->stream));
+    k_plan_masks<<<grid_for(plan->groups_pad * 16, BLK), BLK, 0, ctx->stream>>>(kidx, rs, perm, num_out, K,
+                                                                              plan->groups_pad, plan->hdr, counts);
+    ASR_CHECK_LAUNCH(ctx);
+    return asr_prim::scan_counts(ctx, ctx->scratch, counts, plan->offs, plan->groups_pad + 1);
+}
+
+int asr_geom_conv_plan_fill(asr_hip_context* ctx, Arena& keep, asr_conv_plan* plan, i64 blocks) {
+    if (plan->num_out <= 0) return ASR_HIP_OK;
+    plan->blocks = blocks;
+    plan->pool = (int32_t*)keep.alloc((size_t)(blocks > 0 ? blocks : 1) * 64);
+    if (!plan->pool) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(plan->pool, 0xFF, (size_t)(blocks > 0 ? blocks : 1) * 64, ctx->stream));
+    k_plan_fill<<<grid_for(plan->groups_pad * 16, BLK), BLK, 0, ctx->stream>>>(
+            plan->nidx, plan->kidx, plan->rs, plan->perm, plan->num_out, plan->K, plan->groups_pad, plan->offs,
+            plan->hdr, plan->pool);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
+int asr_geom_conv_plan_build(asr_hip_context* ctx, Arena& keep, const int32_t* nidx, const uint8_t* kidx, const i64* rs,
+                             const int32_t* perm, i64 num_out, int K, asr_conv_plan* plan) {
+    ASR_TRY(asr_geom_conv_plan_count(ctx, keep, nidx, kidx, rs, perm, num_out, K, plan));
+    if (num_out <= 0) return ASR_HIP_OK;
+    i64 blocks = 0;
+    ASR_TRY(asr_prim::read_i64(ctx, plan->offs + plan->groups_pad, &blocks));
+    return asr_geom_conv_plan_fill(ctx, keep, plan, blocks);
+}

@@ -256,10 +256,14 @@ typedef struct asr_sparse_conv_args {
      * small input run the instances that large inputs select (parity tests). */
     int force_nt;
     int force_waves;
+    /* 16-bit entry points only: row-group plan of this neighbour list (asr_hip_sparse_conv_plan_create), or NULL
+     * to have a temporary one built for the call.  A plan is tied to (neighbour arrays, row_perm, num_out). */
+    const struct asr_hip_conv_plan* plan;
 } asr_sparse_conv_args;
 int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* args);
 /* Launch statistics of the MFMA sparse conv since the last reset: text "NT,KC,IMP,WAVES,DUAL:count;..."
- * (template instance k_sconv_mfma<NT,KC,IMP,WAVES,DUAL> -> number of launches), NUL terminated. */
+ * (template instance k_sconv_mfma<NT,KC,IMP,WAVES,DUAL> -> number of launches), NUL terminated.  The 16-bit
+ * kernels count as "NT,KC,IMP,WAVES,DUAL,MODE,PLAN" (PLAN 1: k_sconv_plan16, 0: k_sconv_mfma16). */
 int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t cap, int reset);
 
 /* ---- a12 on the 16-bit matrix cores (v_mfma_f32_16x16x32_{f16,bf16}) --------------------------------
@@ -269,9 +273,9 @@ int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t c
  * ASR_CONV16_BF16X3: f32 activations and weights; every operand is split exactly into three bf16 terms and
  *   the product is evaluated with six bf16 MFMAs, f32 accumulate -- fp32-class results (error of the dropped
  *   terms < 2^-23 per product) at 2.7x the f32 matrix peak.  args as for asr_hip_sparse_conv_f32.
- * Both take the filters re-packed by asr_hip_sparse_conv_pack ([plane][K][cout padded to 16][cin padded to
- * 32], 16-bit; bank b appended as columns); args->filters / filters_b are ignored, cout_b > 0 selects the
- * two-bank form.  cin and the row strides must be multiples of 8 (f16) / 4 (f32) elements. */
+ * Both take the filters re-packed by asr_hip_sparse_conv_pack (16-bit, [plane][K][cin panel][cout padded to
+ * 16][panel depth] in the kernels' LDS order; bank b appended as columns); args->filters / filters_b are
+ * ignored, cout_b > 0 selects the two-bank form.  cin and the row strides must be multiples of 8 (f16) / 4 (f32) elements. */
 #define ASR_CONV16_F16 1
 #define ASR_CONV16_BF16X3 2
 size_t asr_hip_sparse_conv_packed_bytes(int mode, int kernel_size, int cin, int cout, int cout_b);
@@ -280,6 +284,20 @@ int asr_hip_sparse_conv_pack(asr_hip_context* ctx, int mode, const float* filter
 int asr_hip_sparse_conv_f16(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed_dev,
                             int out_is_f16);
 int asr_hip_sparse_conv_bf16x3(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed_dev);
+/* Row-group plan: the neighbour list re-laid in the order the 16-bit kernels stream it -- per 16 consecutive
+ * rows (row_perm order) the set of kernel slots in use and, slot by slot, the 16 neighbour indices.  Built once
+ * per list and reused by every convolution over it (the U-Net runs ~10 per grid level); the kernels then need no
+ * neighbour table in LDS and do no CSR parsing.  The plan owns its device memory; the arrays it was built from
+ * must keep their contents while it is in use.  Per-pair importance (neighbors_importance) and neighbour-count
+ * normalisation are served by the table-driven kernel, which ignores the plan. */
+typedef struct asr_hip_conv_plan asr_hip_conv_plan;
+int asr_hip_sparse_conv_plan_create(asr_hip_context* ctx, const int32_t* neighbors_index_dev,
+                                    const uint8_t* neighbors_kernel_index_dev, const int64_t* neighbors_row_splits_dev,
+                                    const int32_t* row_perm_dev, int64_t num_out, int kernel_size,
+                                    asr_hip_conv_plan** plan_out);
+void asr_hip_sparse_conv_plan_destroy(asr_hip_conv_plan* plan);
+/* bytes of device memory a plan holds */
+size_t asr_hip_sparse_conv_plan_bytes(const asr_hip_conv_plan* plan);
 /* f32 <-> f16 conversion of an activation buffer (n elements) */
 int asr_hip_convert_f16(asr_hip_context* ctx, const void* in_dev, int64_t n, void* out_dev, int to_f16);
 

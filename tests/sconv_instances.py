@@ -15,11 +15,13 @@ BENCH_INSTANCES = {
 }
 
 
-# k_sconv_mfma16 instances of the default bench (bf16x3 arithmetic): (NT, KC, IMP, WAVES, DUAL, MODE) as the
-# library's launch counters report them (template order is <NT, KC, WAVES, MODE, IMP, DUAL>)
+# 16-bit kernel instances of the default bench (bf16x3 arithmetic): (NT, KC, IMP, WAVES, DUAL, MODE, PLAN) as the
+# library's launch counters report them (template order is <NT, KC, WAVES, MODE, IMP, DUAL>; PLAN 1 =
+# k_sconv_plan16, 0 = k_sconv_mfma16)
 BENCH_INSTANCES16 = {
-    (4, 32, 0, 8, 1, 2), (4, 32, 0, 8, 0, 2), (8, 32, 0, 8, 1, 2), (8, 32, 0, 8, 0, 2), (4, 32, 0, 4, 1, 2),
-    (4, 32, 0, 4, 0, 2), (2, 32, 0, 4, 1, 2), (2, 32, 0, 4, 0, 2), (2, 32, 0, 8, 0, 2),
+    (4, 32, 0, 8, 1, 2, 1), (4, 32, 0, 8, 0, 2, 1), (8, 32, 0, 8, 1, 2, 1), (8, 32, 0, 8, 0, 2, 1),
+    (4, 32, 0, 4, 1, 2, 1), (4, 32, 0, 4, 0, 2, 1), (2, 32, 0, 4, 1, 2, 1), (2, 32, 0, 4, 0, 2, 1),
+    (2, 32, 0, 8, 0, 2, 1),
 }
 
 
@@ -27,10 +29,10 @@ def instances16_in_trace(path):
     out = set()
     with open(path) as f:
         for line in f:
-            m = re.match(r"k_sconv_mfma16<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", line)
+            m = re.match(r"k_sconv_(mfma|plan)16<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", line)
             if m:
-                out.add((int(m.group(1)), int(m.group(2)), int(m.group(5) == "true"), int(m.group(3)),
-                         int(m.group(6) == "true"), int(m.group(4))))
+                out.add((int(m.group(2)), int(m.group(3)), int(m.group(6) == "true"), int(m.group(4)),
+                         int(m.group(7) == "true"), int(m.group(5)), int(m.group(1) == "plan")))
     return out
 
 

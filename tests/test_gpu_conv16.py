@@ -63,15 +63,29 @@ SHAPES = [
 
 def test_shapes_cover_the_bench_instances():
     from sconv_instances import BENCH_INSTANCES16
-    forced = {(s[6], 32, 0, s[7], int(s[5] > 0), 2) for s in SHAPES if s[6] and s[7]}
+    forced = {(s[6], 32, 0, s[7], int(s[5] > 0), 2, 1) for s in SHAPES if s[6] and s[7] and s[3] % 32 == 0}
     assert BENCH_INSTANCES16 <= forced, BENCH_INSTANCES16 - forced
 
 
+@pytest.fixture
+def plan_option(request, gpu):
+    """runs a test with the plan-driven kernel (default) or with the table-driven one"""
+    from asr_hip import ops
+    ctx = ops.context(gpu)
+    ctx.set_option("sconv_plan", int(request.param))
+    yield bool(request.param)
+    ctx.set_option("sconv_plan", 1)
+
+
+@pytest.mark.parametrize("plan_option", [1, 0], ids=["plan", "table"], indirect=True)
 @pytest.mark.parametrize("mode", ["bf16x3", "f16"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%s%d-%dx%d+%d-nt%dw%d" % (s[0], s[1], s[3], s[4], s[5], s[6], s[7]))
-def test_sparse_conv16_vs_oracle(geo, gpu, mode, shape):
+def test_sparse_conv16_vs_oracle(geo, gpu, mode, shape, plan_option):
     from asr_hip import ops
     kind, level, K, cin, ca, cb, nt, waves = shape
+    # the plan-driven kernel takes cin that fills whole panels; everything else goes to the table-driven one
+    kc = 64 if mode == "f16" and ((cin + 31) // 32 * 32) % 64 == 0 else 32
+    expect_plan = int(plan_option and cin % kc == 0)
     if mode == "bf16x3" and cin % 4:
         pytest.skip("f32 rows need cin % 4 == 0")
     idx, kidx, rs, num_inp = _csr(geo, kind, level)
@@ -114,6 +128,7 @@ def test_sparse_conv16_vs_oracle(geo, gpu, mode, shape):
     _close(out.cpu().numpy(), ref)
     key = list(ctx.sconv_variant_counts())
     assert len(key) == 1 and key[0][5] == (1 if f16 else 2) and (nt == 0 or key[0][0] == nt)
+    assert key[0][6] == expect_plan, key
     if not cb:
         # importance weighted + normalised single bank (conv1b alone), residual after the activation
         res = rng.standard_normal((v, ca)).astype(np.float32)
@@ -171,7 +186,7 @@ def test_whole_path_precisions(gpu, precision, tol):
     pipe.ctx.sconv_variant_counts(reset=True)
     values = pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
     counts = pipe.ctx.sconv_variant_counts()
-    assert sum(counts.values()) == 44 and all(len(k) == 6 and k[5] == (2 if precision == "bf16x3" else 1) for k in counts)
+    assert sum(counts.values()) == 44 and all(len(k) == 7 and k[5] == (2 if precision == "bf16x3" else 1) and k[6] == 1 for k in counts)
     assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), ref["voxel_keys0"])
     for name, got in (("code", pipe.get("code")), ("values", values)):
         scale = max(1.0, float(np.abs(ref[name]).max()))
@@ -181,3 +196,61 @@ def test_whole_path_precisions(gpu, precision, tol):
     # deterministic
     v2 = pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
     assert torch.equal(values, v2)
+
+
+def test_conv_plan_reuse_and_row_lists(geo, gpu):
+    """One ConvPlan serves every convolution over its list (plain, two-bank, importance-weighted); a plan built
+    for a row list (row_perm + num_rows) writes exactly those rows; per-pair importance ignores the plan."""
+    from asr_hip import ops
+    idx, kidx, rs, num_inp = _csr(geo, "nb", 1)
+    v = len(rs) - 1
+    rng = np.random.default_rng(5)
+    K, cin, ca, cb = 55, 64, 56, 8
+    f = rng.standard_normal((num_inp, cin)).astype(np.float32)
+    Wa = (rng.standard_normal((K, cin, ca)) * np.sqrt(2.0 / (8 * cin))).astype(np.float32)
+    Wb = (rng.standard_normal((K, cin, cb)) * np.sqrt(2.0 / (8 * cin))).astype(np.float32)
+    imp = rng.uniform(0.05, 1.0, size=num_inp).astype(np.float32)
+    nimp = imp[idx.astype(np.int64)]
+    d_idx, d_k, d_rs = _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu)
+    perm = ops.row_groups(d_k, d_rs)
+    plan = ops.ConvPlan(K, d_idx, d_k, d_rs, row_perm=perm)
+    assert 0 < plan.nbytes() < 64 * idx.size + (1 << 21)  # about the size of the list, never 16x it
+    ctx = ops.context(gpu)
+    ctx.sconv_variant_counts(reset=True)
+    pa = ops.pack_filters(_t(Wa, gpu), "bf16x3")
+    pab = ops.pack_filters(_t(Wa, gpu), "bf16x3", _t(Wb, gpu))
+    with O.precise():
+        ref_a = O.sparse_conv(Wa, f, idx, kidx, None, rs, False)
+        ref_b = O.sparse_conv(Wb, f, idx, kidx, nimp, rs, True)
+        ref_i = O.sparse_conv(Wa, f, idx, kidx, nimp, rs, True)
+    a = ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan)
+    _close(a.cpu().numpy(), ref_a)
+    ab, oi = ops.sparse_conv16("bf16x3", pab, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
+                               inp_importance=_t(imp, gpu), normalize=True, cout_b=cb, return_importance=True)
+    _close(ab.cpu().numpy(), np.concatenate([ref_a, ref_b], 1))
+    _close(oi.cpu().numpy(), O.reduce_subarrays_sum(nimp, rs))
+    ai = ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
+                           inp_importance=_t(imp, gpu), normalize=True)
+    _close(ai.cpu().numpy(), ref_i)
+    assert all(k[6] == 1 for k in ctx.sconv_variant_counts())
+    # per-pair importance: table-driven kernel, same numbers
+    ctx.sconv_variant_counts(reset=True)
+    an = ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
+                           neighbors_importance=_t(nimp, gpu), normalize=True)
+    _close(an.cpu().numpy(), ref_i)
+    assert all(k[6] == 0 for k in ctx.sconv_variant_counts())
+    # row list: the first 1000 rows of a shuffled order; other rows of `out` stay untouched
+    order = torch.from_numpy(rng.permutation(v).astype(np.int32)).to(gpu)
+    n_rows = 1000
+    lplan = ops.ConvPlan(K, d_idx, d_k, d_rs, row_perm=order, num_rows=n_rows)
+    out = torch.full((v, ca), 7.0, dtype=torch.float32, device=gpu)
+    ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=order, num_rows=n_rows,
+                      plan=lplan, out=out)
+    rows = order[:n_rows].long().cpu().numpy()
+    got = out.cpu().numpy()
+    _close(got[rows], ref_a[rows])
+    rest = np.setdiff1d(np.arange(v), rows)
+    assert np.all(got[rest] == 7.0)
+    # a plan of another list is refused
+    with pytest.raises(Exception):
+        ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=lplan)

@@ -1,0 +1,92 @@
+// Microbenchmark: per-CU throughput of the sparse-conv gather pattern (16 rows x 128 B per wave-instruction pair,
+// 16 B per lane) as a function of loads in flight and of the footprint the rows come from.
+// build: hipcc --offload-arch=gfx950 -O3 -o gather_bw gather_bw.hip ; run: ./gather_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int DEPTH, int MAP>
+__global__ __launch_bounds__(512) void k_gather(const float* __restrict__ feat, unsigned bytes, const int* __restrict__ idx,
+                                                int n_idx, int iters, int ld_bytes, unsigned* out) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)bytes, 0x00020000);
+    const int lane = threadIdx.x & 63;
+    const int r = MAP == 0 ? (lane & 15) : MAP == 1 ? (lane >> 2) : (lane >> 3);
+    const int g = MAP == 0 ? (lane >> 4) : MAP == 1 ? (lane & 3) : (lane & 7);
+    const unsigned lane_off = MAP == 0 ? 32u * g : 16u * g;
+    const unsigned second = MAP == 0 ? 16u : MAP == 1 ? 64u : 0u;  // MAP 2: second load = rows + 8 (other idx)
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    u32x4 q[DEPTH][2];
+    unsigned acc = 0;
+    int pos = (wave_global * 16 + r) % n_idx;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const unsigned off = (unsigned)idx[pos] * (unsigned)ld_bytes + lane_off;
+        const unsigned off2 = MAP == 2 ? (unsigned)idx[(pos + 8) % n_idx] * (unsigned)ld_bytes + lane_off : off + second;
+        q[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+        q[d][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off2, 0, 0);
+        pos = (pos + 7919) % n_idx;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            acc += q[d][0][0] ^ q[d][1][3];
+            const unsigned off = (unsigned)idx[pos] * (unsigned)ld_bytes + lane_off;
+            const unsigned off2 = MAP == 2 ? (unsigned)idx[(pos + 8) % n_idx] * (unsigned)ld_bytes + lane_off : off + second;
+            q[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+            q[d][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off2, 0, 0);
+            pos = (pos + 7919) % n_idx;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) acc += q[d][0][1] ^ q[d][1][2];
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main() {
+    const int ld = 256;  // 64 channels f32
+    const size_t rows_max = 2500000;
+    float* feat;
+    hipMalloc(&feat, rows_max * ld);
+    hipMemset(feat, 0, rows_max * ld);
+    unsigned* out;
+    hipMalloc(&out, 4);
+    const int n_idx = 1 << 22;
+    int* d_idx;
+    hipMalloc(&d_idx, n_idx * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const size_t foot[] = {64, 8192, 65536, 2500000};  // rows: 16 KB (L1), 2 MB (L2), 16 MB (MALL), 640 MB (HBM)
+    for (size_t rows : foot) {
+        std::vector<int> h(n_idx);
+        srand(1);
+        for (int i = 0; i < n_idx; ++i) h[i] = (int)(((size_t)rand() * 32768 + rand()) % rows);
+        hipMemcpy(d_idx, h.data(), n_idx * 4, hipMemcpyHostToDevice);
+        for (int map : {0, 1, 2})
+        for (int blocks_per_cu : {2}) {
+            for (int depth : {2}) {
+                const int iters = 2000 / depth;
+                const int grid = 256 * blocks_per_cu;
+                auto launch = [&]() {
+                    if (map == 0) k_gather<2, 0><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
+                    if (map == 1) k_gather<2, 1><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
+                    if (map == 2) k_gather<2, 2><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
+                };
+                launch();
+                hipDeviceSynchronize();
+                hipEventRecord(e0);
+                launch();
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                const double bytes = (double)grid * 8 * (iters * depth) * 2048.0;
+                printf("map %d rows %8zu  blocks/CU %d depth %d : %7.2f TB/s  (%5.1f B/clk/CU at 2.4 GHz)\n", map, rows, blocks_per_cu,
+                       depth, bytes / ms / 1e9, bytes / ms / 1e9 * 1e12 / 256 / 2.4e9 / 1e0 / 1e0 * 1.0);
+            }
+        }
+    }
+    return 0;
+}

@@ -916,18 +916,17 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
                 jobs.push_back({g.down_idx, g.down_kidx, g.down_rs, g.perm_down, c.v, 9});
             }
         }
-        std::vector<i64> blocks(jobs.size(), 0);
+        std::vector<asr_conv_plan> plans(jobs.size());
         for (size_t j = 0; j < jobs.size(); ++j) {
-            asr_conv_plan& pl = ctx->conv_plans[jobs[j].rs];
-            ASR_TRY(asr_geom_conv_plan_count(ctx, ctx->persist, jobs[j].idx, jobs[j].kidx, jobs[j].rs, jobs[j].perm,
-                                             jobs[j].rows, jobs[j].K, &pl));
-            if (pl.offs)
-                ASR_HIP_CHECK(ctx, hipMemcpyAsync(&blocks[j], pl.offs + pl.groups_pad, sizeof(i64),
-                                                  hipMemcpyDeviceToHost, ctx->stream));
+            plans[j].nidx = jobs[j].idx;
+            plans[j].kidx = jobs[j].kidx;
+            plans[j].rs = jobs[j].rs;
+            plans[j].perm = jobs[j].perm;
+            plans[j].num_out = jobs[j].rows;
+            plans[j].K = jobs[j].K;
         }
-        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (size_t j = 0; j < jobs.size(); ++j)
-            ASR_TRY(asr_geom_conv_plan_fill(ctx, ctx->persist, &ctx->conv_plans[jobs[j].rs], blocks[j]));
+        ASR_TRY(asr_geom_conv_plan_batch(ctx, ctx->persist, plans.data(), (int)plans.size()));
+        for (size_t j = 0; j < jobs.size(); ++j) ctx->conv_plans[jobs[j].rs] = plans[j];
     }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 

@@ -340,6 +340,8 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* args);
 int asr_geom_conv_plan_count(asr_hip_context* ctx, Arena& keep, const int32_t* nidx, const uint8_t* kidx, const i64* rs,
                              const int32_t* perm, i64 num_out, int K, asr_conv_plan* plan);
 int asr_geom_conv_plan_fill(asr_hip_context* ctx, Arena& keep, asr_conv_plan* plan, i64 blocks);
+// plans[j] with nidx/kidx/rs/perm/num_out/K set: all built in one pass over the concatenated lists, one pool
+int asr_geom_conv_plan_batch(asr_hip_context* ctx, Arena& keep, asr_conv_plan* plans, int n);
 int asr_geom_conv_plan_build(asr_hip_context* ctx, Arena& keep, const int32_t* nidx, const uint8_t* kidx, const i64* rs,
                              const int32_t* perm, i64 num_out, int K, asr_conv_plan* plan);  // count + read-back + fill
 

@@ -1986,6 +1986,124 @@ int asr_geom_conv_plan_fill(asr_hip_context* ctx, Arena& keep, asr_conv_plan* pl
     return ASR_HIP_OK;
 }
 
+// All lists of a build in one pass: one slot-set kernel, one scan, one read-back, one fill over the concatenated
+// row ranges.  The plans share one pool (their headers hold positions in it).
+namespace {
+constexpr int PLAN_MAX_JOBS = 16;
+struct PlanBatch {
+    int n;
+    i64 base[PLAN_MAX_JOBS + 1];  // first (padded) row of each job, multiples of 256; base[n] = total
+    i64 rows[PLAN_MAX_JOBS];
+    int K[PLAN_MAX_JOBS];
+    const int32_t* nidx[PLAN_MAX_JOBS];
+    const uint8_t* kidx[PLAN_MAX_JOBS];
+    const i64* rs[PLAN_MAX_JOBS];
+    const int32_t* perm[PLAN_MAX_JOBS];
+};
+__device__ inline int plan_job_of(const PlanBatch& b, i64 row) {
+    int j = 0;
+    while (j + 1 < b.n && row >= b.base[j + 1]) ++j;
+    return j;
+}
+__global__ void k_plan_masks_batch(PlanBatch b, uint4* __restrict__ hdr, i64* __restrict__ counts) {
+    const i64 grow = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (grow >= b.base[b.n]) return;
+    const int j = plan_job_of(b, grow);
+    const i64 row = grow - b.base[j];
+    unsigned long long m = 0;
+    if (row < b.rows[j]) {
+        const i64 q = b.perm[j] ? b.perm[j][row] : row;
+        const uint8_t* kidx = b.kidx[j];
+        for (i64 p = b.rs[j][q], pe = b.rs[j][q + 1]; p < pe; ++p) {
+            const int k = kidx[p];
+            if (k < b.K[j]) m |= 1ull << k;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m |= __shfl_xor(m, o, 64);
+    if ((threadIdx.x & 15) == 0) {
+        hdr[grow >> 4] = make_uint4((unsigned)m, (unsigned)(m >> 32), 0u, 0u);
+        counts[grow >> 4] = (i64)__popcll(m);
+    }
+}
+__global__ void k_plan_fill_batch(PlanBatch b, const i64* __restrict__ offs, uint4* __restrict__ hdr,
+                                  int32_t* __restrict__ pool) {
+    const i64 grow = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (grow >= b.base[b.n]) return;
+    const i64 grp = grow >> 4;
+    const unsigned off = (unsigned)offs[grp];
+    if ((grow & 15) == 0) hdr[grp].z = off;
+    const int j = plan_job_of(b, grow);
+    const i64 row = grow - b.base[j];
+    if (row >= b.rows[j]) return;
+    const uint2 h = *reinterpret_cast<const uint2*>(&hdr[grp]);
+    const unsigned long long m = (unsigned long long)h.x | ((unsigned long long)h.y << 32);
+    const i64 q = b.perm[j] ? b.perm[j][row] : row;
+    const uint8_t* kidx = b.kidx[j];
+    const int32_t* nidx = b.nidx[j];
+    for (i64 p = b.rs[j][q], pe = b.rs[j][q + 1]; p < pe; ++p) {
+        const int k = kidx[p];
+        if (k >= b.K[j]) continue;
+        pool[((i64)off + __popcll(m & ((1ull << k) - 1))) * 16 + (row & 15)] = nidx[p];
+    }
+}
+}  // namespace
+
+int asr_geom_conv_plan_batch(asr_hip_context* ctx, Arena& keep, asr_conv_plan* plans, int n) {
+    if (n > PLAN_MAX_JOBS) ASR_FAIL(ctx, ASR_HIP_EINVAL, "conv_plan_batch: too many lists");
+    PlanBatch b;
+    memset(&b, 0, sizeof(b));
+    b.n = 0;
+    i64 total = 0;
+    int which[PLAN_MAX_JOBS];
+    for (int j = 0; j < n; ++j) {
+        asr_conv_plan& pl = plans[j];
+        pl.hdr = nullptr;
+        pl.pool = nullptr;
+        pl.offs = nullptr;
+        pl.groups = pl.groups_pad = pl.blocks = 0;
+        if (pl.num_out <= 0) continue;
+        pl.groups = (pl.num_out + 15) / 16;
+        pl.groups_pad = (pl.groups + 15) / 16 * 16;
+        which[b.n] = j;
+        b.base[b.n] = total;
+        b.rows[b.n] = pl.num_out;
+        b.K[b.n] = pl.K;
+        b.nidx[b.n] = pl.nidx;
+        b.kidx[b.n] = pl.kidx;
+        b.rs[b.n] = pl.rs;
+        b.perm[b.n] = pl.perm;
+        total += pl.groups_pad * 16;
+        ++b.n;
+    }
+    b.base[b.n] = total;
+    if (b.n == 0) return ASR_HIP_OK;
+    const i64 groups = total / 16;
+    uint4* hdr = (uint4*)keep.alloc(groups * sizeof(uint4));
+    i64* offs = (i64*)keep.alloc((groups + 1) * sizeof(i64));
+    i64* counts = (i64*)ctx->scratch.alloc((groups + 1) * sizeof(i64));
+    if (!hdr || !offs || !counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(counts + groups, 0, sizeof(i64), ctx->stream));
+    k_plan_masks_batch<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, hdr, counts);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(asr_prim::scan_counts(ctx, ctx->scratch, counts, offs, groups + 1));
+    i64 blocks = 0;
+    ASR_TRY(asr_prim::read_i64(ctx, offs + groups, &blocks));
+    int32_t* pool = (int32_t*)keep.alloc((size_t)(blocks > 0 ? blocks : 1) * 64);
+    if (!pool) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(pool, 0xFF, (size_t)(blocks > 0 ? blocks : 1) * 64, ctx->stream));
+    k_plan_fill_batch<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, offs, hdr, pool);
+    ASR_CHECK_LAUNCH(ctx);
+    for (int t = 0; t < b.n; ++t) {
+        asr_conv_plan& pl = plans[which[t]];
+        pl.hdr = hdr + b.base[t] / 16;
+        pl.offs = offs + b.base[t] / 16;
+        pl.pool = pool;
+        pl.blocks = blocks;
+    }
+    return ASR_HIP_OK;
+}
+
 int asr_geom_conv_plan_build(asr_hip_context* ctx, Arena& keep, const int32_t* nidx, const uint8_t* kidx, const i64* rs,
                              const int32_t* perm, i64 num_out, int K, asr_conv_plan* plan) {
     ASR_TRY(asr_geom_conv_plan_count(ctx, keep, nidx, kidx, rs, perm, num_out, K, plan));

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
 // Row weights (conv1b: importance of the neighbour) are read per (row, slot) through the plan as well.
 // ------------------------------------------------------------------------------------------
 template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) void k_sconv_plan16(
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4) void k_sconv_plan16(
         asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
         const float* __restrict__ zeros) {
     constexpr int TM = WAVES * 16;
@@ -571,13 +571,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
              ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.y) << 32)) & ((1ull << K) - 1);
     const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane((int)h.z);
     if (lane == 0) s_wm[wave] = wmask;
-    // output rows of this lane's four accumulator rows (-1: beyond the list)
-    int q4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const i64 lr = row0 + wave * 16 + 4 * g + i;
-        q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
-    }
     __syncthreads();
     unsigned long long bmask = 0;
 #pragma unroll
@@ -611,13 +604,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
             __builtin_amdgcn_make_buffer_rsrc((void*)plan.pool, 0, (int)plan.pool_bytes, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(ROWW ? a.inp_importance : zeros), 0, ROWW ? (int)(unsigned)(a.num_inp * 4) : 4, RSRC_FLAGS);
-    // weight panel -> LDS: chunk c = s * WAVES + wave (1 KB) of the panel, lane l moves its 16-byte piece
-    unsigned w_off[SV];
+    // weight panel -> LDS: chunk c = s * WAVES + wave (1 KB) of the panel, lane l moves its 16-byte piece; the
+    // chunk position is wave-uniform and travels in the scalar offset
+    const int lane16 = lane * 16;
+    unsigned w_soff[SV];
 #pragma unroll
     for (int s = 0; s < SV; ++s) {
         const int c = s * WAVES + wave;
         const int pl = c / CHUNKS_PER_PLANE, ci = c % CHUNKS_PER_PLANE;
-        w_off[s] = c < NCHUNK ? (unsigned)((pl * plane_stride + (i64)n0 * KC) * 2 + ci * 1024 + lane * 16) : OOB_OFF;
+        w_soff[s] = (unsigned)((pl * plane_stride + (i64)n0 * KC) * 2 + ci * 1024);
     }
     auto dma_panel = [&](const int qk, const int qp, auto bufc) __attribute__((always_inline)) {
         const int soff = (((qk < 0 ? 0 : qk) * npanel + qp) * ctot_pad * KC) * 2;
@@ -627,7 +622,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
             const int c = s * WAVES + wave;
             if (NCHUNK % WAVES == 0 || c < NCHUNK)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)&dst[c * 64], 16,
-                                                         (int)w_off[s], soff, 0, 0);
+                                                         lane16, soff + (int)w_soff[s], 0, 0);
         }
     };
     // neighbour index of this lane's row for slot k (wave-uniform k): one 64-byte block of the pool.  The load
@@ -673,7 +668,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
                         __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off + (32 * j + 4 * hh) * ESZ, soff, 0);
     };
 
-    u32x4 a_q0[NJ * AW], a_q1[NJ * AW];
+    // Feature gathers run two steps ahead, or one step ahead where the eight registers that saves buy another
+    // block per CU (plain 8-wave instances: 80 registers -> three blocks of NT = 8; measured per layer)
+    constexpr int DEPTH = (WAVES == 8 && !IMP && !DUAL) ? 1 : 2;
+    u32x4 a_q0[NJ * AW], a_q1[DEPTH == 2 ? NJ * AW : 1];
     unsigned long long todo1 = bmask;
     int k_cur = bmask ? __builtin_ctzll(bmask) : -1, p_cur = 0;
     int k1 = k_cur, p1 = 0;
@@ -685,7 +683,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
         dma_panel(k_cur, p_cur, B0());
         if (ROWW && roww) idx4_next = load_idx4(k_cur);
         gather_a(k_cur, p_cur, a_q0, true);
-        gather_a(k1, p1, a_q1, false);
+        if constexpr (DEPTH == 2) gather_a(k1, p1, a_q1, false);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -733,7 +731,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
                 }
             }
         }
-        gather_a(k2, p2, aq, false);
+        if constexpr (DEPTH == 2)
+            gather_a(k2, p2, aq, false);
+        else
+            gather_a(k1, p1, aq, false);
         if (active) {
             const u32x4* sb = BUF ? s_B1 : s_B0;
             __builtin_amdgcn_s_setprio(1);
@@ -761,16 +762,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
                     for (int nb = 0; nb < NT; ++nb) {
                         const int col = nb * 16 + ncol;
                         const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
-                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);
-                        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);
-                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);
-#define ASR_SIX(ACC_)                                                         \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ACC_, 0, 0, 0);
+                        // one weight plane at a time (a B fragment lives for at most three MFMAs), small terms first
+#define ASR_SIX(ACC_)                                                                                   \
+    {                                                                                                   \
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);                     \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, ACC_, 0, 0, 0);                          \
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);                         \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC_, 0, 0, 0);                          \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ACC_, 0, 0, 0);                          \
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);                                        \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, ACC_, 0, 0, 0);                          \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, ACC_, 0, 0, 0);                          \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ACC_, 0, 0, 0);                          \
+    }
                         if (IMP) {
                             ASR_SIX(tacc[nb])
                         } else {
@@ -811,7 +815,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
     while (k_cur >= 0) {
         step(a_q0, B0());
         if (k_cur < 0) break;
-        step(a_q1, B1());
+        if constexpr (DEPTH == 2)
+            step(a_q1, B1());
+        else
+            step(a_q0, B1());
     }
 #undef ASR_SEQ_ADVANCE
 
@@ -825,6 +832,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 ? 2 : 3) : 4) voi
         bv[nb] = *bp;
     }
     const bool res16 = MODE == ASR_CONV16_F16;
+    // output rows of this lane's four accumulator rows (-1: beyond the list)
+    int q4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 lr = row0 + wave * 16 + 4 * g + i;
+        q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const i64 q = q4[i];

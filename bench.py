@@ -36,10 +36,10 @@ PRECISION_INFO = {
     # six bf16 MFMAs per algorithmic product: the executed work is priced at the bf16 peak
     # f32 in / f32 out with fp32-class error: priced against the f32 matrix peak like the exact f32 kernel; the
     # executed work (6 bf16 MFMAs per product) is reported beside it
-    "bf16x3": ("f32", MFMA_F32_PEAK_TFLOPS, "k_sconv_mfma16<bf16x3>",
+    "bf16x3": ("f32", MFMA_F32_PEAK_TFLOPS, "k_sconv_plan16<bf16x3>",
                "dtype f32: f32-input MFMA dense peak; the kernel executes 6 bf16 MFMA products per algorithmic "
                "product (bf16 dense peak %.0f TFLOP/s)" % MFMA_16BIT_PEAK_TFLOPS),
-    "f16": ("f16", MFMA_16BIT_PEAK_TFLOPS, "k_sconv_mfma16<f16>", "f16 MFMA dense peak"),
+    "f16": ("f16", MFMA_16BIT_PEAK_TFLOPS, "k_sconv_plan16<f16>", "f16 MFMA dense peak"),
 }
 
 
@@ -328,7 +328,7 @@ def main():
     pipelined = None
     if world == 1 and not args.no_pipelined:
         pipelined = [pipelined_rate(pipe, weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(6, 2 * args.steps), d)
-                     for d in (2, 3)]
+                     for d in (2, 3)]  # contexts in flight
 
     # raw-scan rate (outside `value`: the metric takes radii as inputs): the exact 24-NN radius
     # estimate of the pre-filter (cpp/lib/preprocess.cpp:25-39) on the GPU, steady state (second call), + one step

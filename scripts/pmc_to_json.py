@@ -13,15 +13,15 @@ def total(path, col):
     lines = open(path).read().splitlines()
     names = lines[0].split("|")
     i = names.index(col)
-    return sum(float(l.split("|")[i]) for l in lines[1:] if l.startswith("k_sconv_mfma")), \
-        sum(int(l.split("|")[1]) for l in lines[1:] if l.startswith("k_sconv_mfma"))
+    return sum(float(l.split("|")[i]) for l in lines[1:] if l.startswith(("k_sconv_mfma", "k_sconv_plan"))), \
+        sum(int(l.split("|")[1]) for l in lines[1:] if l.startswith(("k_sconv_mfma", "k_sconv_plan")))
 
 
 fetch, n1 = total("profiles/%s_fetch.csv" % tag, "FETCH_SIZE")
 write, n2 = total("profiles/%s_write.csv" % tag, "WRITE_SIZE")
 assert n1 == n2 == launches, (n1, n2, launches)
 hbm = (2 * fetch + write) * 1024
-json.dump({"kernel": "k_sconv_mfma16" if precision != "f32" else "k_sconv_mfma", "precision": precision, "launches": launches, "fetch_size_kb": fetch, "write_size_kb": write,
+json.dump({"kernel": "k_sconv_plan16" if precision != "f32" else "k_sconv_mfma", "precision": precision, "launches": launches, "fetch_size_kb": fetch, "write_size_kb": write,
            "hbm_bytes_per_forward": hbm, "hbm_bytes_per_launch": hbm / launches, "points": 10_000_000,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0` "
                    "(10 M points); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half of a "

@@ -255,7 +255,14 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
     __shared__ float s_norm[8][CCG];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const float cxf = (float)(lane & 3), cyf = (float)((lane >> 2) & 3), czf = (float)(lane >> 4);
+    // pair loop on the matrix cores: the 64 x 4 cell sums of a voxel are ONE 16 x 16 accumulator tile,
+    // D[i = cy + 4 cz][j = c + 4 cx] = sum over pairs of (hy hz)[i] * (hx w f_c)[j], i.e. k = 16 i + j of the group matrix;
+    // a v_mfma_f32_16x16x4_f32 takes four pairs: lane (i = n, pair g) supplies A = hy(cy) hz(cz), lane (j = n, pair g)
+    // B = hx(cx) f_c -- three hat functions and two products per lane for four pairs, where the VALU loop spent 15
+    // instructions per pair.
+    const float a_cy = (float)(n & 3), a_cz = (float)(n >> 2);  // A operand: row i = n
+    const float b_cx = (float)(n >> 2);                         // B operand: column j = n -> cx = j / 4, channel j % 4
+    const int b_c = n & 3;
     // filter fragments: wreg[T][j][t] = W[k = 16 j + 4 g + t][o = 16 T + n], W = filters viewed as [256][cout]
     float wreg[2][16][4];
 #pragma unroll
@@ -330,7 +337,8 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
             const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(moy), u));
             const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(moz), u));
             const float sc2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(msc), u));
-            float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
+            f32x4 D = {0.f, 0.f, 0.f, 0.f};
+            float norm_lane = 0.f;
             if (!heavy && cnt_all > 0) {
                 const int b = __builtin_amdgcn_readlane(mb, u);
                 for (int p0 = 0; p0 < cnt_all; p0 += 64) {
@@ -348,28 +356,30 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
                     cconv_pair_coords((P.x - ox) * sc2, (P.y - oy) * sc2, (P.z - oz) * sc2, ux, uy, uz);
                     norm_lane += w;
                     __builtin_amdgcn_wave_barrier();
-                    s_pair[wib][2 * lane] = make_float4(ux, uy, uz, w * F.x);
-                    s_pair[wib][2 * lane + 1] = make_float4(w * F.y, w * F.z, w * F.w, 0.f);
+                    // lanes beyond cnt park zero features: their products vanish
+                    s_pair[wib][2 * lane] = make_float4(ux, uy, uz, 0.f);
+                    s_pair[wib][2 * lane + 1] = make_float4(w * F.x, w * F.y, w * F.z, w * F.w);
                     __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-                    for (int j = 0; j < cnt; ++j) {
-                        const float4 a = s_pair[wib][2 * j], bq = s_pair[wib][2 * j + 1];
-                        const float wx = fminf(fmaxf(1.f - fabsf(a.x - cxf), 0.f), 1.f);
-                        const float wy = fminf(fmaxf(1.f - fabsf(a.y - cyf), 0.f), 1.f);
-                        const float wz = fminf(fmaxf(1.f - fabsf(a.z - czf), 0.f), 1.f);
-                        const float wt = wx * wy * wz;
-                        B0 += wt * a.w;
-                        B1 += wt * bq.x;
-                        B2 += wt * bq.y;
-                        B3 += wt * bq.z;
+                    const float* sp = reinterpret_cast<const float*>(&s_pair[wib][0]);
+#pragma unroll 2
+                    for (int j = 0; j < cnt; j += 4) {
+                        const float4 a = s_pair[wib][2 * (j + g)];
+                        const float fc = sp[8 * (j + g) + 4 + b_c];
+                        const float wx = fminf(fmaxf(1.f - fabsf(a.x - b_cx), 0.f), 1.f);
+                        const float wy = fminf(fmaxf(1.f - fabsf(a.y - a_cy), 0.f), 1.f);
+                        const float wz = fminf(fmaxf(1.f - fabsf(a.z - a_cz), 0.f), 1.f);
+                        D = __builtin_amdgcn_mfma_f32_16x16x4f32(wy * wz, wx * fc, D, 0, 0, 0);
                     }
                 }
             }
-            *reinterpret_cast<float4*>(&s_bt[wib][u][4 * lane]) = make_float4(B0, B1, B2, B3);
+            // D[r] = cell sums k = 16 (4 g + r) + n
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_bt[wib][u][16 * (4 * g + r) + n] = D[r];
             const float norm = wave_sum_dpp(norm_lane);
             if (lane == 0) s_norm[wib][u] = heavy ? -1.f : norm;  // -1: written by k_cconv_heavy
             if (basis_out && q0 + u < num_out) {
-                *reinterpret_cast<float4*>(&basis_out[(q0 + u) * 256 + 4 * lane]) = make_float4(B0, B1, B2, B3);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) basis_out[(q0 + u) * 256 + 16 * (4 * g + r) + n] = D[r];
                 if (lane == 0) norm_out[q0 + u] = norm;
             }
         }

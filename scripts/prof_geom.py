@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 pts, nrm = synth.scan_cloud(n, seed=1000, device=dev)
 radii = synth.knn_radii_gpu(pts, 24)
 bb = synth.bounding_box(pts, 0.1)
-pipe = ImplicitPipeline(synth.make_weights(4, seed=0), device=dev)
+pipe = ImplicitPipeline(synth.make_weights(4, seed=0), device=dev, precision="bf16x3")
 pipe.ctx.set_option("overlap", overlap)
 for i in range(4):
     torch.cuda.synchronize()

@@ -817,12 +817,16 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
                                              const int32_t* start, const int32_t* end, int lfine, int k,
                                              const float* radii_in, float radius_fraction,
                                              int outlier_threshold, float* radii_out,
-                                             uint8_t* inlier_out) {
+                                             uint8_t* inlier_out, const int32_t* list, i64 nlist) {
     constexpr int CMAX = 8;
     __shared__ int s_pref[4][28];
     __shared__ int s_beg[4][28];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 s = blockIdx.x * (i64)4 + wave;
+    i64 s = blockIdx.x * (i64)4 + wave;
+    if (list) {  // only the points (positions in Morton order) that k_knn_cells could not settle
+        if (s >= nlist) return;
+        s = list[s];
+    }
     if (s >= n) return;
     const float4 me = sorted[s];
     const int kk = (int)(n < k ? n : k);
@@ -1027,6 +1031,133 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
         }
     }
     if (lane == 0 && radii_out) radii_out[__float_as_int(me.w)] = sqrtf(__uint_as_float(kth_bits));
+}
+
+
+// ------------------------------------------------------------------------------------------
+// kNN radius, fast path: ONE WAVE PER OCCUPIED CELL of the finest level.  All points of a cell share the 3^3
+// block of candidate cells, so the wave stages the candidates in LDS 64 at a time and every lane keeps the K
+// smallest squared distances of ITS query point in registers (ascending; inserting d and dropping the largest is
+// a[c] = med3(a[c-1], d, a[c]) from the top down: one v_med3_f32 per slot, no divergence; a chunk no lane can use
+// is skipped with one ballot).  The wave-per-point kernel above spends 27 table probes, a candidate walk and two
+// 31-step bit searches on every point.  A result is exact when the k-th distance does not exceed the cell size
+// (the k nearest lie inside the block); the other points -- sparse regions, cells with fewer than k candidates
+// -- go to a list that k_knn settles level by level as before.  Same numbers as k_knn (tested).
+// ------------------------------------------------------------------------------------------
+// first point of every run of equal level-`level` cells in the sorted codes.  4096 points per block, ONE atomic per
+// block for the block's share of the list (same-address atomics retire at ~88 / us).
+__global__ __launch_bounds__(256) void k_cell_list(const u64* codes, i64 n, int level, int32_t* list, int* cnt) {
+    __shared__ int s_cnt[256];
+    __shared__ int s_base;
+    const int s = 3 * (ASR_MAX_LEVEL - level);
+    const i64 base = blockIdx.x * (i64)4096;
+    int mine = 0;
+    unsigned flags = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const i64 i = base + j * 256 + threadIdx.x;
+        if (i < n && (i == 0 || (codes[i - 1] >> s) != (codes[i] >> s))) {
+            flags |= 1u << j;
+            ++mine;
+        }
+    }
+    s_cnt[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int c = s_cnt[t];
+            s_cnt[t] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(cnt, tot) : 0;
+    }
+    __syncthreads();
+    int o = s_base + s_cnt[threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (flags & (1u << j)) list[o++] = (int32_t)(base + j * 256 + threadIdx.x);
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_cells(asr_octree_frame f, const float4* sorted, i64 n, HashTab t,
+                                                   const int32_t* start, const int32_t* end, int lfine, int k,
+                                                   const int32_t* cells, i64 ncells, float* radii_out,
+                                                   int32_t* fallback, int* fallback_cnt) {
+    __shared__ int s_pref[4][28];
+    __shared__ int s_beg[4][28];
+    __shared__ __attribute__((aligned(16))) float4 s_cand[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const i64 ci = blockIdx.x * (i64)4 + wave;
+    if (ci >= ncells) return;
+    const int first = cells[ci];
+    const float4 p0 = sorted[first];
+    int x, y, z;
+    frame_coord(f, p0.x, p0.y, p0.z, lfine, x, y, z);
+    const int lim = (1 << lfine) - 1;
+    x = min(max(x, 0), lim);
+    y = min(max(y, 0), lim);
+    z = min(max(z, 0), lim);
+    int b = 0, cnt = 0;
+    if (lane < 27) {
+        int xx = x + lane % 3 - 1, yy = y + (lane / 3) % 3 - 1, zz = z + lane / 9 - 1;
+        if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim) {
+            i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | (u64(1) << (3 * lfine)));
+            if (slot >= 0) {
+                b = start[slot];
+                cnt = end[slot] - b;
+            }
+        }
+    }
+    int pre = cnt;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        int up = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += up;
+    }
+    const int total = __shfl(pre, 26, 64);
+    const int qb = __shfl(b, 13, 64), qn = __shfl(cnt, 13, 64);  // the cell itself: its points are the queries
+    if (lane < 27) {
+        s_pref[wave][lane + 1] = pre;
+        s_beg[wave][lane] = b;
+    }
+    if (lane == 0) s_pref[wave][0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const float cs = f.voxel_size[lfine];
+    const float cs2 = cs * cs;
+    for (int q0 = 0; q0 < qn; q0 += 64) {
+        const bool active = q0 + lane < qn;
+        const float4 me = sorted[qb + (active ? q0 + lane : 0)];
+        float a[K];  // squared distances are >= 0 and finite: float order, +inf = empty
+#pragma unroll
+        for (int c = 0; c < K; ++c) a[c] = __uint_as_float(0x7f800000u);
+        if (total >= k) {
+            for (int c0 = 0; c0 < total; c0 += 64) {
+                const int m = min(64, total - c0);
+                __builtin_amdgcn_wave_barrier();  // the previous chunk has been read
+                if (lane < m) s_cand[wave][lane] = radius_candidate(sorted, s_pref[wave], s_beg[wave], c0 + lane);
+                __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < m; ++j) {
+                    const float4 pt = s_cand[wave][j];
+                    const float d = sqdist3(pt.x, pt.y, pt.z, me.x, me.y, me.z);
+                    if (__ballot(d < a[K - 1]) == 0) continue;
+#pragma unroll
+                    for (int c = K - 1; c > 0; --c) a[c] = __builtin_amdgcn_fmed3f(a[c - 1], d, a[c]);
+                    a[0] = fminf(a[0], d);
+                }
+            }
+        }
+        float kth = a[K - 1];
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+            if (c == k - 1) kth = a[c];
+        if (active) {
+            if (total >= k && kth <= cs2)
+                radii_out[__float_as_int(me.w)] = sqrtf(kth);
+            else
+                fallback[atomicAdd(fallback_cnt, 1)] = qb + q0 + lane;
+        }
+    }
 }
 
 // rows are sorted by a segmented radix sort on (distance bits, index) keys; unpack + compat
@@ -1581,6 +1712,7 @@ struct RadiusState {
     float4* sorted = nullptr;  // points in Morton order, w = original index
     int32_t* ids = nullptr;    // original index of the point at each Morton position
     int32_t* rank = nullptr;   // inverse of ids (only when the caller asked for it)
+    const u64* codes = nullptr;  // sorted level-21 codes (scratch arena: valid until the next reset)
     HashTab tab;
     int32_t* start = nullptr;
     int32_t* end = nullptr;
@@ -1618,6 +1750,7 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     int32_t* ids = arena_alloc<int32_t>(ka, n + 1);
     st.sorted = arena_alloc<float4>(ka, n + 1);
     st.ids = ids;
+    st.codes = codes;
     st.rank = want_rank ? arena_alloc<int32_t>(ka, n + 1) : nullptr;
     if (!codes_u || !codes || !ids_u || !ids || !st.sorted || (want_rank && !st.rank))
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
@@ -1748,10 +1881,46 @@ int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const floa
     RadiusState st;
     int host[16];
     ASR_TRY(build_point_index(ctx, frame, pts, n, 0, lfine, st));
-    k_knn<<<grid_for(n, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lfine, k,
-                                                   radii_in, radius_fraction, outlier_threshold, radii_out,
-                                                   inlier_out);
-    ASR_CHECK_LAUNCH(ctx);
+    const bool fast = !inlier_out && radii_out && k <= 32 && n >= k && ctx->opt.knn_cells;
+    if (fast) {
+        // cell-parallel pass, then the wave-per-point kernel for what it could not certify
+        int32_t* cells = arena_alloc<int32_t>(ctx->scratch, n + 1);
+        int32_t* fallback = arena_alloc<int32_t>(ctx->scratch, n + 1);
+        if (!cells || !fallback) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 12, 0, 2 * sizeof(int), ctx->stream));
+        const int lq = std::max(1, lfine - (int)ctx->opt.knn_level_off);  // level of the cells the fast path works on
+        k_cell_list<<<grid_for(n, 4096), BLK, 0, ctx->stream>>>(st.codes, n, lq, cells, ctx->d_flags + 12);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(read_flags(ctx, host));
+        const i64 ncells = host[12];
+#define ASR_KNN_CELLS(K_)                                                                                           \
+    k_knn_cells<K_><<<grid_for(ncells, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lq, \
+                                                                   k, cells, ncells, radii_out, fallback,            \
+                                                                   ctx->d_flags + 13)
+        if (k <= 8)
+            ASR_KNN_CELLS(8);
+        else if (k <= 16)
+            ASR_KNN_CELLS(16);
+        else if (k <= 24)
+            ASR_KNN_CELLS(24);
+        else
+            ASR_KNN_CELLS(32);
+#undef ASR_KNN_CELLS
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(read_flags(ctx, host));
+        const i64 nfb = host[13];
+        if (nfb > 0) {
+            k_knn<<<grid_for(nfb, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lfine, k,
+                                                             radii_in, radius_fraction, outlier_threshold, radii_out,
+                                                             nullptr, fallback, nfb);
+            ASR_CHECK_LAUNCH(ctx);
+        }
+    } else {
+        k_knn<<<grid_for(n, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lfine, k,
+                                                       radii_in, radius_fraction, outlier_threshold, radii_out,
+                                                       inlier_out, nullptr, 0);
+        ASR_CHECK_LAUNCH(ctx);
+    }
     ASR_TRY(read_flags(ctx, host));
     if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "cell table overflow");
     return ASR_HIP_OK;

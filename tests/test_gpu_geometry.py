@@ -329,3 +329,31 @@ def test_non_finite_points_are_rejected(gpu):
         asr.create_octree(bad, rad, bb[0], bb[1])
     with pytest.raises(RuntimeError):
         asr.KDTree(np.where(np.isfinite(bad), bad, np.float32(np.nan))).compute_k_radius(8)
+
+
+@pytest.mark.gpu
+def test_knn_radius_cell_path_equals_the_wave_path():
+    """asr_hip_knn_radius: the cell-parallel fast path (one wave per occupied cell, top-k in registers) plus its
+    fallback list gives the radii of the wave-per-point kernel, bit for bit, on a cloud with duplicates, dense and
+    sparse regions and isolated points; a slice is checked against the brute-force oracle."""
+    from asr_hip import ops, synth
+    dev = torch.device("cuda:0")
+    p, _ = synth.scan_cloud(300000, seed=12, device="cpu", density_variance=10.0)
+    pts = p.numpy().copy()
+    rng = np.random.default_rng(3)
+    pts[:2000] = pts[2000:4000]                                   # duplicates
+    pts[4000:4200] = rng.uniform(-3, 3, size=(200, 3))            # isolated points far from the surface
+    d = torch.from_numpy(pts).to(dev)
+    ctx = ops.context(dev)
+    try:
+        for k in (1, 8, 24, 32, 40):
+            ctx.set_option("knn_cells", 1)
+            fast = synth.knn_radii_gpu(d, k)
+            ctx.set_option("knn_cells", 0)
+            slow = synth.knn_radii_gpu(d, k)
+            assert torch.equal(fast, slow), (k, float((fast - slow).abs().max()))
+    finally:
+        ctx.set_option("knn_cells", 1)
+    small = pts[:20000]
+    got = synth.knn_radii_gpu(torch.from_numpy(small).to(dev), 24).cpu().numpy()
+    assert np.array_equal(got, O.knn_radius(small, 24))

@@ -38,7 +38,6 @@ const OptEntry k_options[] = {
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
         {"knn_cells", "ASR_KNN_CELLS", &AsrOptions::knn_cells},
-        {"knn_level_off", "ASR_KNN_LEVEL_OFF", &AsrOptions::knn_level_off},
         {"overlap", "ASR_OVERLAP", &AsrOptions::overlap},
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},

@@ -1042,7 +1042,9 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
 // is skipped with one ballot).  The wave-per-point kernel above spends 27 table probes, a candidate walk and two
 // 31-step bit searches on every point.  A result is exact when the k-th distance does not exceed the cell size
 // (the k nearest lie inside the block); the other points -- sparse regions, cells with fewer than k candidates
-// -- go to a list that k_knn settles level by level as before.  Same numbers as k_knn (tested).
+// -- go to a list that k_knn settles level by level as before.  Same numbers as k_knn (tested).  Measured and not
+// kept: cells one level coarser (43 vs 26 ms), one wave per parent cell with the 4^3 block of finest cells as
+// candidates (fuller waves, but 2.3x the candidates per query: 20.5 vs 16.7 ms).
 // ------------------------------------------------------------------------------------------
 // first point of every run of equal level-`level` cells in the sorted codes.  4096 points per block, ONE atomic per
 // block for the block's share of the list (same-address atomics retire at ~88 / us).
@@ -1888,13 +1890,12 @@ int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const floa
         int32_t* fallback = arena_alloc<int32_t>(ctx->scratch, n + 1);
         if (!cells || !fallback) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 12, 0, 2 * sizeof(int), ctx->stream));
-        const int lq = std::max(1, lfine - (int)ctx->opt.knn_level_off);  // level of the cells the fast path works on
-        k_cell_list<<<grid_for(n, 4096), BLK, 0, ctx->stream>>>(st.codes, n, lq, cells, ctx->d_flags + 12);
+        k_cell_list<<<grid_for(n, 4096), BLK, 0, ctx->stream>>>(st.codes, n, lfine, cells, ctx->d_flags + 12);
         ASR_CHECK_LAUNCH(ctx);
         ASR_TRY(read_flags(ctx, host));
         const i64 ncells = host[12];
 #define ASR_KNN_CELLS(K_)                                                                                           \
-    k_knn_cells<K_><<<grid_for(ncells, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lq, \
+    k_knn_cells<K_><<<grid_for(ncells, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lfine, \
                                                                    k, cells, ncells, radii_out, fallback,            \
                                                                    ctx->d_flags + 13)
         if (k <= 8)

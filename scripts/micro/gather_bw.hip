@@ -1,6 +1,6 @@
 // Microbenchmark: per-CU throughput of the sparse-conv gather pattern (16 rows x 128 B per wave-instruction pair,
 // 16 B per lane) as a function of loads in flight and of the footprint the rows come from.
-// build: hipcc --offload-arch=gfx950 -O3 -o gather_bw gather_bw.hip ; run: ./gather_bw
+// build: hipcc --offload-arch=gfx950 -O3 -o scripts/micro/gather_bw scripts/micro/gather_bw.hip ; run on the GPU box: scripts/micro/gather_bw
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -254,3 +254,28 @@ def test_conv_plan_reuse_and_row_lists(geo, gpu):
     # a plan of another list is refused
     with pytest.raises(Exception):
         ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=lplan)
+
+
+def test_feature_matrix_beyond_4gb(gpu):
+    """Feature matrices of 4 GB and more are out of reach of buffer addressing: the launcher hands them to the
+    table-driven kernel, which switches to 64-bit pointers.  9 M rows x 128 f32 (4.6 GB), neighbours spread over the
+    whole matrix, against a float64 gather-and-contract on the GPU."""
+    from asr_hip import ops
+    g = torch.Generator(device=gpu).manual_seed(11)
+    num_inp, cin, cout, K, v, per_row = 9_000_000, 128, 32, 27, 2048, 6
+    f = torch.randn((num_inp, cin), generator=g, device=gpu, dtype=torch.float32)
+    assert f.numel() * 4 > 2**32
+    W = torch.randn((K, cin, cout), generator=g, device=gpu) * (2.0 / (per_row * cin)) ** 0.5
+    idx = torch.randint(0, num_inp, (v * per_row,), generator=g, device=gpu, dtype=torch.int64)
+    idx[-per_row:] = torch.arange(num_inp - per_row, num_inp, device=gpu)  # the very last rows of the matrix
+    slots = torch.stack([torch.randperm(K, generator=g, device=gpu)[:per_row].sort().values for _ in range(v)]).reshape(-1)
+    rs = torch.arange(0, v * per_row + 1, per_row, device=gpu, dtype=torch.int64)
+    ref = torch.einsum("pc,pco->po", f[idx].double(), W.double()[slots]).reshape(v, per_row, cout).sum(1)
+    ctx = ops.context(gpu)
+    ctx.sconv_variant_counts(reset=True)
+    out = ops.sparse_conv16("bf16x3", ops.pack_filters(W, "bf16x3"), K, cin, cout, f, idx.to(torch.int32),
+                            slots.to(torch.uint8), rs)
+    counts = ctx.sconv_variant_counts()
+    assert len(counts) == 1 and list(counts)[0][6] == 0, counts  # table-driven kernel
+    err = float((out.double() - ref).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err

@@ -133,6 +133,51 @@ __device__ inline void cconv_batch(const float* __restrict__ inp_pos, const floa
     }
 }
 
+// The same batch on the matrix cores (cin == 4): the 64 cells x 4 features of the voxel are one 16 x 16 accumulator
+// tile D[i = cy + 4 cz][j = c + 4 cx] (k = 16 i + j of the cell-major basis), four pairs per v_mfma_f32_16x16x4_f32;
+// lane (n = lane & 15, g = lane >> 4) supplies A = hy(cy) hz(cz) and B = hx(cx) w f_c of pair g (see k_cconv_mfma).
+template <bool SORTED>
+__device__ inline void cconv_batch_mma(const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
+                                       const int32_t* __restrict__ nidx, const float* __restrict__ nimp, i64 p0, int cnt,
+                                       int lane, float ox, float oy, float oz, float sc2, f32x4& D, float& norm_lane,
+                                       float4* s_pair) {
+    const int n = lane & 15, g = lane >> 4;
+    const float a_cy = (float)(n & 3), a_cz = (float)(n >> 2), b_cx = (float)(n >> 2);
+    const int b_c = n & 3;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    float4 F = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < cnt) {
+        const i64 p = p0 + lane;
+        const int32_t i = nidx[p];
+        const float w = nimp ? nimp[p] : 1.f;
+        norm_lane += w;
+        float4 P;
+        if (SORTED) {
+            P = reinterpret_cast<const float4*>(inp_pos)[2 * (i64)i];
+            F = reinterpret_cast<const float4*>(inp_pos)[2 * (i64)i + 1];
+        } else {
+            P = make_float4(inp_pos[3 * (i64)i], inp_pos[3 * (i64)i + 1], inp_pos[3 * (i64)i + 2], 0.f);
+            F = make_float4(inp_feat[4 * (i64)i], inp_feat[4 * (i64)i + 1], inp_feat[4 * (i64)i + 2], inp_feat[4 * (i64)i + 3]);
+        }
+        cconv_pair_coords((P.x - ox) * sc2, (P.y - oy) * sc2, (P.z - oz) * sc2, ux, uy, uz);
+        F = make_float4(w * F.x, w * F.y, w * F.z, w * F.w);
+    }
+    __builtin_amdgcn_wave_barrier();
+    s_pair[2 * lane] = make_float4(ux, uy, uz, 0.f);
+    s_pair[2 * lane + 1] = F;  // zero beyond cnt: those products vanish
+    __builtin_amdgcn_wave_barrier();
+    const float* sp = reinterpret_cast<const float*>(s_pair);
+#pragma unroll 2
+    for (int j = 0; j < cnt; j += 4) {
+        const float4 a = s_pair[2 * (j + g)];
+        const float fc = sp[8 * (j + g) + 4 + b_c];
+        const float wx = fminf(fmaxf(1.f - fabsf(a.x - b_cx), 0.f), 1.f);
+        const float wy = fminf(fmaxf(1.f - fabsf(a.y - a_cy), 0.f), 1.f);
+        const float wz = fminf(fmaxf(1.f - fabsf(a.z - a_cz), 0.f), 1.f);
+        D = __builtin_amdgcn_mfma_f32_16x16x4f32(wy * wz, wx * fc, D, 0, 0, 0);
+    }
+}
+
 // One wave per output voxel, persistent blocks (grid-stride over voxels).  The 4-channel slice
 // of the filter is staged in LDS once per block as [cell][cout][4] (a guarded global load per
 // filter element costs a vmcnt(0) round trip each: 128 per voxel).
@@ -458,15 +503,29 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
         float norm_total = 0.f;
         for (int c0 = 0; c0 < cin; c0 += 4) {
             float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, norm_lane = 0.f;
-            for (i64 p0 = b + 64 * (i64)wave; p0 < e; p0 += 64 * 16)
-                cconv_batch<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, (int)((e - p0) < 64 ? (e - p0) : 64), lane, cin,
-                                    c0, ox, oy, oz, sc2, cxf, cyf, czf, B0, B1, B2, B3, norm_lane, s_pair[wave]);
+            f32x4 D = {0.f, 0.f, 0.f, 0.f};
+            const bool mma = cin == 4;  // the whole path: pair loop on the matrix cores
+            for (i64 p0 = b + 64 * (i64)wave; p0 < e; p0 += 64 * 16) {
+                const int cnt = (int)((e - p0) < 64 ? (e - p0) : 64);
+                if (mma)
+                    cconv_batch_mma<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, cnt, lane, ox, oy, oz, sc2, D, norm_lane,
+                                            s_pair[wave]);
+                else
+                    cconv_batch<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, cnt, lane, cin, c0, ox, oy, oz, sc2, cxf, cyf,
+                                        czf, B0, B1, B2, B3, norm_lane, s_pair[wave]);
+            }
             const float norm = wave_sum_dpp(norm_lane);
             __syncthreads();  // previous chunk's partials consumed
-            s_part[wave][lane][0] = B0;
-            s_part[wave][lane][1] = B1;
-            s_part[wave][lane][2] = B2;
-            s_part[wave][lane][3] = B3;
+            if (mma) {  // D[r] = basis element k = 16 (4 g + r) + n = 4 cell + channel
+                float* flat = &s_part[wave][0][0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) flat[16 * (4 * (lane >> 4) + r) + (lane & 15)] = D[r];
+            } else {
+                s_part[wave][lane][0] = B0;
+                s_part[wave][lane][1] = B1;
+                s_part[wave][lane][2] = B2;
+                s_part[wave][lane][3] = B3;
+            }
             if (lane == 0) s_norm[wave] = norm;
             __syncthreads();
             if (wave == 0) {

@@ -92,6 +92,8 @@ struct GridDev {
 // environment (ASR_SCONV_MIN_BLOCKS, ...) when the context is created, for experiments.
 struct AsrOptions {
     i64 sconv_min_blocks = 2816;  // narrow the column tile until a launch has this many blocks (11 per CU)
+    i64 sconv16_min_blocks = 1024;  // the same for the 16-bit kernels (4 per CU: every column chunk of a tile gathers the
+                                    // features again, and these kernels are bound by the load path on the small grids)
     i64 sconv_wide_min = 2048;    // 8-wave (128-row) blocks when they still give this many blocks
     i64 sconv_dry = 0;            // measurement aid: 1 = prologue + epilogue, 2 = no wave-level slot skip, 3 = prologue
     i64 row_segment = 524288;     // rows are regrouped inside segments of this many consecutive rows

@@ -954,7 +954,7 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
             ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: force_nt must be 1, 2, 4 or 8 and divide the padded width");
         nt = a.force_nt;
     } else {
-        while (nt > 2 && tiles64 * (ctot_pad / (nt * 16)) < ctx->opt.sconv_min_blocks) nt >>= 1;
+        while (nt > 2 && tiles64 * (ctot_pad / (nt * 16)) < ctx->opt.sconv16_min_blocks) nt >>= 1;
     }
     const i64 tiles128 = (a.num_out + 127) / 128;
     bool wide = tiles128 * (ctot_pad / (nt * 16)) >= ctx->opt.sconv_wide_min;

@@ -20,7 +20,7 @@ BENCH_INSTANCES = {
 # k_sconv_plan16, 0 = k_sconv_mfma16)
 BENCH_INSTANCES16 = {
     (4, 32, 0, 8, 1, 2, 1), (4, 32, 0, 8, 0, 2, 1), (8, 32, 0, 8, 1, 2, 1), (8, 32, 0, 8, 0, 2, 1),
-    (4, 32, 0, 4, 1, 2, 1), (4, 32, 0, 4, 0, 2, 1), (2, 32, 0, 4, 1, 2, 1), (2, 32, 0, 4, 0, 2, 1),
+    (8, 32, 0, 4, 1, 2, 1), (8, 32, 0, 4, 0, 2, 1), (2, 32, 0, 4, 1, 2, 1), (2, 32, 0, 4, 0, 2, 1),
     (2, 32, 0, 8, 0, 2, 1),
 }
 

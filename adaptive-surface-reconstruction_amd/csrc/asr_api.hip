@@ -856,7 +856,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             if (!prev.down_idx || !prev.down_kidx || !prev.down_rs)
                 ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
             ASR_TRY(asr_geom_invert(ctx, g.v, prev.up_idx, prev.up_rs, prev.v, prev.up_kidx,
-                                    prev.down_idx, prev.down_rs, prev.down_kidx));
+                                    prev.down_idx, prev.down_rs, prev.down_kidx, prev.v));
             prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
             prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
             if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");

@@ -315,7 +315,7 @@ int asr_geom_dual_count(asr_hip_context* ctx, const u64* nodes, i64 num_nodes, c
 int asr_geom_dual_fill(asr_hip_context* ctx, i64* out);
 int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, const i64* rs,
                     i64 num_rows, const uint8_t* attr, int32_t* out_idx, i64* out_rs,
-                    uint8_t* out_attr);
+                    uint8_t* out_attr, i64 known_pairs = -1);
 void asr_geom_release(asr_hip_context* ctx);
 
 int asr_mesh_contour_count(asr_hip_context* ctx, const float* values, i64 num_values, const i64* duals,

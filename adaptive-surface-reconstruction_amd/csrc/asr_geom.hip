@@ -2044,9 +2044,12 @@ int asr_geom_dual_fill(asr_hip_context* ctx, i64* out) {
 
 int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, const i64* rs,
                     i64 num_rows, const uint8_t* attr, int32_t* out_idx, i64* out_rs,
-                    uint8_t* out_attr) {
-    i64 p = 0;
-    if (num_rows > 0) ASR_TRY(read_i64(ctx, rs + num_rows, &p));
+                    uint8_t* out_attr, i64 known_pairs) {
+    i64 p = known_pairs;  // >= 0: the caller knows rs[num_rows] (no read-back)
+    if (p < 0) {
+        p = 0;
+        if (num_rows > 0) ASR_TRY(read_i64(ctx, rs + num_rows, &p));
+    }
     i64* counts = arena_alloc<i64>(ctx->scratch, num_points + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, (num_points + 1) * sizeof(i64), ctx->stream));

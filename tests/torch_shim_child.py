@@ -78,6 +78,30 @@ def main():
     o, s = mod(t(f), t(idx), t(kidx), t(nimp), t(rs))
     parity.assert_close(o.cpu().numpy(), O.sparse_conv(W, f, idx, kidx, nimp, rs, True))
     parity.assert_close(s.cpu().numpy(), O.reduce_subarrays_sum(nimp, rs))
+
+    # and with no Python in the process at all: csrc/shim_demo (libtorch) loads the op library and an archive whose
+    # module carries its inputs as buffers, runs forward() and writes the result
+    class Closed(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for name, val in (("kernel", t(W)), ("feats", t(f)), ("idx", t(idx)), ("kidx", t(kidx)), ("imp", t(nimp)),
+                              ("rs", t(rs))):
+                self.register_buffer(name, val)
+
+        def forward(self):
+            none = torch.empty(0, device=self.feats.device)
+            return torch.ops.open3d.sparse_conv(self.kernel, self.feats, none, self.idx, self.kidx, self.imp, self.rs,
+                                                True, 64)
+
+    import subprocess
+    demo = os.path.join(os.path.dirname(LIB), "shim_demo")
+    with tempfile.TemporaryDirectory() as d:
+        path, outp = os.path.join(d, "closed.pt"), os.path.join(d, "out.bin")
+        torch.jit.script(Closed()).save(path)
+        r = subprocess.run([demo, LIB, path, outp], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = np.fromfile(outp, np.float32).reshape(v, -1)
+    parity.assert_close(got, O.sparse_conv(W, f, idx, kidx, nimp, rs, True))
     print("SHIM OK")
 
 

@@ -513,8 +513,13 @@ __global__ __launch_bounds__(256) void k_query_levels(asr_octree_frame f, const 
 // boundaries of the sorted code array: cell (prefix,level) starts / ends at i
 template <bool COUNT_ONLY>
 __global__ __launch_bounds__(256) void k_cell_bounds(const u64* codes, i64 n, int lmin, int lmax, HashTab t,
-                                                     int32_t* start, int32_t* end, int* cnt) {
+                                                     int32_t* start, int32_t* end, int* cnt, int* level_cnt) {
     __shared__ int s_sum[4];
+    __shared__ int s_lvl[ASR_MAX_LEVEL + 1];  // COUNT_ONLY: cells per level (the host picks the hashed levels)
+    if (COUNT_ONLY) {
+        if (threadIdx.x <= ASR_MAX_LEVEL) s_lvl[threadIdx.x] = 0;
+        __syncthreads();
+    }
     int local = 0;
     for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i <= n; i += (i64)gridDim.x * blockDim.x) {
         u64 a = i > 0 ? codes[i - 1] : 0, b = i < n ? codes[i] : 0;
@@ -525,7 +530,10 @@ __global__ __launch_bounds__(256) void k_cell_bounds(const u64* codes, i64 n, in
             if (has_a && has_b && pa == pb) continue;
             u64 marker = u64(1) << (3 * l);
             if (COUNT_ONLY) {
-                if (has_b) ++local;
+                if (has_b) {
+                    ++local;
+                    atomicAdd(&s_lvl[l], 1);
+                }
             } else {
                 u64 slot;
                 if (has_a) {
@@ -549,6 +557,7 @@ __global__ __launch_bounds__(256) void k_cell_bounds(const u64* codes, i64 n, in
         if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = local;
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(&cnt[8], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        if (level_cnt && threadIdx.x <= ASR_MAX_LEVEL && s_lvl[threadIdx.x]) atomicAdd(&level_cnt[threadIdx.x], s_lvl[threadIdx.x]);
     }
 }
 
@@ -577,9 +586,51 @@ constexpr int RADIUS_SPLIT = 64;
 
 // lanes 0..26 look up the 3^3 cells around the query; returns the candidate total, fills the
 // per-wave prefix / begin tables
-__device__ inline int radius_cells(const asr_octree_frame& f, const HashTab& t, const int32_t* start,
-                                   const int32_t* end, float cx, float cy, float cz, float r, int lane,
-                                   int* s_pref, int* s_beg) {
+// Point ranges of cells.  Levels up to `lhash` are in the hash table; finer levels -- where a cloud with very dense
+// spots would put nearly every point into a cell of its own, ten million entries per level -- are looked up by two
+// binary searches in the Morton-sorted level-21 codes (the points of a cell are contiguous in that order).
+struct CellIndex {
+    HashTab tab;
+    const int32_t* start;
+    const int32_t* end;
+    const u64* codes;  // sorted (on the bits of the finest indexed level)
+    int n;
+    int lhash;
+};
+__device__ inline void cell_range(const CellIndex& ci, u64 cell, int lev, int& b, int& cnt) {
+    b = 0;
+    cnt = 0;
+    if (lev <= ci.lhash) {
+        const i64 slot = tab_find_slot(ci.tab, cell | (u64(1) << (3 * lev)));
+        if (slot >= 0) {
+            b = ci.start[slot];
+            cnt = ci.end[slot] - b;
+        }
+        return;
+    }
+    const int s = 3 * (ASR_MAX_LEVEL - lev);
+    int lo = 0, hi = ci.n;  // first point whose level-`lev` cell is >= cell
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((ci.codes[mid] >> s) < cell)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    int lo2 = lo, hi2 = ci.n;  // first point whose cell is > cell
+    while (lo2 < hi2) {
+        const int mid = (lo2 + hi2) >> 1;
+        if ((ci.codes[mid] >> s) <= cell)
+            lo2 = mid + 1;
+        else
+            hi2 = mid;
+    }
+    b = lo;
+    cnt = lo2 - lo;
+}
+
+__device__ inline int radius_cells(const asr_octree_frame& f, const CellIndex& ci, float cx, float cy, float cz,
+                                   float r, int lane, int* s_pref, int* s_beg) {
     const int lev = query_level(f, r);
     int x, y, z;
     frame_coord(f, cx, cy, cz, lev, x, y, z);
@@ -587,13 +638,8 @@ __device__ inline int radius_cells(const asr_octree_frame& f, const HashTab& t, 
     int b = 0, n = 0;
     if (lane < 27) {
         int xx = x + lane % 3 - 1, yy = y + (lane / 3) % 3 - 1, zz = z + lane / 9 - 1;
-        if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim) {
-            i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | (u64(1) << (3 * lev)));
-            if (slot >= 0) {
-                b = start[slot];
-                n = end[slot] - b;
-            }
-        }
+        if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
+            cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b, n);
     }
     int pre = n;  // inclusive prefix of n over lanes 0..26
 #pragma unroll
@@ -629,8 +675,7 @@ __device__ inline float4 radius_candidate(const float4* sorted, const int* s_pre
 template <int MODE>
 __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
                                                       const float* centers, const float* sizes,
-                                                      i64 v, HashTab t, const int32_t* start,
-                                                      const int32_t* end, i64* counts, u64* tmp,
+                                                      i64 v, CellIndex ci, i64* counts, u64* tmp,
                                                       int32_t* heavy_out, int* heavy_cnt,
                                                       uint8_t* is_heavy) {
     __shared__ int s_pref[4][28];
@@ -644,7 +689,7 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
     const float r = sizes[q];
     const float r2 = r * r;
-    const int total = radius_cells(f, t, start, end, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
+    const int total = radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
     i64 found = 0;
     bool heavy = MODE == 2 && total > RADIUS_GIANT;
     for (int i0 = 0; i0 < total && !heavy; i0 += 64) {
@@ -713,9 +758,9 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
 // keys at hoff[j] + cursor (any order: the rows are sorted by a segmented sort afterwards).
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const float4* sorted, const float* centers,
-                                                      const float* sizes, const int32_t* heavy, HashTab t,
-                                                      const int32_t* start, const int32_t* end, i64* counts,
-                                                      const i64* hoff, int* cursor, u64* keys_out, int32_t* row_out) {
+                                                      const float* sizes, const int32_t* heavy, CellIndex ci,
+                                                      i64* counts, const i64* hoff, int* cursor, u64* keys_out,
+                                                      int32_t* row_out) {
     __shared__ int s_pref[4][28];
     __shared__ int s_beg[4][28];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -724,7 +769,7 @@ __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const 
     const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
     const float r = sizes[q];
     const float r2 = r * r;
-    const int total = radius_cells(f, t, start, end, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
+    const int total = radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
     int per = (total + RADIUS_SPLIT - 1) / RADIUS_SPLIT;
     per = (per + 255) & ~255;  // whole 4-wave rounds
     const int lo = blockIdx.y * per;
@@ -1715,6 +1760,8 @@ struct RadiusState {
     int32_t* ids = nullptr;    // original index of the point at each Morton position
     int32_t* rank = nullptr;   // inverse of ids (only when the caller asked for it)
     const u64* codes = nullptr;  // sorted level-21 codes (scratch arena: valid until the next reset)
+    int lhash = ASR_MAX_LEVEL;   // finest level in the hash table (finer ones: binary search in codes)
+    CellIndex index() const { return {tab, start, end, codes, (int)n, lhash}; }
     HashTab tab;
     int32_t* start = nullptr;
     int32_t* end = nullptr;
@@ -1741,7 +1788,7 @@ void asr_geom_release(asr_hip_context* ctx) {
 // arena when null.  `want_rank`: also build the original index -> Morton position table.
 static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                              i64 n, int lmin, int lmax, RadiusState& st, Arena* keep = nullptr,
-                             bool want_rank = false) {
+                             bool want_rank = false, bool hash_all = true) {
     int host[16];
     st.frame = *frame;
     st.n = n;
@@ -1768,21 +1815,37 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
         ASR_CHECK_LAUNCH(ctx);
     }
     HashTab dummy{nullptr, nullptr, 0};
+    int* level_cnt = ctx->d_flags + 32;  // cells per level
+    int host_lvl[ASR_MAX_LEVEL + 1] = {0};
     if (n > 0) {
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(level_cnt, 0, (ASR_MAX_LEVEL + 1) * sizeof(int), ctx->stream));
         k_cell_bounds<true><<<std::min<unsigned>(grid_for(n + 1, BLK), 4096u), BLK, 0, ctx->stream>>>(
-                codes, n, lmin, lmax, dummy, nullptr, nullptr, ctx->d_flags);
+                codes, n, lmin, lmax, dummy, nullptr, nullptr, ctx->d_flags, level_cnt);
         ASR_CHECK_LAUNCH(ctx);
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(host_lvl, level_cnt, sizeof(host_lvl), hipMemcpyDeviceToHost, ctx->stream));
     }
     ASR_TRY(read_flags(ctx, host));
     if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "points contain non-finite values");
-    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * (i64)host[8]));
+    // Levels whose cells hold fewer than four points on average stay out of the hash table (a cloud with very dense
+    // spots has query levels at which every point is a cell: 10^7 insertions per level); they are served by binary
+    // search (cell_range).  Option search_hash_level forces the finest hashed level (tests).
+    int lhash = lmax;
+    if (!hash_all) {
+        lhash = lmin;
+        while (lhash < lmax && (i64)host_lvl[lhash + 1] * 4 <= n) ++lhash;
+        if (ctx->opt.search_hash_level >= 0) lhash = (int)std::min<i64>(lmax, std::max<i64>(lmin - 1, ctx->opt.search_hash_level));
+    }
+    st.lhash = lhash;
+    i64 cells = 0;
+    for (int l = lmin; l <= lhash; ++l) cells += host_lvl[l];
+    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * cells));
     ASR_TRY(make_table(ctx, ctx->scratch, cap, false, st.tab));
     st.start = arena_alloc<int32_t>(ctx->scratch, cap);
     st.end = arena_alloc<int32_t>(ctx->scratch, cap);
     if (!st.start || !st.end) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     if (n > 0) {
         k_cell_bounds<false><<<grid_for(n + 1, BLK), BLK, 0, ctx->stream>>>(
-                codes, n, lmin, lmax, st.tab, st.start, st.end, ctx->d_flags);
+                codes, n, lmin, lhash, st.tab, st.start, st.end, ctx->d_flags, nullptr);
         ASR_CHECK_LAUNCH(ctx);
     }
     return ASR_HIP_OK;
@@ -1819,7 +1882,7 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     st.v = v;
     int lmin, lmax;
     ASR_TRY(query_level_range(ctx, frame, sizes, v, &lmin, &lmax));
-    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st, keep, true));
+    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st, keep, true, false));
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     st.tmp = arena_alloc<u64>(ctx->scratch, (size_t)v * RADIUS_LIGHT);
     st.heavy = arena_alloc<int32_t>(ctx->scratch, v);
@@ -1827,17 +1890,16 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     if (!counts || !st.tmp || !st.heavy || !st.is_heavy) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 10, 0, sizeof(int), ctx->stream));
     // one pass: counts, the sorted light rows (fixed slots) and the list of heavy rows
-    k_radius_query<2><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.tab,
-                                                                    st.start, st.end, counts, st.tmp, st.heavy,
-                                                                    ctx->d_flags + 10, st.is_heavy);
+    k_radius_query<2><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(),
+                                                                    counts, st.tmp, st.heavy, ctx->d_flags + 10,
+                                                                    st.is_heavy);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(read_flags(ctx, host));
     if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search cell table overflow");
     st.num_heavy = host[10];
     if (st.num_heavy > 0) {
         k_radius_heavy<false><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                *frame, st.sorted, centers, sizes, st.heavy, st.tab, st.start, st.end, counts, nullptr, nullptr,
-                nullptr, nullptr);
+                *frame, st.sorted, centers, sizes, st.heavy, st.index(), counts, nullptr, nullptr, nullptr, nullptr);
         ASR_CHECK_LAUNCH(ctx);
     }
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
@@ -1856,11 +1918,11 @@ int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame*
     RadiusState st;
     int host[16], lmin, lmax;
     ASR_TRY(query_level_range(ctx, frame, radii, n, &lmin, &lmax));
-    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st));
+    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st, nullptr, false, false));
     i64* counts = arena_alloc<i64>(ctx->scratch, n + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     k_radius_query<0><<<grid_for(n + 1, 4), BLK, 0, ctx->stream>>>(
-            *frame, st.sorted, pts, radii, n, st.tab, st.start, st.end, counts, nullptr, nullptr, nullptr, nullptr);
+            *frame, st.sorted, pts, radii, n, st.index(), counts, nullptr, nullptr, nullptr, nullptr);
     ASR_CHECK_LAUNCH(ctx);
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, counts, n * sizeof(i64), hipMemcpyDeviceToDevice,
                                       ctx->stream));
@@ -1972,8 +2034,7 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         if (!cursor) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemsetAsync(cursor, 0, (size_t)nh * sizeof(int), ctx->stream));
         k_radius_heavy<true><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                st.frame, st.sorted, centers, sizes, st.heavy, st.tab, st.start, st.end, nullptr, hoff, cursor, k_u,
-                t_row);
+                st.frame, st.sorted, centers, sizes, st.heavy, st.index(), nullptr, hoff, cursor, k_u, t_row);
         ASR_CHECK_LAUNCH(ctx);
         // order by (row, squared distance, index) with two stable radix sorts: by the 64-bit key, then
         // by the row (a segmented sort spends 1.6 ms on the few 10^4-entry rows)

@@ -9,7 +9,7 @@ from asr_hip.pipeline import ImplicitPipeline
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 overlap = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = torch.device("cuda:0")
-pts, nrm = synth.scan_cloud(n, seed=1000, device=dev)
+pts, nrm = synth.scan_cloud(n, seed=1000, device=dev, density_variance=float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
 radii = synth.knn_radii_gpu(pts, 24)
 bb = synth.bounding_box(pts, 0.1)
 pipe = ImplicitPipeline(synth.make_weights(4, seed=0), device=dev, precision="bf16x3")

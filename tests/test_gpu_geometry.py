@@ -93,11 +93,19 @@ def test_grid_hierarchy_bit_exact(case, gpu):
             keys = nxt
 
 
-def test_multi_radius_search(case, gpu):
+@pytest.mark.parametrize("hash_level", [-1, 0, 8], ids=["auto", "binary-search", "hash-to-8"])
+def test_multi_radius_search(case, gpu, hash_level):
+    """hash_level: finest level of the search's cell hash table; finer query levels find their cells by binary search in
+    the Morton-sorted codes (auto: levels whose cells hold fewer than four points; 0: every level)"""
     g = case["grids"][0]
-    idx, dist, rs, compat = case["ops"].multi_radius_search(
-        case["frame"], case["tpts"], case["trad"], torch.from_numpy(g["voxel_centers"]).to(gpu),
-        torch.from_numpy(g["voxel_sizes"]).to(gpu))
+    ctx = case["ops"].context(gpu)
+    ctx.set_option("search_hash_level", hash_level)
+    try:
+        idx, dist, rs, compat = case["ops"].multi_radius_search(
+            case["frame"], case["tpts"], case["trad"], torch.from_numpy(g["voxel_centers"]).to(gpu),
+            torch.from_numpy(g["voxel_sizes"]).to(gpu))
+    finally:
+        ctx.set_option("search_hash_level", -1)
     o_idx, o_dist, o_rs, o_compat = case["o"].radius_search(case["pts"], case["rad"],
                                                             g["voxel_centers"], g["voxel_sizes"])
     assert np.array_equal(rs.cpu().numpy(), o_rs)

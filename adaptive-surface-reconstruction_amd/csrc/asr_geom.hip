@@ -1126,6 +1126,8 @@ __global__ __launch_bounds__(256) void k_cell_list(const u64* codes, i64 n, int 
         if (flags & (1u << j)) list[o++] = (int32_t)(base + j * 256 + threadIdx.x);
 }
 
+constexpr int KNN_CELL_MAX_POINTS = 128;       // queries of one cell (two passes of a wave)
+constexpr int KNN_CELL_MAX_CANDIDATES = 4096;  // points of its 3^3 block
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_cells(asr_octree_frame f, const float4* sorted, i64 n, HashTab t,
                                                    const int32_t* start, const int32_t* end, int lfine, int k,
@@ -1172,6 +1174,12 @@ __global__ __launch_bounds__(256) void k_knn_cells(asr_octree_frame f, const flo
     __builtin_amdgcn_wave_barrier();
     const float cs = f.voxel_size[lfine];
     const float cs2 = cs * cs;
+    // Crowded cells go to the wave-per-point kernel: this wave would walk points x candidates alone (a dense spot of
+    // 10^5 points in one cell: 10^10 distance evaluations on one SIMD; such a cloud took 312 s before this line).
+    if (total < k || qn > KNN_CELL_MAX_POINTS || total > KNN_CELL_MAX_CANDIDATES) {
+        for (int q0 = lane; q0 < qn; q0 += 64) fallback[atomicAdd(fallback_cnt, 1)] = qb + q0;
+        return;
+    }
     for (int q0 = 0; q0 < qn; q0 += 64) {
         const bool active = q0 + lane < qn;
         const float4 me = sorted[qb + (active ? q0 + lane : 0)];

@@ -351,6 +351,7 @@ def test_knn_radius_cell_path_equals_the_wave_path():
     rng = np.random.default_rng(3)
     pts[:2000] = pts[2000:4000]                                   # duplicates
     pts[4000:4200] = rng.uniform(-3, 3, size=(200, 3))            # isolated points far from the surface
+    pts[10000:40000] = pts[9000] + rng.normal(0, 2e-5, size=(30000, 3)).astype(np.float32)  # a dense spot: one crowded cell
     d = torch.from_numpy(pts).to(dev)
     ctx = ops.context(dev)
     try:

@@ -1126,8 +1126,7 @@ __global__ __launch_bounds__(256) void k_cell_list(const u64* codes, i64 n, int 
         if (flags & (1u << j)) list[o++] = (int32_t)(base + j * 256 + threadIdx.x);
 }
 
-constexpr int KNN_CELL_MAX_POINTS = 128;       // queries of one cell (two passes of a wave)
-constexpr int KNN_CELL_MAX_CANDIDATES = 4096;  // points of its 3^3 block
+constexpr int KNN_CELL_MAX_WORK = 12288;  // passes of 64 queries x candidates of the 3^3 block a wave may take on (~0.5 ms)
 template <int K>
 __global__ __launch_bounds__(256) void k_knn_cells(asr_octree_frame f, const float4* sorted, i64 n, HashTab t,
                                                    const int32_t* start, const int32_t* end, int lfine, int k,
@@ -1176,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_knn_cells(asr_octree_frame f, const flo
     const float cs2 = cs * cs;
     // Crowded cells go to the wave-per-point kernel: this wave would walk points x candidates alone (a dense spot of
     // 10^5 points in one cell: 10^10 distance evaluations on one SIMD; such a cloud took 312 s before this line).
-    if (total < k || qn > KNN_CELL_MAX_POINTS || total > KNN_CELL_MAX_CANDIDATES) {
+    if (total < k || (i64)((qn + 63) / 64) * total > KNN_CELL_MAX_WORK) {
         for (int q0 = lane; q0 < qn; q0 += 64) fallback[atomicAdd(fallback_cnt, 1)] = qb + q0;
         return;
     }
@@ -1834,13 +1833,13 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     }
     ASR_TRY(read_flags(ctx, host));
     if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "points contain non-finite values");
-    // Levels whose cells hold fewer than four points on average stay out of the hash table (a cloud with very dense
+    // Levels whose cells hold fewer than two points on average stay out of the hash table (a cloud with very dense
     // spots has query levels at which every point is a cell: 10^7 insertions per level); they are served by binary
     // search (cell_range).  Option search_hash_level forces the finest hashed level (tests).
     int lhash = lmax;
     if (!hash_all) {
         lhash = lmin;
-        while (lhash < lmax && (i64)host_lvl[lhash + 1] * 4 <= n) ++lhash;
+        while (lhash < lmax && (i64)host_lvl[lhash + 1] * 2 <= n) ++lhash;
         if (ctx->opt.search_hash_level >= 0) lhash = (int)std::min<i64>(lmax, std::max<i64>(lmin - 1, ctx->opt.search_hash_level));
     }
     st.lhash = lhash;

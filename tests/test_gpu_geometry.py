@@ -96,7 +96,7 @@ def test_grid_hierarchy_bit_exact(case, gpu):
 @pytest.mark.parametrize("hash_level", [-1, 0, 8], ids=["auto", "binary-search", "hash-to-8"])
 def test_multi_radius_search(case, gpu, hash_level):
     """hash_level: finest level of the search's cell hash table; finer query levels find their cells by binary search in
-    the Morton-sorted codes (auto: levels whose cells hold fewer than four points; 0: every level)"""
+    the Morton-sorted codes (auto: levels whose cells hold fewer than two points; 0: every level)"""
     g = case["grids"][0]
     ctx = case["ops"].context(gpu)
     ctx.set_option("search_hash_level", hash_level)

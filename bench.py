@@ -126,13 +126,19 @@ def cpu_baseline(n_sample, seed):
                       (n_sample, dt, {k: round(v, 2) for k, v in timings.items()})}
 
 
-def exact_f32_run(weights, dev, inputs, n, steps, shapes):
+def exact_f32_run(weights, dev, inputs, n, steps, shapes, values=None):
     """Outside the timed region and not part of `value`: the same cloud through the f32-input MFMA kernel
-    (v_mfma_f32_16x16x4_f32, a bit-exact fmaf chain) -- the round-1 arithmetic, for comparison."""
+    (v_mfma_f32_16x16x4_f32, a bit-exact fmaf chain) -- the round-1 arithmetic, for comparison; `values`: the timed
+    run's result, whose largest deviation from this kernel's is reported relative to the range of the values."""
     from asr_hip.pipeline import ImplicitPipeline
     pipe = ImplicitPipeline(weights, device=dev, precision="f32")
-    pipe.forward(*inputs)
+    ref = pipe.forward(*inputs)
     torch.cuda.synchronize()
+    dev_rel = None
+    if values is not None and values.shape == ref.shape:
+        scale = float(ref.abs().max())
+        dev_rel = {"max_abs_deviation": float((values.double() - ref.double()).abs().max()), "range_of_values": scale}
+        dev_rel["deviation_over_range"] = dev_rel["max_abs_deviation"] / scale if scale > 0 else None
     unet = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -143,7 +149,8 @@ def exact_f32_run(weights, dev, inputs, n, steps, shapes):
     flops, launches = conv_flops(pipe.sizes, shapes)
     tf = flops / (unet / steps * 1e-3) / 1e12
     return {"ms_per_step": dt / steps * 1e3, "points_per_s": n * steps / dt, "unet_ms": unet / steps,
-            "kernel": "k_sconv_mfma", "achieved_tflops": tf, "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS}
+            "kernel": "k_sconv_mfma", "achieved_tflops": tf, "frac_of_f32_mfma_peak": tf / MFMA_F32_PEAK_TFLOPS,
+            "timed_values_vs_this_kernel": dev_rel}
 
 
 def mesh_stage(pipe, synth):
@@ -317,6 +324,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world, dev)
     assert values.shape[0] == pipe.sizes.num_voxels[0] and bool(torch.isfinite(values).all())
+    values_timed = values.clone()  # `values` lives in the context arena until the next forward
     if one_scan:
         if rank == 0:
             print(json.dumps(one_scan_line(args, world, n, dt, sharded)))
@@ -338,7 +346,8 @@ def main():
     t_knn2 = time.perf_counter() - t_knn2
     exact = None
     if world == 1 and args.precision == "bf16x3" and not args.no_exact_f32:
-        exact = exact_f32_run(weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(args.steps, 2), shapes)
+        exact = exact_f32_run(weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(args.steps, 2), shapes,
+                              values_timed)
     if rank == 0:
         steps = max(args.steps, 1)
         ms = dt / steps * 1e3

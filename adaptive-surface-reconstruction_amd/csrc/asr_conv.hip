@@ -167,7 +167,6 @@ __device__ inline void cconv_batch_mma(const float* __restrict__ inp_pos, const 
     s_pair[2 * lane + 1] = F;  // zero beyond cnt: those products vanish
     __builtin_amdgcn_wave_barrier();
     const float* sp = reinterpret_cast<const float*>(s_pair);
-#pragma unroll 2
     for (int j = 0; j < cnt; j += 4) {
         const float4 a = s_pair[2 * (j + g)];
         const float fc = sp[8 * (j + g) + 4 + b_c];
@@ -406,7 +405,6 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
                     s_pair[wib][2 * lane + 1] = make_float4(w * F.x, w * F.y, w * F.z, w * F.w);
                     __builtin_amdgcn_wave_barrier();
                     const float* sp = reinterpret_cast<const float*>(&s_pair[wib][0]);
-#pragma unroll 2
                     for (int j = 0; j < cnt; j += 4) {
                         const float4 a = s_pair[wib][2 * (j + g)];
                         const float fc = sp[8 * (j + g) + 4 + b_c];

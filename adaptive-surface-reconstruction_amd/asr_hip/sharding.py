@@ -276,13 +276,50 @@ class ShardedNetwork:
 
 # ---- GPU backend: the C ABI through asr_hip.ops --------------------------------------------------------
 class HipBackend:
-    def __init__(self, device):
+    """precision "f32": the exact f32 MFMA kernel; "bf16x3": the plan-driven 16-bit kernel (fp32-class).  Either way a
+    row is computed by the same kernel arithmetic as on one GPU, so sharded results equal the unsharded pipeline of the
+    same precision bit for bit."""
+
+    def __init__(self, device, precision="f32"):
+        if precision not in ("f32", "bf16x3"):
+            raise ValueError("HipBackend: precision must be 'f32' or 'bf16x3'")
         self.device = torch.device(device)
+        self.precision = precision
+        self._packed = {}   # weight tensors (by identity) -> packed 16-bit copy; kept across forwards
+        self._plans = {}    # (row splits, row list) -> (int32 row list, ConvPlan); one geometry
+        self._keep = []
+
+    def new_geometry(self):
+        """the neighbour lists changed: plans of the previous geometry are dropped"""
+        self._plans.clear()
+
+    def _pack(self, kernel, kernel_b=None):
+        from . import ops
+        key = (id(kernel), id(kernel_b))
+        if key not in self._packed:
+            self._keep.append((kernel, kernel_b))  # identities stay unique while cached
+            self._packed[key] = ops.pack_filters(kernel, "bf16x3", kernel_b)
+        return self._packed[key]
+
+    def _plan(self, K, csr, rows):
+        from . import ops
+        idx, kidx, rs = csr
+        key = (rs.data_ptr(), rows.data_ptr(), int(rows.numel()))
+        if key not in self._plans:
+            perm = rows.to(torch.int32).contiguous()
+            self._plans[key] = (perm, ops.ConvPlan(K, idx, kidx, rs, row_perm=perm, num_rows=rows.numel()), rows)
+        return self._plans[key][:2]
 
     def sparse_conv(self, kernel, bias, x, csr, rows, v_out, imp=None, normalize=False, residual=None):
         from . import ops
         idx, kidx, rs = csr
         out = torch.zeros((v_out, kernel.shape[2]), dtype=torch.float32, device=self.device)
+        if self.precision == "bf16x3" and x.shape[1] % 4 == 0:
+            perm, plan = self._plan(kernel.shape[0], csr, rows)
+            return ops.sparse_conv16("bf16x3", self._pack(kernel), kernel.shape[0], kernel.shape[1], kernel.shape[2], x,
+                                     idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias, relu=True,
+                                     residual=residual, out=out, return_importance=imp is not None, row_perm=perm,
+                                     num_rows=rows.numel(), plan=plan)
         return ops.sparse_conv(kernel, x, idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias,
                                relu=True, residual=residual, out=out, return_importance=imp is not None,
                                row_perm=rows.to(torch.int32), num_rows=rows.numel())
@@ -293,10 +330,17 @@ class HipBackend:
         idx, kidx, rs = csr
         ca, cb = ka.shape[2], kb.shape[2]
         out = torch.zeros((v_out, ca + cb), dtype=torch.float32, device=self.device)
-        perm = rows.to(torch.int32)
-        if ca % 16 == 8 and cb == 8 and x.shape[1] % 4 == 0:
+        fused = ca % 16 == 8 and cb == 8 and x.shape[1] % 4 == 0
+        if fused and self.precision == "bf16x3":
+            perm, plan = self._plan(ka.shape[0], csr, rows)
+            _, oimp = ops.sparse_conv16("bf16x3", self._pack(ka, kb), ka.shape[0], ka.shape[1], ca, x, idx, kidx, rs,
+                                        inp_importance=imp, normalize=True, bias=ba, relu=True, out=out,
+                                        return_importance=True, row_perm=perm, num_rows=rows.numel(), cout_b=cb,
+                                        bias_b=bb, plan=plan)
+            return out, oimp
+        if fused:
             _, oimp = ops.sparse_conv(ka, x, idx, kidx, rs, inp_importance=imp, normalize=True, bias=ba, relu=True,
-                                      out=out, return_importance=True, algo=2, row_perm=perm,
+                                      out=out, return_importance=True, algo=2, row_perm=rows.to(torch.int32),
                                       num_rows=rows.numel(), filters_b=kb, bias_b=bb)
             return out, oimp
         a = self.sparse_conv(ka, ba, x, csr, rows, v_out)
@@ -342,10 +386,12 @@ class ShardedImplicitPipeline:
     """points / normals / radii (replicated on every rank) -> values[V0, 2] with the network half sharded
     over the ranks of `group`; same call signature as ImplicitPipeline.forward."""
 
-    def __init__(self, weights, device, group=None, point_radius_scale=1.0, octree_max_depth=21, scale_sdf=True):
+    def __init__(self, weights, device, group=None, point_radius_scale=1.0, octree_max_depth=21, scale_sdf=True,
+                 precision="f32"):
         from .pipeline import ImplicitPipeline
         self.pipe = ImplicitPipeline(weights, device=device, point_radius_scale=point_radius_scale,
                                      octree_max_depth=octree_max_depth, scale_sdf=scale_sdf)
+        self.backend = HipBackend(self.pipe.device, precision)
         self.pipe.ctx.set_option("build_search", 0)  # each rank searches only the rows it owns
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -357,6 +403,7 @@ class ShardedImplicitPipeline:
         pipe = self.pipe
         pipe.build(points, radii, bb_min, bb_max)
         geom = geometry_from_pipeline(pipe)
-        self.net = ShardedNetwork(HipBackend(pipe.device), geom, pipe._weights, self.rank, self.world, self.group)
+        self.backend.new_geometry()
+        self.net = ShardedNetwork(self.backend, geom, pipe._weights, self.rank, self.world, self.group)
         values, rows = self.net.forward(points, normals, radii, _lib.frame_init(bb_min, bb_max), pipe.scale_sdf)
         return self.net.stitch(values, rows)

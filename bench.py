@@ -293,7 +293,7 @@ def main():
     weights = synth.make_weights(1, seed=0, init="reference")  # released weights are not in the repo
     if one_scan:
         from asr_hip.sharding import ShardedImplicitPipeline
-        sharded = ShardedImplicitPipeline(weights, dev)
+        sharded = ShardedImplicitPipeline(weights, dev, precision="bf16x3" if args.precision == "bf16x3" else "f32")
         pipe = sharded.pipe
     else:
         pipe = ImplicitPipeline(weights, device=dev, precision=args.precision)

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_points, channel_div, out):
+def _worker(rank, world, port, n_points, channel_div, precision, out):
     sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd"), os.path.join(REPO, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -38,11 +38,11 @@ def _worker(rank, world, port, n_points, channel_div, out):
     rad = synth.knn_radii_gpu(pts, 24)
     bb = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(channel_div, seed=6)
-    sp = sharding.ShardedImplicitPipeline(weights, dev)
+    sp = sharding.ShardedImplicitPipeline(weights, dev, precision=precision)
     full = sp.forward(pts, nrm, rad, bb[0], bb[1])
     info = {"rank": rank, "owned": [int(r.numel()) for r in sp.net.rows], "halo": sp.net.halo_rows()}
     if rank == 0:
-        single = ImplicitPipeline(weights, device=dev).forward(pts, nrm, rad, bb[0], bb[1])
+        single = ImplicitPipeline(weights, device=dev, precision=precision).forward(pts, nrm, rad, bb[0], bb[1])
         info["equal"] = bool(torch.equal(full, single))
         info["max_abs_diff"] = float((full - single).abs().max())
         info["v0"] = int(single.shape[0])
@@ -51,12 +51,16 @@ def _worker(rank, world, port, n_points, channel_div, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_points,channel_div", [(2, 30000, 2), (3, 8000, 1)])
-def test_sharded_values_equal_single_process(gpu, world, n_points, channel_div):
+@pytest.mark.parametrize("world,n_points,channel_div,precision",
+                         [(2, 30000, 2, "f32"), (3, 8000, 1, "f32"), (2, 30000, 1, "bf16x3"), (3, 8000, 2, "bf16x3")])
+def test_sharded_values_equal_single_process(gpu, world, n_points, channel_div, precision):
+    """precision: the arithmetic of the 53 sparse convs on both sides (exact f32 MFMA / plan-driven bf16x3 kernel with a
+    plan per rank's row list): per row the same kernel arithmetic, so the stitched values are bit-identical either way"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_points, channel_div, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_points, channel_div, precision, out))
+             for r in range(world)]
     for p in procs:
         p.start()
     infos = sorted([out.get(timeout=900) for _ in range(world)], key=lambda d: d["rank"])

@@ -39,6 +39,7 @@ const OptEntry k_options[] = {
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
         {"sconv16_min_blocks", "ASR_SCONV16_MIN_BLOCKS", &AsrOptions::sconv16_min_blocks},
         {"knn_cells", "ASR_KNN_CELLS", &AsrOptions::knn_cells},
+        {"knn_deep", "ASR_KNN_DEEP", &AsrOptions::knn_deep},
         {"search_hash_level", "ASR_SEARCH_HASH_LEVEL", &AsrOptions::search_hash_level},
         {"overlap", "ASR_OVERLAP", &AsrOptions::overlap},
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},

@@ -98,6 +98,7 @@ struct AsrOptions {
     i64 sconv_dry = 0;            // measurement aid: 1 = prologue + epilogue, 2 = no wave-level slot skip, 3 = prologue
     i64 row_segment = 524288;     // rows are regrouped inside segments of this many consecutive rows
     i64 search_hash_level = -1;   // >= 0: finest level of the search's cell hash table (finer: binary search); tests
+    i64 knn_deep = 1;             // kNN radius: finer start levels for the points of crowded cells (0: off)
     i64 knn_cells = 1;            // kNN radius: cell-parallel fast path (0: wave per point only)
     i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment

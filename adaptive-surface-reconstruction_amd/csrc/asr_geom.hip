@@ -858,9 +858,9 @@ __global__ void k_radius_unpack_heavy(const u64* keys, const int32_t* hrow, i64 
 // d_k <= (cell size)^2, because every point closer than one cell size lies inside the 3^3 block.
 // Selection: binary search on the bit pattern of the (non-negative) squared distances with wave
 // ballots; up to 512 candidates are held in registers, larger sets are streamed from memory.
-__global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* sorted, i64 n, HashTab t,
-                                             const int32_t* start, const int32_t* end, int lfine, int k,
-                                             const float* radii_in, float radius_fraction,
+constexpr int KNN_CROWD = 1024;  // points of a finest-level cell above which a point starts its search on a finer level
+__global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* sorted, i64 n, CellIndex ci, int lfine,
+                                             int ldeep, int k, const float* radii_in, float radius_fraction,
                                              int outlier_threshold, float* radii_out,
                                              uint8_t* inlier_out, const int32_t* list, i64 nlist) {
     constexpr int CMAX = 8;
@@ -878,9 +878,29 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
     u32 kth_bits = 0;
     u32 bound_bits = 0x7f800000u;  // upper bound of the answer (+inf until a level has been evaluated)
     int total = 0;
-    for (int lev = lfine; lev >= 0; --lev) {
+    // Start level: the finest table level, or -- for a point in a crowded cell of a cloud with dense spots (ldeep >
+    // lfine: the codes are sorted that deep) -- the level at which its own cell holds at most KNN_CROWD points; cells
+    // below the table's finest level are found by binary search in the sorted codes (cell_range).
+    int lev0 = lfine;
+    if (ldeep > lfine) {
+        const u64 code = ci.codes[s];
+        int b0, pop;
+        cell_range(ci, code >> (3 * (ASR_MAX_LEVEL - lfine)), lfine, b0, pop);
+        while (pop > KNN_CROWD && lev0 < ldeep) {
+            ++lev0;
+            cell_range(ci, code >> (3 * (ASR_MAX_LEVEL - lev0)), lev0, b0, pop);
+        }
+    }
+    for (int lev = lev0; lev >= 0; --lev) {
         int x, y, z;
-        frame_coord(f, me.x, me.y, me.z, lev, x, y, z);
+        if (lev > lfine) {  // the point's cell as the sorted codes have it
+            const u64 cell = ci.codes[s] >> (3 * (ASR_MAX_LEVEL - lev));
+            x = (int)asr_compact21(cell);
+            y = (int)asr_compact21(cell >> 1);
+            z = (int)asr_compact21(cell >> 2);
+        } else {
+            frame_coord(f, me.x, me.y, me.z, lev, x, y, z);
+        }
         const int lim = (1 << lev) - 1;
         x = min(max(x, 0), lim);  // points outside the root cube were clamped into it
         y = min(max(y, 0), lim);
@@ -888,13 +908,8 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
         int b = 0, cnt = 0;
         if (lane < 27) {
             int xx = x + lane % 3 - 1, yy = y + (lane / 3) % 3 - 1, zz = z + lane / 9 - 1;
-            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim) {
-                i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | (u64(1) << (3 * lev)));
-                if (slot >= 0) {
-                    b = start[slot];
-                    cnt = end[slot] - b;
-                }
-            }
+            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
+                cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b, cnt);
         }
         int pre = cnt;
 #pragma unroll
@@ -1091,6 +1106,16 @@ __global__ __launch_bounds__(256) void k_knn(asr_octree_frame f, const float4* s
 // kept: cells one level coarser (43 vs 26 ms), one wave per parent cell with the 4^3 block of finest cells as
 // candidates (fuller waves, but 2.3x the candidates per query: 20.5 vs 16.7 ms).
 // ------------------------------------------------------------------------------------------
+// largest population of a level-`level` cell (table slots hold [start, end) per (cell, level))
+__global__ void k_max_cell_pop(HashTab t, const int32_t* start, const int32_t* end, int level, int* out) {
+    const u64 slot = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    if (slot > t.mask) return;
+    const u64 key = t.keys[slot];
+    if (key == 0 || asr_key_level(key) != level) return;
+    const int pop = end[slot] - start[slot];
+    if (pop > KNN_CROWD) atomicMax(out, pop);
+}
+
 // first point of every run of equal level-`level` cells in the sorted codes.  4096 points per block, ONE atomic per
 // block for the block's share of the list (same-address atomics retire at ~88 / us).
 __global__ __launch_bounds__(256) void k_cell_list(const u64* codes, i64 n, int level, int32_t* list, int* cnt) {
@@ -1767,6 +1792,10 @@ struct RadiusState {
     int32_t* ids = nullptr;    // original index of the point at each Morton position
     int32_t* rank = nullptr;   // inverse of ids (only when the caller asked for it)
     const u64* codes = nullptr;  // sorted level-21 codes (scratch arena: valid until the next reset)
+    u64* codes_w = nullptr;      // the same, writable, and the unsorted inputs of the sort (deepen_point_index)
+    const u64* codes_u = nullptr;
+    const int32_t* ids_u = nullptr;
+    int32_t* ids_w = nullptr;
     int lhash = ASR_MAX_LEVEL;   // finest level in the hash table (finer ones: binary search in codes)
     CellIndex index() const { return {tab, start, end, codes, (int)n, lhash}; }
     HashTab tab;
@@ -1807,6 +1836,10 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     st.sorted = arena_alloc<float4>(ka, n + 1);
     st.ids = ids;
     st.codes = codes;
+    st.codes_w = codes;
+    st.codes_u = codes_u;
+    st.ids_u = ids_u;
+    st.ids_w = ids;
     st.rank = want_rank ? arena_alloc<int32_t>(ka, n + 1) : nullptr;
     if (!codes_u || !codes || !ids_u || !ids || !st.sorted || (want_rank && !st.rank))
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
@@ -1938,6 +1971,17 @@ int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame*
     return ASR_HIP_OK;
 }
 
+// Re-sorts the points on the code bits down to level `ldeep` (they were sorted down to the table's finest level): the
+// cell ranges of the table stay what they are (a stable sort on more bits only reorders points inside those cells), and
+// cells of finer levels become contiguous, i.e. searchable (cell_range).
+static int deepen_point_index(asr_hip_context* ctx, const float* pts, RadiusState& st, int ldeep) {
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, st.codes_u, st.codes_w, st.ids_u, st.ids_w, st.n, 63,
+                                      3 * (ASR_MAX_LEVEL - ldeep))));
+    k_gather_points<<<grid_for(st.n, BLK), BLK, 0, ctx->stream>>>(pts, st.ids_w, st.n, st.sorted, st.rank);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+
 // KDTree::ComputeKRadius / ComputeInlier (cpp/lib/nsearch.cpp:30-86)
 int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts, i64 n, int k,
                  const float* radii_in, float radius_fraction, int outlier_threshold, float* radii_out,
@@ -1952,6 +1996,21 @@ int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const floa
     RadiusState st;
     int host[16];
     ASR_TRY(build_point_index(ctx, frame, pts, n, 0, lfine, st));
+    st.lhash = lfine;
+    // dense spots: a finest-level cell with thousands of points makes every one of them walk thousands of candidates.
+    // Such clouds get their points sorted eight levels deeper, and the points of crowded cells start on a finer level.
+    int ldeep = lfine;
+    {
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 14, 0, sizeof(int), ctx->stream));
+        k_max_cell_pop<<<grid_for((i64)st.tab.mask + 1, BLK), BLK, 0, ctx->stream>>>(st.tab, st.start, st.end, lfine,
+                                                                                   ctx->d_flags + 14);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(read_flags(ctx, host));
+        if (host[14] > KNN_CROWD && ctx->opt.knn_deep) {
+            ldeep = std::min<int>(ASR_MAX_LEVEL, lfine + 8);
+            ASR_TRY(deepen_point_index(ctx, pts, st, ldeep));
+        }
+    }
     const bool fast = !inlier_out && radii_out && k <= 32 && n >= k && ctx->opt.knn_cells;
     if (fast) {
         // cell-parallel pass, then the wave-per-point kernel for what it could not certify
@@ -1980,15 +2039,15 @@ int asr_geom_knn(asr_hip_context* ctx, const asr_octree_frame* frame, const floa
         ASR_TRY(read_flags(ctx, host));
         const i64 nfb = host[13];
         if (nfb > 0) {
-            k_knn<<<grid_for(nfb, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lfine, k,
-                                                             radii_in, radius_fraction, outlier_threshold, radii_out,
-                                                             nullptr, fallback, nfb);
+            k_knn<<<grid_for(nfb, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.index(), lfine, ldeep, k, radii_in,
+                                                             radius_fraction, outlier_threshold, radii_out, nullptr,
+                                                             fallback, nfb);
             ASR_CHECK_LAUNCH(ctx);
         }
     } else {
-        k_knn<<<grid_for(n, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.tab, st.start, st.end, lfine, k,
-                                                       radii_in, radius_fraction, outlier_threshold, radii_out,
-                                                       inlier_out, nullptr, 0);
+        k_knn<<<grid_for(n, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, n, st.index(), lfine, ldeep, k, radii_in,
+                                                       radius_fraction, outlier_threshold, radii_out, inlier_out,
+                                                       nullptr, 0);
         ASR_CHECK_LAUNCH(ctx);
     }
     ASR_TRY(read_flags(ctx, host));

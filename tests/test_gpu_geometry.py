@@ -363,6 +363,12 @@ def test_knn_radius_cell_path_equals_the_wave_path():
             assert torch.equal(fast, slow), (k, float((fast - slow).abs().max()))
     finally:
         ctx.set_option("knn_cells", 1)
-    small = pts[:20000]
+    small = pts[:20000]  # half of it is the dense spot: its points start their search on a finer level ...
     got = synth.knn_radii_gpu(torch.from_numpy(small).to(dev), 24).cpu().numpy()
     assert np.array_equal(got, O.knn_radius(small, 24))
+    try:  # ... which must not change a bit
+        ctx.set_option("knn_deep", 0)
+        flat = synth.knn_radii_gpu(torch.from_numpy(small).to(dev), 24).cpu().numpy()
+    finally:
+        ctx.set_option("knn_deep", 1)
+    assert np.array_equal(got, flat)

@@ -94,6 +94,68 @@ __global__ void k_f16_to_f32(const u16* __restrict__ in, i64 n, float* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Epilogue shared by the two kernels below: acc[nb][i] is C[row = 4 g + i][col = ncol] of the wave's 16 x 16 blocks.
+// rows[i] / norms[i]: output row (-1: none) and importance sum of accumulator row i; bank b (DUAL) sits in the upper
+// half of the last column tile (acc_b) and is the only part that is normalised there.  Normalise, bias, ReLU, residual
+// (activation type), strided store as f32 or f16.
+// ------------------------------------------------------------------------------------------
+template <int NT, int MODE, bool DUAL>
+__device__ inline void sconv16_epilogue(const asr_sparse_conv_args& a, const f32x4 (&acc)[NT], const f32x4& acc_b,
+                                        const int (&rows)[4], const float (&norms)[4], int n0, int ncol, int ca, int cout,
+                                        bool has_b, int out_f16, const float* __restrict__ zeros) {
+    float bv[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+        const int col = n0 + nb * 16 + ncol;
+        const float* bp = (a.bias && col < ca) ? a.bias + col : zeros;
+        if (DUAL && a.bias_b && col >= ca && col < cout) bp = a.bias_b + (col - ca);
+        bv[nb] = *bp;
+    }
+    constexpr bool res16 = MODE == ASR_CONV16_F16;  // the residual has the activations' type
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const i64 q = rows[i];
+        const bool rowok = q >= 0;
+        const float norm = norms[i];
+        const bool do_norm = a.normalize && norm != 0.f;
+        float res[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
+            const bool ok = a.residual && rowok && col < cout;
+            if (res16) {
+                const u16* rp = ok ? (const u16*)a.residual + q * a.residual_ld + col : (const u16*)zeros;
+                res[nb] = (float)__builtin_bit_cast(_Float16, *rp);
+            } else {
+                const float* rp = ok ? a.residual + q * a.residual_ld + col : zeros;
+                res[nb] = *rp;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+            const int col = n0 + nb * 16 + ncol;
+            float v = acc[nb][i];
+            if (DUAL) {
+                const bool colb = col >= ca;
+                if (nb == NT - 1 && has_b && colb) v = acc_b[i];
+                v = (colb && do_norm) ? v / norm : v;
+            } else {
+                v = do_norm ? v / norm : v;
+            }
+            v += bv[nb];
+            if (a.relu) v = fmaxf(v, 0.f);
+            v += res[nb];
+            if (rowok && col < cout) {
+                if (out_f16)
+                    ((u16*)a.out)[q * a.out_ld + col] = f32_to_f16_bits(v);
+                else
+                    a.out[q * a.out_ld + col] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // the kernel.  Block = WAVES waves, tile = WAVES*16 output rows x NT*16 columns; per (slot, KC-deep cin panel)
 // step the weight panel [planes][NCOL][KC] goes global -> registers -> LDS (XOR-swizzled 16-byte pieces,
 // conflict-free ds_read_b128), double buffered, with the same two-step register prefetch as k_sconv_mfma.
@@ -444,58 +506,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
     }
 #undef ASR_SEQ_ADVANCE
 
-    // epilogue (as k_sconv_mfma): acc[nb][i] is C[row = 4 g + i][col = ncol] of the wave's 16 x 16 block
-    float bv[NT];
-#pragma unroll
-    for (int nb = 0; nb < NT; ++nb) {
-        const int col = n0 + nb * 16 + ncol;
-        const float* bp = (a.bias && col < ca) ? a.bias + col : zeros;
-        if (DUAL && a.bias_b && col >= ca && col < cout) bp = a.bias_b + (col - ca);
-        bv[nb] = *bp;
-    }
-    const bool res16 = MODE == ASR_CONV16_F16;  // the residual has the activations' type
+    int rows4[4];
+    float norms4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int lr = wave * 16 + 4 * g + i;
-        const i64 q = s_row[lr];
-        const bool rowok = q >= 0;
-        const float norm = s_norm[lr];
-        const bool do_norm = a.normalize && norm != 0.f;
-        float res[NT];
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-            const int col = n0 + nb * 16 + ncol;
-            const bool ok = a.residual && rowok && col < cout;
-            if (res16) {
-                const u16* rp = ok ? (const u16*)a.residual + q * a.residual_ld + col : (const u16*)zeros;
-                res[nb] = (float)__builtin_bit_cast(_Float16, *rp);
-            } else {
-                const float* rp = ok ? a.residual + q * a.residual_ld + col : zeros;
-                res[nb] = *rp;
-            }
-        }
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-            const int col = n0 + nb * 16 + ncol;
-            float v = acc[nb][i];
-            if (DUAL) {
-                const bool colb = col >= ca;
-                if (nb == NT - 1 && has_b && colb) v = acc_b[i];
-                v = (colb && do_norm) ? v / norm : v;
-            } else {
-                v = do_norm ? v / norm : v;
-            }
-            v += bv[nb];
-            if (a.relu) v = fmaxf(v, 0.f);
-            v += res[nb];
-            if (rowok && col < cout) {
-                if (out_f16)
-                    ((u16*)a.out)[q * a.out_ld + col] = f32_to_f16_bits(v);
-                else
-                    a.out[q * a.out_ld + col] = v;
-            }
-        }
+        rows4[i] = s_row[wave * 16 + 4 * g + i];
+        norms4[i] = s_norm[wave * 16 + 4 * g + i];
     }
+    sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, rows4, norms4, n0, ncol, ca, cout, has_b, out_f16, zeros);
     if (a.out_importance && ychunk == 0 && tid < TM && s_row[tid] >= 0)
         a.out_importance[s_row[tid]] = s_norm[tid];
 }
@@ -822,16 +840,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     }
 #undef ASR_SEQ_ADVANCE
 
-    // epilogue: acc[nb][i] is C[row = 4 g + i][col = ncol] of the wave's 16 x 16 block
-    float bv[NT];
-#pragma unroll
-    for (int nb = 0; nb < NT; ++nb) {
-        const int col = n0 + nb * 16 + ncol;
-        const float* bp = (a.bias && col < ca) ? a.bias + col : zeros;
-        if (DUAL && a.bias_b && col >= ca && col < cout) bp = a.bias_b + (col - ca);
-        bv[nb] = *bp;
-    }
-    const bool res16 = MODE == ASR_CONV16_F16;
     // output rows of this lane's four accumulator rows (-1: beyond the list)
     int q4[4];
 #pragma unroll
@@ -839,47 +847,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         const i64 lr = row0 + wave * 16 + 4 * g + i;
         q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
     }
+    sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, q4, norm4, n0, ncol, ca, cout, has_b, out_f16, zeros);
+    if (ROWW && a.out_importance && ncol == 0 && (DUAL ? has_b : ychunk == 0)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const i64 q = q4[i];
-        const bool rowok = q >= 0;
-        const float norm = norm4[i];
-        const bool do_norm = a.normalize && norm != 0.f;
-        float res[NT];
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-            const int col = n0 + nb * 16 + ncol;
-            const bool ok = a.residual && rowok && col < cout;
-            if (res16) {
-                const u16* rp = ok ? (const u16*)a.residual + q * a.residual_ld + col : (const u16*)zeros;
-                res[nb] = (float)__builtin_bit_cast(_Float16, *rp);
-            } else {
-                const float* rp = ok ? a.residual + q * a.residual_ld + col : zeros;
-                res[nb] = *rp;
-            }
-        }
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-            const int col = n0 + nb * 16 + ncol;
-            float v = acc[nb][i];
-            if (DUAL) {
-                const bool colb = col >= ca;
-                if (nb == NT - 1 && has_b && colb) v = acc_b[i];
-                v = (colb && do_norm) ? v / norm : v;
-            } else {
-                v = do_norm ? v / norm : v;
-            }
-            v += bv[nb];
-            if (a.relu) v = fmaxf(v, 0.f);
-            v += res[nb];
-            if (rowok && col < cout) {
-                if (out_f16)
-                    ((u16*)a.out)[q * a.out_ld + col] = f32_to_f16_bits(v);
-                else
-                    a.out[q * a.out_ld + col] = v;
-            }
-        }
-        if (ROWW && a.out_importance && ncol == 0 && rowok && (DUAL ? has_b : ychunk == 0)) a.out_importance[q] = norm;
+        for (int i = 0; i < 4; ++i)
+            if (q4[i] >= 0) a.out_importance[q4[i]] = norm4[i];
     }
 }
 

@@ -94,6 +94,66 @@ __global__ void k_f16_to_f32(const u16* __restrict__ in, i64 n, float* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Products of one step, shared by the two kernels below: fa = the wave's A fragments of the step (f16: one per 32
+// k; bf16x3: the three exact bf16 terms of the gathered f32), sb = the step's weight panel in LDS.  bf16x3 evaluates
+// a*b as the six products a_i*b_j with i + j <= 2, one weight plane at a time (a B fragment lives for at most three
+// MFMAs) and the small terms first.  IMP: everything goes to the per-slot accumulators tacc; DUAL: the last column
+// tile also feeds tacc[0] (bank b, scaled per row at the end of the slot).
+// ------------------------------------------------------------------------------------------
+template <int NT, int KC, int MODE, bool IMP, bool DUAL, int PLANES, int NJ>
+__device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32x4* __restrict__ sb, f32x4 (&acc)[NT],
+                                        f32x4 (&tacc)[IMP ? NT : 1], bool has_b, int ncol, int g) {
+    constexpr int SLOTS = KC / 8;
+    constexpr int PLANE_PIECES = NT * 16 * SLOTS;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if constexpr (MODE == ASR_CONV16_F16) {
+            const f16x8 af = __builtin_bit_cast(f16x8, fa[j][0]);
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                const int col = nb * 16 + ncol;
+                const f16x8 bf = __builtin_bit_cast(f16x8, sb[col * SLOTS + swz<KC>(col, 4 * j + g)]);
+                if (IMP) {
+                    tacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[nb], 0, 0, 0);
+                } else {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nb], 0, 0, 0);
+                    if (DUAL && has_b && nb == NT - 1)
+                        tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);
+                }
+            }
+        } else {
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[j][0]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 1 ? 1 : 0]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 2 ? 2 : 0]);
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                const int col = nb * 16 + ncol;
+                const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
+#define ASR_SIX(ACC_)                                                                                   \
+    {                                                                                                   \
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);                     \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, ACC_, 0, 0, 0);                          \
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);                         \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC_, 0, 0, 0);                          \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ACC_, 0, 0, 0);                          \
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);                                        \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, ACC_, 0, 0, 0);                          \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, ACC_, 0, 0, 0);                          \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ACC_, 0, 0, 0);                          \
+    }
+                if (IMP) {
+                    ASR_SIX(tacc[nb])
+                } else {
+                    ASR_SIX(acc[nb])
+                    if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
+                }
+#undef ASR_SIX
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Epilogue shared by the two kernels below: acc[nb][i] is C[row = 4 g + i][col = ncol] of the wave's 16 x 16 blocks.
 // rows[i] / norms[i]: output row (-1: none) and importance sum of accumulator row i; bank b (DUAL) sits in the upper
 // half of the last column tile (acc_b) and is the only part that is normalised there.  Normalise, bias, ReLU, residual
@@ -428,51 +488,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
         if (active) {
             const u32x4* sb = s_B[buf];
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if constexpr (MODE == ASR_CONV16_F16) {
-                    const f16x8 af = __builtin_bit_cast(f16x8, fa[j][0]);
-#pragma unroll
-                    for (int nb = 0; nb < NT; ++nb) {
-                        const int col = nb * 16 + ncol;
-                        const f16x8 bf = __builtin_bit_cast(f16x8, sb[col * SLOTS + swz<KC>(col, 4 * j + g)]);
-                        if (IMP) {
-                            tacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[nb], 0, 0, 0);
-                        } else {
-                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nb], 0, 0, 0);
-                            if (DUAL && has_b && nb == NT - 1)
-                                tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);
-                        }
-                    }
-                } else {
-                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[j][0]);
-                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 1 ? 1 : 0]);
-                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 2 ? 2 : 0]);
-#pragma unroll
-                    for (int nb = 0; nb < NT; ++nb) {
-                        const int col = nb * 16 + ncol;
-                        const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
-                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);
-                        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);
-                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);
-                        // smallest terms first
-#define ASR_SIX(ACC_)                                                         \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ACC_, 0, 0, 0);    \
-    ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ACC_, 0, 0, 0);
-                        if (IMP) {
-                            ASR_SIX(tacc[nb])
-                        } else {
-                            ASR_SIX(acc[nb])
-                            if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
-                        }
-#undef ASR_SIX
-                    }
-                }
-            }
+            sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa, sb, acc, tacc, has_b, ncol, g);
             __builtin_amdgcn_s_setprio(0);
             // end of a slot: scale the slot's importance-weighted products per row and fold them in
             if ((IMP || DUAL) && p_cur == npanel - 1) {
@@ -756,53 +772,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         if (active) {
             const u32x4* sb = BUF ? s_B1 : s_B0;
             __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if constexpr (MODE == ASR_CONV16_F16) {
-                    const f16x8 af = __builtin_bit_cast(f16x8, fa[j][0]);
-#pragma unroll
-                    for (int nb = 0; nb < NT; ++nb) {
-                        const int col = nb * 16 + ncol;
-                        const f16x8 bf = __builtin_bit_cast(f16x8, sb[col * SLOTS + swz<KC>(col, 4 * j + g)]);
-                        if (IMP) {
-                            tacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[nb], 0, 0, 0);
-                        } else {
-                            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nb], 0, 0, 0);
-                            if (DUAL && has_b && nb == NT - 1)
-                                tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);
-                        }
-                    }
-                } else {
-                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[j][0]);
-                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 1 ? 1 : 0]);
-                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, fa[j][PLANES > 2 ? 2 : 0]);
-#pragma unroll
-                    for (int nb = 0; nb < NT; ++nb) {
-                        const int col = nb * 16 + ncol;
-                        const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
-                        // one weight plane at a time (a B fragment lives for at most three MFMAs), small terms first
-#define ASR_SIX(ACC_)                                                                                   \
-    {                                                                                                   \
-        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);                     \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, ACC_, 0, 0, 0);                          \
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);                         \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC_, 0, 0, 0);                          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, ACC_, 0, 0, 0);                          \
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);                                        \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, ACC_, 0, 0, 0);                          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, ACC_, 0, 0, 0);                          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, ACC_, 0, 0, 0);                          \
-    }
-                        if (IMP) {
-                            ASR_SIX(tacc[nb])
-                        } else {
-                            ASR_SIX(acc[nb])
-                            if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
-                        }
-#undef ASR_SIX
-                    }
-                }
-            }
+            sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa, sb, acc, tacc, has_b, ncol, g);
             __builtin_amdgcn_s_setprio(0);
             if (ROWW && roww && slot_end) {
 #pragma unroll

@@ -279,3 +279,47 @@ def test_feature_matrix_beyond_4gb(gpu):
     assert len(counts) == 1 and list(counts)[0][6] == 0, counts  # table-driven kernel
     err = float((out.double() - ref).abs().max())
     assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+
+
+def test_plan_kernel_equals_table_kernel_on_random_lists(gpu):
+    """Random neighbour lists (empty rows, rows with every slot, shuffled entry order inside a row, row lists, padded
+    strides): the plan-driven kernel and the table-driven one run the same products in the same slot order, so plain
+    convolutions agree bit for bit; with importance the row sums are formed in a different order (1e-6)."""
+    from asr_hip import ops
+    ctx = ops.context(gpu)
+    g = torch.Generator(device="cpu").manual_seed(99)
+    for case in range(24):
+        K = [27, 55, 9][case % 3]
+        cin = [32, 64, 96, 128][case % 4]
+        cout = [16, 24, 40, 128, 56][case % 5]
+        v, num_inp = int(torch.randint(1, 3000, (1,), generator=g)), int(torch.randint(1, 4000, (1,), generator=g))
+        lens = torch.randint(0, min(K, 14) + 1, (v,), generator=g)
+        lens[torch.randint(0, v, (max(1, v // 50),), generator=g)] = K  # some full rows
+        slots = torch.cat([torch.randperm(K, generator=g)[:int(n)] for n in lens]) if int(lens.sum()) else torch.zeros(0, dtype=torch.int64)
+        rs = torch.zeros(v + 1, dtype=torch.int64)
+        rs[1:] = torch.cumsum(lens, 0)
+        idx = torch.randint(0, num_inp, (int(rs[-1]),), generator=g)
+        ld = cin + [0, 4, 32][case % 3]
+        fbuf = torch.randn((num_inp, ld), generator=g)
+        f = fbuf.to(gpu)[:, :cin]
+        W = (torch.randn((K, cin, cout), generator=g) * 0.1).to(gpu)
+        imp = torch.rand(num_inp, generator=g).to(gpu) if case % 2 else None
+        use_rows = case % 4 == 3
+        perm = torch.randperm(v, generator=g).to(torch.int32).to(gpu) if case % 3 else None
+        n_rows = max(1, v // 2) if (use_rows and perm is not None) else None
+        kw = dict(inp_importance=imp, normalize=imp is not None, relu=True, row_perm=perm, num_rows=n_rows)
+        pk = ops.pack_filters(W, "bf16x3")
+        outs = []
+        for plan_on in (1, 0):
+            ctx.set_option("sconv_plan", plan_on)
+            ctx.sconv_variant_counts(reset=True)
+            out = torch.full((v, cout), -3.0, device=gpu)
+            ops.sparse_conv16("bf16x3", pk, K, cin, cout, f, idx.to(torch.int32).to(gpu), slots.to(torch.uint8).to(gpu),
+                              rs.to(gpu), out=out, **kw)
+            assert list(ctx.sconv_variant_counts())[0][6] == plan_on
+            outs.append(out)
+        ctx.set_option("sconv_plan", 1)
+        if imp is None:
+            assert torch.equal(outs[0], outs[1]), case
+        else:
+            assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max())), case

@@ -733,13 +733,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         const bool active = (wmask >> k_cur) & 1;
         float w4[4] = {0.f, 0.f, 0.f, 0.f};
         const bool slot_end = p_cur == npanel - 1;
-        if (ROWW && roww) {  // the same loads in every step (see load_idx)
+        if (ROWW && roww) {
+            // only where they are needed (wave-uniform branches): the wait at the end of the step needs at least the
+            // NJ*AW gathers after the panel DMA, more loads in between only make it wait for them as well
             if (p_cur == 0) idx4_cur = idx4_next;
-            const u32x4 nx = load_idx4(k1);
-            if (p1 == 0) idx4_next = nx;  // first step of the next slot is the next step
+            if (p1 == 0) idx4_next = load_idx4(k1);  // first step of the next slot is the next step
+            if (slot_end && active) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)  // idx -1 (or a wave without the slot) -> beyond the buffer -> 0
-                w4[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_i, (int)(idx4_cur[i] * 4u), 0, 0));
+                for (int i = 0; i < 4; ++i)  // idx -1 -> beyond the buffer -> 0
+                    w4[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_i, (int)(idx4_cur[i] * 4u), 0, 0));
+            }
         }
         u32x4 fa[NJ][PLANES];
         if (active) {

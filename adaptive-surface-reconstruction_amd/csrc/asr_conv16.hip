@@ -686,13 +686,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         if (first) idx = load_idx(qk);
         const unsigned long long rest = qk < 0 ? 0ull : (bmask >> qk) >> 1;
         const int kn = rest ? qk + 1 + __builtin_ctzll(rest) : -1;
-        const int nxt = load_idx(kn);  // every step; consumed when the gather moves on to slot kn
-        if (sw) {
+        if (sw) {  // once per slot: take the prefetched index, prefetch the one of the slot after it
             cache_k = qk;
             const bool valid = has_slot(qk) && idx >= 0;
             cache_off = valid ? (unsigned)idx * (unsigned)(a.inp_ld * ESZ) + (unsigned)(8 * g * ESZ) : OOB_OFF;
+            pref_idx = load_idx(kn);
         }
-        pref_idx = nxt;
         const int soff = qp * KC * ESZ;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)

@@ -1173,7 +1173,12 @@ __global__ __launch_bounds__(256) void k_knn_cells(asr_octree_frame f, const flo
     z = min(max(z, 0), lim);
     int b = 0, cnt = 0;
     if (lane < 27) {
-        int xx = x + lane % 3 - 1, yy = y + (lane / 3) % 3 - 1, zz = z + lane / 9 - 1;
+        // candidate cells nearest first (the cell itself, 6 face, 12 edge, 8 corner neighbours): the k-th distance is
+        // tight after the first few, and chunks of the far cells are skipped by the ballot test below
+        constexpr unsigned char order[27] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25,
+                                             0, 2, 6, 8, 18, 20, 24, 26};
+        const int c = order[lane];
+        int xx = x + c % 3 - 1, yy = y + (c / 3) % 3 - 1, zz = z + c / 9 - 1;
         if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim) {
             i64 slot = tab_find_slot(t, asr_morton3d((u64)xx, (u64)yy, (u64)zz) | (u64(1) << (3 * lfine)));
             if (slot >= 0) {
@@ -1189,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_knn_cells(asr_octree_frame f, const flo
         if (lane >= o) pre += up;
     }
     const int total = __shfl(pre, 26, 64);
-    const int qb = __shfl(b, 13, 64), qn = __shfl(cnt, 13, 64);  // the cell itself: its points are the queries
+    const int qb = __shfl(b, 0, 64), qn = __shfl(cnt, 0, 64);  // the cell itself: its points are the queries
     if (lane < 27) {
         s_pref[wave][lane + 1] = pre;
         s_beg[wave][lane] = b;

@@ -94,4 +94,53 @@ TREE_B = {
               "up_kernel_index": [0, 1, 2, 3, 4, 5, 6, 7]},
 }
 
+# ---- tree C: BalanceFaces inserts a sibling group ---------------------------------------------------------
+# One point P = (0.45, 0.05, 0.05), r 0.1 -> level 3 (0.125 >= 0.1 > 0.0625, octree.h:42-47); cell
+# (floor(0.45 * 8), 0, 0) = (3, 0, 0): Morton = x bits 0 and 1 at positions 0 and 3 = 9, key 9 | 1<<9 = 521.
+# CreateAncestorsAndSiblings (octree.cpp:110-150): siblings 520..527 (children of 521>>3 = 65 = level-2 cell
+# (1,0,0)), parent group 64..71 (children of 8), 8..15, root 1: 25 nodes.
+# BalanceFaces (octree.cpp:152-206), first-sibling queue {8, 64, 520} (:160-166):
+#   8   : HasFirstChild (64 exists) -> not a leaf, skipped (:175-176);
+#   64  : its first child 512 does not exist, so the GROUP counts as a leaf although its sibling 65 is refined
+#         ("process only the first sibling", :163-164); parent (0,0,0) of level 1, face neighbours 9, 10, 12 exist,
+#         the other three are outside the cube (INVALID_KEY, :188) -> nothing;
+#   520 : leaf; parent 65 = level-2 cell (1,0,0).  -x: 64 exists; -y, -z: outside; +y: (1,1,0) = 3|64 = 67 exists;
+#         +z: (1,0,1) = 5|64 = 69 exists; +x: (2,0,0) = Morton 8 | 64 = 72 is NOT a node: the while loop (:191-201)
+#         inserts the sibling group 72..79, queues 72, then key >>= 3 = 9 is found and the loop ends.
+# Second round {72}: leaf; parent 9 = level-1 cell (1,0,0): 8, 11, 13 exist, (2,0,0) is outside -> nothing.
+# Leaves (nodes without first child, :208-228): 9 now has the first child 72 and becomes inner.
+TREE_C = {
+    "points": [[0.45, 0.05, 0.05]], "radii": [0.1],
+    "nodes_unbalanced": [1] + list(range(8, 16)) + list(range(64, 72)) + list(range(520, 528)),
+    "nodes": [1] + list(range(8, 16)) + list(range(64, 80)) + list(range(520, 528)),
+    "leaves": list(range(10, 16)) + [64] + list(range(66, 72)) + list(range(72, 80)) + list(range(520, 528)),
+    "balance_rounds": 2,
+}
+
+# ---- tree D: one walk of the while loop inserts two levels --------------------------------------------------
+# The same point with r 0.05 -> level 4 (0.0625 >= 0.05); cell (floor(0.45 * 16), 0, 0) = (7, 0, 0): x = 0b111 at
+# Morton positions 0, 3, 6 = 73, key 73 | 1<<12 = 4169.  Closure: 4168..4175 (children of 521), 520..527, 64..71,
+# 8..15, 1.  BalanceFaces queue {8, 64, 520, 4168}:
+#   4168: leaf; parent 521 = level-3 cell (3,0,0); +x neighbour (4,0,0): x = 0b100 -> Morton 64, key 64 | 512 = 576,
+#         not a node: the loop inserts 576..583 and queues 576; key >>= 3 = 72 (level-2 cell (2,0,0)) is not a
+#         node either: inserts 72..79, queues 72; key >>= 3 = 9 exists.  Its other face neighbours 520, 523, 525
+#         are siblings;
+#   520 : its first child (520<<3 = 4160) does not exist -> leaf group; parent 65: +x neighbour 72 -- present or
+#         not depending on whether 4168 was visited first; either way 72..79 ends up in the set;
+#   8, 64 as in tree C.
+# Second round {576, 72} (either order): 576 is a leaf, parent 72 = level-2 cell (2,0,0): 65, 73, 74, 76 exist, the
+# rest is outside; 72 now has the first child 576 -> skipped.  The reference's sequential walk and the
+# round-synchronous statement used here give the same set.
+TREE_D = {
+    "points": [[0.45, 0.05, 0.05]], "radii": [0.05],
+    "nodes_unbalanced": [1] + list(range(8, 16)) + list(range(64, 72)) + list(range(520, 528)) + list(range(4168, 4176)),
+    "nodes": [1] + list(range(8, 16)) + list(range(64, 80)) + list(range(520, 528)) + list(range(576, 584)) +
+             list(range(4168, 4176)),
+    # inner: 1, 8, 9 (child 72), 65 (child 520), 72 (child 576), 521 (child 4168)
+    "leaves": list(range(10, 16)) + [64] + list(range(66, 72)) + list(range(73, 80)) + [520] + list(range(522, 528)) +
+              list(range(576, 584)) + list(range(4168, 4176)),
+    "balance_rounds": 2,
+}
+
 TREES = {"A": TREE_A, "B": TREE_B}
+BALANCE_TREES = {"C": TREE_C, "D": TREE_D}

@@ -55,3 +55,38 @@ def test_hip_reproduces_the_hand_worked_tree(gpu, name):
     nodes = tree.nodes.cpu().numpy().view(np.uint64)
     leaves = tree.leaves.cpu().numpy().view(np.uint64)
     _check(t, nodes, leaves, grids)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["round-synchronous", "sequential-walk"])
+@pytest.mark.parametrize("name", ["C", "D"])
+def test_oracle_balance_inserts_the_hand_worked_nodes(name, mode):
+    """BalanceFaces (/root/reference/cpp/lib/octree.cpp:152-206) has to ADD sibling groups in these trees; both
+    statements of the oracle (mode 0 = round-synchronous leaf test, mode 1 = the reference's sequential walk) give
+    the hand-derived node and leaf sets"""
+    t = micro.BALANCE_TREES[name]
+    o = O.Oracle()
+    o.build_octree(np.array(t["points"], np.float32), np.array(t["radii"], np.float32),
+                   np.array(micro.BBOX[0], np.float32), np.array(micro.BBOX[1], np.float32), mode=mode)
+    assert o.nodes.tolist() == t["nodes"] and o.leaves.tolist() == t["leaves"]
+    assert len(t["nodes"]) > len(t["nodes_unbalanced"]) and set(t["nodes_unbalanced"]) < set(t["nodes"])
+    assert o.balance_rounds == t["balance_rounds"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["C", "D"])
+def test_hip_balance_inserts_the_hand_worked_nodes(gpu, name):
+    import adaptivesurfacereconstruction as asr
+    t = micro.BALANCE_TREES[name]
+    tree = asr.create_octree(np.array(t["points"], np.float32), np.array(t["radii"], np.float32),
+                             micro.BBOX[0], micro.BBOX[1])
+    assert tree.nodes.cpu().numpy().view(np.uint64).tolist() == t["nodes"]
+    assert tree.leaves.cpu().numpy().view(np.uint64).tolist() == t["leaves"]
+    # the grids built on the balanced leaves: the 55-slot lists of the oracle on the same (hand-checked) leaf set
+    o = O.Oracle()
+    o.build_octree(np.array(t["points"], np.float32), np.array(t["radii"], np.float32),
+                   np.array(micro.BBOX[0], np.float32), np.array(micro.BBOX[1], np.float32))
+    want = o.create_grids(5)
+    got = asr.create_grids_from_octree(tree, 5, voxel_info_all_levels=True)
+    for g, w in zip(got, want):
+        for k in ("voxel_keys", "neighbors_index", "neighbors_kernel_index", "neighbors_row_splits"):
+            assert np.array_equal(g[k], w[k]), k

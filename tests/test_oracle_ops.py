@@ -156,3 +156,19 @@ def test_dense_open3d_style_evaluation_equals_the_pairwise_one():
         with O.dense():
             b = O.sparse_conv(W, f, idx, kidx, nimp, rs, normalize)
         assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())
+
+
+@pytest.mark.parametrize("tag,n", [("d4_3k", 3000), ("d1_2k", 2000), ("layers_d4_1k", 1000)])
+def test_fixture_inputs_come_out_of_the_committed_generator(golden_dir, tag, n):
+    """provenance chain of tests/golden/unet_*.npz: the stored inputs are what tests/golden/make_unet_fixture.py
+    derives TODAY from (n, seed) -- scan_cloud, 24-NN radii, bounding box -- so a change of the generators after
+    the fixtures were written (which would make the committed script stop reproducing them) fails here.  The
+    outputs need /root/reference and are re-derived by running that script in the build container."""
+    from asr_hip import synth
+    fx = np.load(os.path.join(golden_dir, "unet_%s.npz" % tag))
+    seed = int(fx["seed"])
+    pts, nrm = synth.scan_cloud(n, seed=seed, device="cpu")
+    assert np.array_equal(pts.numpy(), fx["points"]) and np.array_equal(nrm.numpy(), fx["normals"])
+    assert np.array_equal(synth.knn_radii(fx["points"], 24), fx["radii"])
+    bb_min, bb_max = synth.bounding_box(fx["points"], 0.1)
+    assert np.array_equal(bb_min, fx["bb_min"]) and np.array_equal(bb_max, fx["bb_max"])

@@ -99,7 +99,7 @@ class ImplicitSizes(ctypes.Structure):
 EXPORTS = [
     "asr_hip_context_create", "asr_hip_context_destroy", "asr_hip_context_set_stream",
     "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes",
-    "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_set_option", "asr_hip_context_get_option",
+    "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_weights_changed", "asr_hip_context_set_option", "asr_hip_context_get_option",
     "asr_hip_sparse_conv_variant_counts", "asr_hip_sparse_conv_packed_bytes", "asr_hip_sparse_conv_pack",
     "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_convert_f16",
     "asr_hip_sparse_conv_plan_create", "asr_hip_sparse_conv_plan_destroy", "asr_hip_sparse_conv_plan_bytes",

@@ -95,6 +95,13 @@ int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* 
     ASR_FAIL(ctx, ASR_HIP_EINVAL, "unknown option '%s'", name);
 }
 int asr_hip_context_device(const asr_hip_context* ctx) { return ctx ? ctx->device : -1; }
+int asr_hip_context_weights_changed(asr_hip_context* ctx) {
+    CTX_GUARD(ctx);
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // a forward that reads the copies may still be running
+    for (auto& kv : ctx->packed_weights) (void)hipFree(kv.second);
+    ctx->packed_weights.clear();
+    return ASR_HIP_OK;
+}
 int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t cap, int reset) {
     if (!ctx || (!buf && cap)) return ASR_HIP_EINVAL;
     std::string s;
@@ -551,17 +558,22 @@ struct Net {
 
     // packed 16-bit copy of a (two-bank) filter tensor, made once per weight tensor and mode
     int packed(const asr_weight* ka, const asr_weight* kb, const void** out) {
-        auto key = std::make_pair((const void*)ka->data, precision);
+        const int cb = kb ? (int)kb->shape[2] : 0;
+        const asr_hip_context::PackedKey key((const void*)ka->data, kb ? (const void*)kb->data : nullptr, ka->shape[0],
+                                             ka->shape[1], ka->shape[2], (i64)cb, precision);
         auto it = ctx->packed_weights.find(key);
         if (it == ctx->packed_weights.end()) {
-            const int cb = kb ? (int)kb->shape[2] : 0;
             const size_t bytes = asr_conv16_packed_bytes(precision, (int)ka->shape[0], (int)ka->shape[1],
                                                          (int)ka->shape[2], cb);
             void* p = nullptr;
             ASR_HIP_CHECK(ctx, hipMalloc(&p, bytes));
+            const int rc = asr_conv16_pack(ctx, precision, ka->data, kb ? kb->data : nullptr, (int)ka->shape[0],
+                                           (int)ka->shape[1], (int)ka->shape[2], cb, p);
+            if (rc != ASR_HIP_OK) {  // never cache a buffer that was not filled
+                (void)hipFree(p);
+                return rc;
+            }
             it = ctx->packed_weights.emplace(key, p).first;
-            ASR_TRY(asr_conv16_pack(ctx, precision, ka->data, kb ? kb->data : nullptr, (int)ka->shape[0],
-                                    (int)ka->shape[1], (int)ka->shape[2], cb, p));
         }
         *out = it->second;
         return ASR_HIP_OK;
@@ -740,6 +752,13 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     ctx->scratch.reset();
     ctx->named.clear();
     ctx->values = ctx->feats1 = ctx->importance = ctx->code = nullptr;
+    // nothing of the previous build survives the arena reset above
+    ctx->agg_rs = nullptr;
+    ctx->agg_idx = ctx->agg_spos = nullptr;
+    ctx->agg_dist = ctx->agg_compat = nullptr;
+    ctx->agg_sorted = nullptr;
+    ctx->has_search = false;
+    ctx->build_mark_ok = false;
     memset(&ctx->sizes, 0, sizeof(ctx->sizes));
     ctx->sizes.num_points = n;
     if (asr_octree_frame_init(&ctx->frame, prm->bb_min, prm->bb_max) != ASR_HIP_OK)
@@ -944,6 +963,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     }
     if (want_search) {
         GridDev& g0 = ctx->grids[0];
+        ctx->has_search = true;
         ctx->sizes.num_agg_pairs = agg_pairs;
         name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * agg_pairs);
         name_it(ctx, "aggregation_neighbors_dist", ctx->agg_dist, 4 * agg_pairs);
@@ -964,7 +984,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_TRY(ensure_events(ctx));
     if (n != ctx->sizes.num_points || ctx->sizes.num_voxels[0] == 0)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: no matching implicit_build");
-    if (!ctx->agg_rs || !ctx->agg_sorted || ctx->opt.build_search == 0)
+    if (!ctx->has_search || !ctx->agg_rs || !ctx->agg_sorted)  // what the LAST BUILD did, not the option's value now
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: the build skipped the aggregation search (option build_search)");
     ctx->scratch.reset();
     if (ctx->build_mark_ok) arena_rewind(ctx->persist, ctx->build_mark);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/asr_hip.h"
@@ -155,6 +156,7 @@ struct asr_hip_context {
     i64* agg_rs = nullptr;
     int32_t* agg_spos = nullptr;         // neighbour of each aggregation pair as a position in Morton order
     const float4* agg_sorted = nullptr;  // points in Morton order (x, y, z, original index bits)
+    bool has_search = false;             // the last implicit_build ran the aggregation search
     float* values = nullptr;
     float* feats1 = nullptr;
     float* importance = nullptr;
@@ -174,9 +176,11 @@ struct asr_hip_context {
     hipEvent_t aux_ev = nullptr;
     hipEvent_t aux_t0 = nullptr, aux_t1 = nullptr;  // search start / end on the auxiliary stream
     bool search_overlapped = false;
-    // packed 16-bit copies of the weight tensors of the whole-path driver, keyed by (pointer of the f32
-    // tensor, mode); the weights of a pipeline are static, so they are packed once
-    std::map<std::pair<const void*, int>, void*> packed_weights;
+    // packed 16-bit copies of the weight tensors of the whole-path driver, keyed by (pointers of the f32 tensors
+    // of both banks, their shapes, mode).  A weight table is immutable while a context holds packed copies of it:
+    // callers that update weights in place call asr_hip_context_weights_changed (the copies are made again).
+    typedef std::tuple<const void*, const void*, i64, i64, i64, i64, int> PackedKey;
+    std::map<PackedKey, void*> packed_weights;
 };
 
 #define ASR_FAIL(ctx, code, ...)                         \

@@ -3,7 +3,7 @@
 // TorchScript caller -- asr::ReconstructSurface runs model.pt through module.run_method (cpp/lib/asr.cpp:315-326) --
 // reaches the HIP kernels without a Python interpreter: load libasr_open3d_ops.so (torch.ops.load_library in Python,
 // dlopen / link in C++) next to libasr_hip.so.  Every op unpacks pointers and sizes and calls the C ABI
-// (include/asr_hip.h) on torch's current stream; one library context per device.  Same argument checks as the Python
+// (include/asr_hip.h) on torch's current stream; one library context per (thread, device).  Same argument checks as the Python
 // registration (open3d/ml/torch/ops.py), which must not be imported into the same process (one definition per schema).
 #include <ATen/ATen.h>
 #include <ATen/hip/HIPContext.h>
@@ -11,20 +11,25 @@
 #include <torch/library.h>
 
 #include <map>
-#include <mutex>
 #include <tuple>
 
 #include "../../../include/asr_hip.h"
 
 namespace {
 
+// One library context per (thread, device): a context -- its stream, arenas and error text -- is not thread safe, and
+// libtorch callers may run ops of one GPU from several threads (jit fork, multi-threaded C++ programs).
+struct ThreadContexts {
+    std::map<int, asr_hip_context*> ctxs;
+    ~ThreadContexts() {
+        for (auto& kv : ctxs) asr_hip_context_destroy(kv.second);
+    }
+};
 asr_hip_context* context_for(const at::Tensor& t) {
-    static std::mutex mu;
-    static std::map<int, asr_hip_context*> ctxs;
+    static thread_local ThreadContexts tc;
     TORCH_CHECK(t.is_cuda(), "open3d ops (asr_hip): tensors must live on the GPU");
     const int dev = t.get_device();
-    std::lock_guard<std::mutex> lock(mu);
-    asr_hip_context*& c = ctxs[dev];
+    asr_hip_context*& c = tc.ctxs[dev];
     auto stream = at::hip::getCurrentHIPStream(dev).stream();
     if (!c) {
         c10::DeviceGuard guard(t.device());

@@ -98,8 +98,9 @@ def _sparse_conv_backward(ctx, grad):
     has_imp = nimp.numel() > 0
     lens = rs[1:] - rs[:-1]
     row = torch.repeat_interleave(torch.arange(v, device=f.device), lens)      # output row of every pair
-    if ctx.normalize and has_imp:
-        norm = torch.ops.open3d.reduce_subarrays_sum(nimp, rs)
+    if ctx.normalize:
+        # the forward divides by the importance sum of the row, or by the neighbour COUNT when there is no importance
+        norm = torch.ops.open3d.reduce_subarrays_sum(nimp, rs) if has_imp else lens.to(grad.dtype)
         grad = grad / torch.where(norm != 0, norm, torch.ones_like(norm))[:, None]
     g_filters = g_feats = None
     if ctx.needs_input_grad[1]:

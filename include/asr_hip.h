@@ -65,12 +65,16 @@ size_t asr_hip_context_reserved_bytes(const asr_hip_context* ctx);
 /* HIP device the context is bound to (the device current when it was created); every entry point
  * selects it on the calling thread.  -1 for a null context. */
 int asr_hip_context_device(const asr_hip_context* ctx);
+/* The whole-path driver keeps packed 16-bit copies of the weight tensors it was given (keyed by the tensors'
+ * device pointers and shapes).  Call this after the contents of a weight tensor changed in place -- or when a new
+ * table may reuse the addresses of an old one -- so that the copies are made again by the next forward. */
+int asr_hip_context_weights_changed(asr_hip_context* ctx);
 /* Per-context tunables (no process-wide state).  Names: "sconv_min_blocks" (2816) and
  * "sconv_wide_min" (2048): launch-size thresholds that pick the sparse-conv tile shape;
  * "row_segment" (524288), "row_lpt" (1): MFMA row regrouping; "overlap" (1): aggregation search on a
  * second stream; "sconv_dry" (0): measurement aid; "build_search" (1): 0 makes asr_hip_implicit_build stop
  * after the grid hierarchy (a rank of a sharded run searches only the rows it owns).  Results never depend
- * on the tuning options. */
+ * on the tuning options; "sconv_dry" is the exception: it skips work and produces garbage, for timing only. */
 int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value);
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value);
 

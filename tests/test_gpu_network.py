@@ -327,7 +327,9 @@ def test_sparse_conv_backward_against_torch_autograd(geo, gpu):
     import open3d.ml.torch as ml3d
     pts, nrm, rad, bb, item = geo
     rng = np.random.default_rng(17)
-    for level, cin, cout, with_imp in ((2, 8, 12, True), (3, 16, 8, False)):
+    # (level, cin, cout, neighbour importance, normalize); normalize without importance divides by the neighbour count
+    for level, cin, cout, with_imp, normalize in ((2, 8, 12, True, True), (3, 16, 8, False, False), (2, 8, 8, False, True),
+                                                  (3, 8, 8, True, False)):
         idx, kidx, rs = (item["neighbors_index%d" % level], item["neighbors_kernel_index%d" % level],
                          item["neighbors_row_splits%d" % level])
         v = len(rs) - 1
@@ -341,7 +343,7 @@ def test_sparse_conv_backward_against_torch_autograd(geo, gpu):
         nimp = _t(imp, gpu) if with_imp else empty
         out = ml3d.ops.sparse_conv(filters=W, inp_features=f, inp_importance=empty, neighbors_index=_t(idx, gpu),
                                    neighbors_kernel_index=_t(kidx, gpu), neighbors_importance=nimp,
-                                   neighbors_row_splits=_t(rs, gpu), normalize=with_imp)
+                                   neighbors_row_splits=_t(rs, gpu), normalize=normalize)
         out.backward(_t(gout, gpu))
         # dense fp64 reference on the CPU
         fr = torch.from_numpy(f0).double().requires_grad_(True)
@@ -350,7 +352,7 @@ def test_sparse_conv_backward_against_torch_autograd(geo, gpu):
         w = torch.from_numpy(imp).double() if with_imp else torch.ones(len(idx), dtype=torch.float64)
         contrib = torch.einsum("pc,pco->po", fr[torch.from_numpy(idx).long()] * w[:, None], Wr[torch.from_numpy(kidx).long()])
         ref = torch.zeros((v, cout), dtype=torch.float64).index_add(0, row, contrib)
-        if with_imp:
+        if normalize:
             ref = ref / torch.zeros(v, dtype=torch.float64).index_add(0, row, w)[:, None]
         _close(out.detach().cpu().numpy(), ref.detach().numpy())
         ref.backward(torch.from_numpy(gout).double())

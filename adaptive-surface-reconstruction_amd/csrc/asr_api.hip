@@ -44,6 +44,9 @@ const OptEntry k_options[] = {
         {"overlap", "ASR_OVERLAP", &AsrOptions::overlap},
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
+        {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
+        {"search_groups", "ASR_SEARCH_GROUPS", &AsrOptions::search_groups},
+        {"presort", "ASR_PRESORT", &AsrOptions::presort},
 };
 }  // namespace
 
@@ -87,6 +90,10 @@ int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t v
 }
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value) {
     if (!ctx || !name || !value) return ASR_HIP_EINVAL;
+    if (!strcmp(name, "last_search_margin_pairs")) {  // read-only diagnostic of the last aggregation search
+        *value = ctx->search_overlapped && ctx->aux ? ctx->aux->search_extras : ctx->search_extras;
+        return ASR_HIP_OK;
+    }
     for (const OptEntry& o : k_options)
         if (!strcmp(name, o.name)) {
             *value = ctx->opt.*(o.field);
@@ -764,8 +771,10 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     if (asr_octree_frame_init(&ctx->frame, prm->bb_min, prm->bb_max) != ASR_HIP_OK)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "degenerate bounding box");
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ctx->pindex.valid = false;
+    if (ctx->opt.presort) ASR_TRY(asr_geom_presort(ctx, ctx->persist, &ctx->frame, points, radii, n));
     ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale,
-                                  prm->octree_max_depth));
+                                  prm->octree_max_depth, ctx->pindex.valid ? &ctx->pindex : nullptr));
     ctx->sizes.num_nodes = ctx->num_nodes;
     name_it(ctx, "nodes", ctx->nodes, 8 * ctx->num_nodes);
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -828,7 +837,8 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         ctx->agg_rs = arena_alloc<i64>(sc->persist, g0.v + 1);
         if (!ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
-                                      &agg_pairs, &sc->persist));
+                                      &agg_pairs, &sc->persist, radii, g0.keys, ctx->leaf_lmin, ctx->leaf_lmax,
+                                      ctx->pindex.valid ? &ctx->pindex : nullptr));
         ctx->agg_idx = arena_alloc<int32_t>(sc->persist, agg_pairs);
         ctx->agg_dist = arena_alloc<float>(sc->persist, agg_pairs);
         ctx->agg_compat = arena_alloc<float>(sc->persist, agg_pairs);
@@ -861,23 +871,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         ctx->scratch.reset();
         if (i > 0) {
             GridDev& prev = ctx->grids[i - 1];
-            ASR_TRY(asr_geom_coarsen_count(ctx, prev.keys, prev.v, &g.v));
-            g.keys = arena_alloc<u64>(ctx->persist, g.v);
-            prev.up_idx = arena_alloc<int32_t>(ctx->persist, prev.v);
-            prev.up_kidx = arena_alloc<uint8_t>(ctx->persist, prev.v);
-            prev.up_rs = arena_alloc<i64>(ctx->persist, prev.v + 1);
-            if (!g.keys || !prev.up_idx || !prev.up_kidx || !prev.up_rs)
-                ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            ASR_TRY(asr_geom_coarsen_fill(ctx, prev.keys, prev.v, g.keys, g.v, prev.up_idx,
-                                          prev.up_kidx, prev.up_rs));
-            // neighbors_down = invert(up lists)  (net_definitions_torch.py:548-559)
-            prev.down_idx = arena_alloc<int32_t>(ctx->persist, prev.v);
-            prev.down_kidx = arena_alloc<uint8_t>(ctx->persist, prev.v);
-            prev.down_rs = arena_alloc<i64>(ctx->persist, g.v + 1);
-            if (!prev.down_idx || !prev.down_kidx || !prev.down_rs)
-                ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            ASR_TRY(asr_geom_invert(ctx, g.v, prev.up_idx, prev.up_rs, prev.v, prev.up_kidx,
-                                    prev.down_idx, prev.down_rs, prev.down_kidx, prev.v));
+            // CombineSiblings + neighbors_down = invert(up lists) (net_definitions_torch.py:548-559) in one go
+            ASR_TRY(asr_geom_coarsen_build(ctx, ctx->persist, prev.keys, prev.v, &g.keys, &g.v, &prev.up_idx,
+                                           &prev.up_kidx, &prev.up_rs, &prev.down_idx, &prev.down_kidx, &prev.down_rs));
             prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
             prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
             if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");

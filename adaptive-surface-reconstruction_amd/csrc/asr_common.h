@@ -106,6 +106,9 @@ struct AsrOptions {
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
+    i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
+    i64 search_groups = 0;        // aggregation search: 1 = one wave per sibling group of voxels (measured slower: 3.6 vs 3.3 ms at 10 M points, the kernel is bound by the latency chain of a wave, not by its table probes)
+    i64 presort = 0;              // implicit_build: 1 = points sorted once, up front, for octree insertion and search (measured slower: neighbouring lanes contend for the same table slots, insertion 1.6 vs 1.1 ms)
 };
 
 // Row-group plan of a neighbour list for the plan-driven 16-bit sparse conv (asr_conv16.hip): per 16
@@ -130,6 +133,21 @@ struct asr_conv_plan {
     int K = 0;
     bool usable() const { return hdr && blocks * 64 < (i64(1) << 32) - 65536; }
     asr_conv_plan_view view() const { return {hdr, pool, groups, (unsigned)(blocks * 64)}; }
+};
+
+// Points of the last implicit_build in Morton order (asr_geom_presort): shared by the octree insertion (neighbouring
+// lanes then carry the same key: one table probe per run) and by the aggregation search.
+struct AsrPointIndex {
+    bool valid = false;
+    const float* pts = nullptr;
+    const float* radii = nullptr;
+    i64 n = 0;
+    int lsort = 0;               // sorted on the code bits down to this level
+    float4* sorted = nullptr;    // (x, y, z, original index bits)
+    int32_t* ids = nullptr;      // original index per Morton position
+    int32_t* rank = nullptr;     // Morton position per original index
+    float* srad = nullptr;       // radii in Morton order
+    u64* codes = nullptr;        // sorted level-21 codes
 };
 
 struct asr_hip_context {
@@ -157,6 +175,9 @@ struct asr_hip_context {
     int32_t* agg_spos = nullptr;         // neighbour of each aggregation pair as a position in Morton order
     const float4* agg_sorted = nullptr;  // points in Morton order (x, y, z, original index bits)
     bool has_search = false;             // the last implicit_build ran the aggregation search
+    AsrPointIndex pindex;                // asr_geom_presort
+    int search_extras = 0;               // pairs the last aligned search took from the rounding margin (diagnostic)
+    int leaf_lmin = -1, leaf_lmax = -1;  // levels of the first / last leaf of the last octree
     float* values = nullptr;
     float* feats1 = nullptr;
     float* importance = nullptr;
@@ -279,8 +300,13 @@ __device__ static inline u64 asr_hash64(u64 k) {
 // internal entry points shared between translation units
 int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                         const float* radii, i64 n, float radius_scale, int max_depth, u64* keys);
+// pre: the same points in Morton order (asr_geom_presort) -- inserted in that order, or nullptr
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                          const float* radii, i64 n, float radius_scale, int max_depth);
+                          const float* radii, i64 n, float radius_scale, int max_depth,
+                          const AsrPointIndex* pre = nullptr);
+// Morton order of the points (+ radii) into ctx->pindex, arrays in `keep`
+int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* frame, const float* pts,
+                     const float* radii, i64 n);
 int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* rs, i64* num_pairs);
 int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const i64* rs,
                             int32_t* idx, uint8_t* kidx);
@@ -297,16 +323,26 @@ struct asr_row_group_job {
 };
 int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg);
 int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_out);
+// down_*: optional inverted up lists (rows = coarse voxels; what open3d::invert_neighbors_list returns for the up lists)
 int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out_keys, i64 v_out,
-                          int32_t* up_idx, uint8_t* up_kidx, i64* up_rs);
+                          int32_t* up_idx, uint8_t* up_kidx, i64* up_rs, int32_t* down_idx = nullptr,
+                          uint8_t* down_kidx = nullptr, i64* down_rs = nullptr);
+int asr_geom_coarsen_build(asr_hip_context* ctx, Arena& keep, const u64* keys, i64 v, u64** out_keys, i64* v_out,
+                           int32_t** up_idx, uint8_t** up_kidx, i64** up_rs, int32_t** down_idx, uint8_t** down_kidx,
+                           i64** down_rs);
 int asr_geom_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame, const u64* keys,
                         i64 v, float* centers, float* sizes);
 // keep: arena for the Morton-ordered point arrays (scratch when null); fill: spos (optional) receives
 // each pair's neighbour as a position in Morton order, sorted_out the Morton-ordered points (x, y, z,
 // original index bits) they refer to
+// radii: gathered into Morton order together with the points (the fill call then needs no pass of its own);
+// voxel_keys: the queries are the centres of these grid voxels with radius = voxel size ("aligned": half-size search
+// cells, see AlignedQ in asr_geom.hip); lmin / lmax: levels of the queries when the caller knows them (else -1)
 int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                           i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
-                          i64* num_pairs, Arena* keep = nullptr);
+                          i64* num_pairs, Arena* keep = nullptr, const float* radii = nullptr,
+                          const u64* voxel_keys = nullptr, int lmin_hint = -1, int lmax_hint = -1,
+                          const AsrPointIndex* pre = nullptr);
 int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* radii, i64 n,
                          const float* centers, const float* sizes, i64 v, const i64* rs,
                          int32_t* idx, float* dist, float* compat, int32_t* spos = nullptr,

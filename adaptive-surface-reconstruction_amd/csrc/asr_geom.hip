@@ -35,6 +35,8 @@ struct HashTab {
 // collision (another block hashed to the same bucket) moves to the SAME position of another bucket (double
 // hashing over buckets): stepping to the next slot instead would run through the neighbouring keys of both
 // blocks (measured: 5x slower than plain hashing).  cap is a power of two >= 64, the bucket step is odd.
+// Keys whose low 6 bits are concentrated on a few values (points on a lattice) fill "their" position of the buckets
+// before the table is half full: the builders report the overflow and the hosts rebuild the table four times the size.
 struct TabProbe {
     u64 bucket, step, low, bmask;
     __device__ inline u64 slot() const { return ((bucket & bmask) << 6) | low; }
@@ -206,13 +208,43 @@ __global__ void k_octree_insert_points(asr_octree_frame f, const float* pts, con
                                        i64 n, float radius_scale, int max_depth, HashTab t,
                                        int* cnt, u64* list, int list_cap) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (!(isfinite(pts[3 * i]) && isfinite(pts[3 * i + 1]) && isfinite(pts[3 * i + 2]) && isfinite(radii[i]))) {
-        cnt[11] = 1;  // rejected by the host: the reference has undefined behaviour on such input
-        return;
+    u64 key = 0;
+    if (i < n) {
+        if (!(isfinite(pts[3 * i]) && isfinite(pts[3 * i + 1]) && isfinite(pts[3 * i + 2]) && isfinite(radii[i])))
+            cnt[11] = 1;  // rejected by the host: the reference has undefined behaviour on such input
+        else
+            key = point_key(f, pts, radii, i, radius_scale, max_depth);
     }
-    u64 key = point_key(f, pts, radii, i, radius_scale, max_depth);
+    // consecutive points of a scan mostly fall into the same cell: a lane whose left neighbour carries the same key
+    // leaves the insertion (a probe of the table at least) to it
+    const u64 left = __shfl_up(key, 1, 64);
+    if ((threadIdx.x & 63) != 0 && left == key) return;
     if (key == 0) return;  // the reference inserts key 0 here and then hits UB
+    insert_with_ancestors(t, key, cnt, list, list_cap);
+}
+
+// the same from the Morton-ordered copy of the points (asr_geom_presort): runs of equal keys along a wave
+__global__ void k_octree_insert_sorted(asr_octree_frame f, const float4* sorted, const float* srad, i64 n,
+                                       float radius_scale, int max_depth, HashTab t, int* cnt, u64* list, int list_cap) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    u64 key = 0;
+    if (i < n) {
+        const float4 p = sorted[i];
+        const float r = srad[i];
+        if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(r))) {
+            cnt[11] = 1;
+        } else if (!(p.x < f.bb_min[0] || p.y < f.bb_min[1] || p.z < f.bb_min[2] || p.x > f.bb_max[0] ||
+                     p.y > f.bb_max[1] || p.z > f.bb_max[2])) {
+            int level = level_from_scale(f, radius_scale * r);
+            level = level < max_depth ? level : max_depth;
+            int x, y, z;
+            frame_coord(f, p.x, p.y, p.z, level, x, y, z);
+            key = asr_coord_key(x, y, z, level);
+        }
+    }
+    const u64 left = __shfl_up(key, 1, 64);
+    if ((threadIdx.x & 63) != 0 && left == key) return;
+    if (key == 0) return;
     insert_with_ancestors(t, key, cnt, list, list_cap);
 }
 
@@ -249,6 +281,15 @@ __global__ void k_leaf_flags(HashTab t, const u64* nodes, i64 n, uint8_t* flags)
     if (i >= n) return;
     const u64 k = nodes[i];
     flags[i] = (k != 0 && !((__clzll((long long)k) > 1) && tab_contains(t, k << 3))) ? 1 : 0;
+}
+
+// number of leaves + first / last leaf key in one read-back (the levels of the leaves are the query levels of the
+// aggregation search)
+__global__ void k_leaf_tail(const u64* leaves, const i64* num, i64* out3) {
+    const i64 n = *num;
+    out3[0] = n;
+    out3[1] = n > 0 ? (i64)leaves[0] : 0;
+    out3[2] = n > 0 ? (i64)leaves[n - 1] : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -423,6 +464,30 @@ __global__ void k_coarsen_up(const u64* keys, i64 v, const int32_t* sorted_src, 
         up_kidx[i] = 8;
     }
 }
+// The inverted up lists ("down" lists, net_definitions_torch.py:548-559) follow from the same facts without the
+// generic inversion (histogram + scan + stable sort): coarse voxel p owns either its eight consecutive children
+// (slots 0..7) or the one carried voxel (slot 8), in ascending fine index -- the order of
+// open3d::invert_neighbors_list.  cnt[p] feeds the exclusive scan that gives the row splits.
+__global__ void k_coarsen_down_count(const u64* keys, i64 v, const int32_t* sorted_src, i64 v_out, i64* cnt) {
+    i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (p > v_out) return;
+    cnt[p] = p < v_out ? (merged_head(keys, v, sorted_src[p]) ? 8 : 1) : 0;
+}
+__global__ void k_coarsen_down_fill(const u64* keys, i64 v, const int32_t* sorted_src, i64 v_out, const i64* rs,
+                                    int32_t* down_idx, uint8_t* down_kidx) {
+    i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (p >= v_out) return;
+    const i64 i = sorted_src[p], o = rs[p];
+    if (merged_head(keys, v, i)) {
+        for (int j = 0; j < 8; ++j) {
+            down_idx[o + j] = (int32_t)(i + j);
+            down_kidx[o + j] = (uint8_t)j;
+        }
+    } else {
+        down_idx[o] = (int32_t)i;
+        down_kidx[o] = 8;
+    }
+}
 __global__ void k_iota64(i64* out, i64 n) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = i;
@@ -467,13 +532,15 @@ __global__ void k_point_codes(asr_octree_frame f, const float* pts, i64 n, u64* 
     codes[i] = asr_morton3d((u64)x, (u64)y, (u64)z);
     ids[i] = (int32_t)i;
 }
-__global__ void k_gather_points(const float* pts, const int32_t* ids, i64 n, float4* sorted, int32_t* rank) {
+__global__ void k_gather_points(const float* pts, const int32_t* ids, i64 n, float4* sorted, int32_t* rank,
+                                const float* radii = nullptr, float* srad = nullptr) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i >= n) return;
     int32_t id = ids[i];
     sorted[i] = make_float4(pts[3 * (i64)id], pts[3 * (i64)id + 1], pts[3 * (i64)id + 2],
                             __int_as_float(id));
     if (rank) rank[id] = (int32_t)i;  // original index -> position in Morton order
+    if (srad) srad[i] = radii[id];    // per-point radii in Morton order (k_gather_radii in the same pass)
 }
 // per-point radii in Morton order (the compat factor of a pair then reads next to its neighbours)
 __global__ void k_gather_radii(const float* radii, const int32_t* ids, i64 n, float* out) {
@@ -629,6 +696,23 @@ __device__ inline void cell_range(const CellIndex& ci, u64 cell, int lev, int& b
     cnt = lo2 - lo;
 }
 
+template <int NCELL>
+__device__ inline int cells_prefix(int b, int n, int lane, int* s_pref, int* s_beg) {
+    int pre = n;  // inclusive prefix of n over lanes 0..NCELL-1
+#pragma unroll
+    for (int o = 1; o < (NCELL > 32 ? 64 : 32); o <<= 1) {
+        int up = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += up;
+    }
+    if (lane < NCELL) {
+        s_pref[lane + 1] = pre;
+        s_beg[lane] = b;
+    }
+    if (lane == 0) s_pref[0] = 0;
+    const int total = __shfl(pre, NCELL - 1, 64);
+    __builtin_amdgcn_wave_barrier();
+    return total;
+}
 __device__ inline int radius_cells(const asr_octree_frame& f, const CellIndex& ci, float cx, float cy, float cz,
                                    float r, int lane, int* s_pref, int* s_beg) {
     const int lev = query_level(f, r);
@@ -641,25 +725,51 @@ __device__ inline int radius_cells(const asr_octree_frame& f, const CellIndex& c
         if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
             cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b, n);
     }
-    int pre = n;  // inclusive prefix of n over lanes 0..26
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        int up = __shfl_up(pre, o, 64);
-        if (lane >= o) pre += up;
+    return cells_prefix<27>(b, n, lane, s_pref, s_beg);
+}
+
+// ------------------------------------------------------------------------------------------
+// ALIGNED queries (the aggregation search proper): query q is the centre of the grid voxel `keys[q]` = cell
+// (x, y, z) of level L with radius = that level's cell size s.  The ball is then covered EXACTLY by the 4 x 4 x 4
+// half-size cells (level L + 1) [2x-1, 2x+2]^3 -- a cube of side 2 s holding 1.9x the hits instead of the 6.4x of
+// the 3 x 3 x 3 full-size cells.  "Exactly" has no margin, and the cell of a point (floor of a float product) and
+// the centre of a voxel (a double rounded to float) carry rounding errors of up to 3 M 2^-24 level-21 units
+// (M = largest coordinate magnitude in those units): a hit may sit in one of the first T = 2 + floor(3 M 2^-24)
+// level-21 layers beyond a face of the cube -- then within sqrt(2 S T) + 2 T units of the axis through the voxel
+// centre (S = voxel size in units), i.e. the "pole" of the ball.  k_radius_extras finds exactly those (point,
+// voxel) pairs -- integer tests on the point codes, a handful of candidates per million points -- and the query
+// kernels take them as additional candidates.  Levels whose half cell is narrower than 16 T units (and level 21)
+// keep the 3 x 3 x 3 block of full-size cells, whose margin is half a cell.
+// ------------------------------------------------------------------------------------------
+constexpr int EXTRA_CAP = 1 << 16;
+struct AlignedQ {
+    const u64* keys;     // sorted voxel keys, one per query
+    const int2* extras;  // (query, position in Morton order) pairs beyond the cube
+    const int* extras_cnt;
+    int lhalf_max;       // finest voxel level that uses half cells
+};
+__device__ inline int aligned_cells(const CellIndex& ci, const AlignedQ& aq, u64 key, int lane, int* s_pref, int* s_beg) {
+    int x, y, z, lev;
+    asr_key_coord(key, x, y, z, lev);
+    int b = 0, n = 0;
+    if (lev <= aq.lhalf_max) {
+        const int lim = (2 << lev) - 1;
+        const int xx = 2 * x - 1 + (lane & 3), yy = 2 * y - 1 + ((lane >> 2) & 3), zz = 2 * z - 1 + (lane >> 4);
+        if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
+            cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev + 1, b, n);
+    } else if (lane < 27) {
+        const int lim = (1 << lev) - 1;
+        const int xx = x + lane % 3 - 1, yy = y + (lane / 3) % 3 - 1, zz = z + lane / 9 - 1;
+        if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
+            cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b, n);
     }
-    if (lane < 27) {
-        s_pref[lane + 1] = pre;
-        s_beg[lane] = b;
-    }
-    if (lane == 0) s_pref[0] = 0;
-    const int total = __shfl(pre, 26, 64);
-    __builtin_amdgcn_wave_barrier();
-    return total;
+    return cells_prefix<64>(b, n, lane, s_pref, s_beg);
 }
 // candidate i of the concatenated cell ranges
+template <int NCELL = 27>
 __device__ inline float4 radius_candidate(const float4* sorted, const int* s_pref, const int* s_beg, int i,
                                           int* pos_out = nullptr) {
-    int lo = 0, hi = 27;  // cell c with pref[c] <= i < pref[c+1]
+    int lo = 0, hi = NCELL;  // cell c with pref[c] <= i < pref[c+1]
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (s_pref[mid] <= i)
@@ -672,52 +782,65 @@ __device__ inline float4 radius_candidate(const float4* sorted, const int* s_pre
     return sorted[pos];
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
-                                                      const float* centers, const float* sizes,
-                                                      i64 v, CellIndex ci, i64* counts, u64* tmp,
-                                                      int32_t* heavy_out, int* heavy_cnt,
-                                                      uint8_t* is_heavy) {
-    __shared__ int s_pref[4][28];
-    __shared__ int s_beg[4][28];
-    __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
-    __shared__ int s_pos[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const i64 q = blockIdx.x * (i64)4 + wave;
-    if (q == v && lane == 0) counts[v] = 0;
-    if (q >= v) return;
-    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
-    const float r = sizes[q];
-    const float r2 = r * r;
-    const int total = radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
-    i64 found = 0;
-    bool heavy = MODE == 2 && total > RADIUS_GIANT;
-    for (int i0 = 0; i0 < total && !heavy; i0 += 64) {
-        const int i = i0 + lane;
-        bool hit = false;
-        float d = 0.f;
-        int id = 0, pos = 0;
-        if (i < total) {
-            const float4 pt = radius_candidate(sorted, s_pref[wave], s_beg[wave], i, &pos);
-            d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
-            hit = d < r2;
-            id = __float_as_int(pt.w);
-        }
-        const unsigned long long m = __ballot(hit);
-        if (MODE == 2 && hit) {
-            const i64 o = found + __popcll(m & ((1ull << lane) - 1));
-            if (o < RADIUS_LIGHT) {
-                s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
-                s_pos[wave][o] = pos;
+// the (voxel, point) pairs of the rounding margin, see above.  One thread per point (position s in Morton order).
+struct ExtraParams {
+    int lmin, lmax;  // voxel levels to test (<= lhalf_max)
+    int T;
+    int rho[ASR_MAX_LEVEL + 1];  // pole radius in level-21 units per voxel level
+};
+__global__ void k_radius_extras(const u64* codes, const float4* sorted, i64 n, const u64* keys, i64 v, const float* centers,
+                                const float* sizes, ExtraParams ep, int2* out, int* out_cnt) {
+    const i64 s = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const u64 code = codes[s];
+    const int c[3] = {(int)asr_compact21(code), (int)asr_compact21(code >> 1), (int)asr_compact21(code >> 2)};
+    for (int lev = ep.lmin; lev <= ep.lmax; ++lev) {
+        const int sh = ASR_MAX_LEVEL - lev, H = 1 << (sh - 1), S = 1 << sh;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int A = c[a] + H, m = A & (S - 1);
+            int xa;
+            if (m < ep.T)
+                xa = (A >> sh) - 2;  // beyond the + face of voxel xa
+            else if (m >= S - ep.T)
+                xa = (A >> sh) + 1;  // beyond the - face
+            else
+                continue;
+            const int b0 = (a + 1) % 3, b1 = (a + 2) % 3;
+            const int y0 = c[b0] >> sh, y1 = c[b1] >> sh;
+            if (abs(c[b0] - (y0 * S + H)) > ep.rho[lev] || abs(c[b1] - (y1 * S + H)) > ep.rho[lev]) continue;
+            int xyz[3];
+            xyz[a] = xa;
+            xyz[b0] = y0;
+            xyz[b1] = y1;
+            const u64 key = asr_coord_key(xyz[0], xyz[1], xyz[2], lev);
+            if (!key) continue;
+            i64 lo = 0, hi = v;  // first voxel key >= key
+            while (lo < hi) {
+                const i64 mid = (lo + hi) >> 1;
+                if (keys[mid] < key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            if (lo >= v || keys[lo] != key) continue;
+            const float4 pt = sorted[s];
+            const float r = sizes[lo];
+            if (sqdist3(pt.x, pt.y, pt.z, centers[3 * lo], centers[3 * lo + 1], centers[3 * lo + 2]) < r * r) {
+                const int o = atomicAdd(out_cnt, 1);
+                if (o < EXTRA_CAP) out[o] = make_int2((int)lo, (int)s);
             }
         }
-        found += __popcll(m);
-        if (MODE == 2 && found > RADIUS_LIGHT) heavy = true;
     }
-    if (MODE == 0) {
-        if (lane == 0) counts[q] = found;
-        return;
-    }
+}
+
+// end of a row of the aggregation search (MODE 2): the wave holds `found` hits, the first RADIUS_LIGHT of them as
+// (distance bits | index) keys + Morton positions in LDS.  Heavy rows go to the list of k_radius_heavy; the others
+// are ranked inside the wave (rank = number of smaller keys, keys are unique) and written, sorted, to the row's fixed
+// slot tmp[q * RADIUS_LIGHT ..] as (distance, position in Morton order): k_radius_place turns the position back into
+// the index with a clustered read.
+__device__ inline void radius_row_out(i64 q, i64 found, bool heavy, int lane, const u64* s_keys, const int* s_pos,
+                                      i64* counts, u64* tmp, int32_t* heavy_out, int* heavy_cnt, uint8_t* is_heavy) {
     if (heavy) {  // counted and written by k_radius_heavy
         if (lane == 0) {
             counts[q] = 0;
@@ -732,19 +855,17 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     }
     __builtin_amdgcn_wave_barrier();
     const int h = (int)found;
-    // rows are ordered by (squared distance, ORIGINAL index); what is stored is (distance, position in
-    // Morton order): k_radius_place turns the position back into the index with a clustered read
     u64 mine[RADIUS_LIGHT / 64];
     int mypos[RADIUS_LIGHT / 64];
     int rank[RADIUS_LIGHT / 64];
 #pragma unroll
     for (int u = 0; u < RADIUS_LIGHT / 64; ++u) {
-        mine[u] = lane + 64 * u < h ? s_keys[wave][lane + 64 * u] : 0;
-        mypos[u] = lane + 64 * u < h ? s_pos[wave][lane + 64 * u] : 0;
+        mine[u] = lane + 64 * u < h ? s_keys[lane + 64 * u] : 0;
+        mypos[u] = lane + 64 * u < h ? s_pos[lane + 64 * u] : 0;
         rank[u] = 0;
     }
     for (int j = 0; j < h; ++j) {  // LDS broadcast reads
-        const u64 kj = s_keys[wave][j];
+        const u64 kj = s_keys[j];
 #pragma unroll
         for (int u = 0; u < RADIUS_LIGHT / 64; ++u) rank[u] += kj < mine[u];
     }
@@ -753,39 +874,206 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
         if (lane + 64 * u < h) tmp[q * RADIUS_LIGHT + rank[u]] = (mine[u] & 0xffffffff00000000ull) | (u32)mypos[u];
 }
 
+// ------------------------------------------------------------------------------------------
+// Aggregation search, one wave per SIBLING GROUP of voxels.  The leaves that share a parent (X, Y, Z) of level
+// L - 1 are consecutive in the sorted key array; their balls (radius = cell size s of level L, centres at the cell
+// centres) lie inside the 4 x 4 x 4 block of level-L cells [2X-1, 2X+2]^3 with half a cell of margin on every side.
+// The wave looks those 64 cells up ONCE (8 table probes per voxel instead of 27 .. 64), stages their points in LDS
+// and tests them against each of its up to eight voxels from there.  On a surface-like cloud the block holds about
+// as many points as two separate 3^3 blocks.  Blocks with more than GROUP_CAP points (dense spots next to coarse
+// voxels) hand their voxels to the per-voxel kernel through a list.
+// ------------------------------------------------------------------------------------------
+constexpr int GROUP_CAP = 512;
+__global__ void k_group_heads(const u64* keys, i64 v, int32_t* heads, int* cnt) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    const bool head = i < v && (i == 0 || (keys[i] >> 3) != (keys[i - 1] >> 3));
+    const int o = block_append(head, cnt);
+    if (head) heads[o] = (int32_t)i;
+}
+__global__ __launch_bounds__(256) void k_radius_groups(const float4* sorted, const u64* keys, const float* centers,
+                                                       const float* sizes, i64 v, const int32_t* heads, const int* num_heads,
+                                                       CellIndex ci, i64* counts, u64* tmp, int32_t* heavy_out,
+                                                       int* heavy_cnt, uint8_t* is_heavy, int32_t* fb_list, int* fb_cnt) {
+    __shared__ int s_pref[4][65];
+    __shared__ int s_beg[4][64];
+    __shared__ float4 s_pt[4][GROUP_CAP];
+    __shared__ int s_cpos[4][GROUP_CAP];
+    __shared__ u64 s_keys[4][RADIUS_LIGHT];
+    __shared__ int s_pos[4][RADIUS_LIGHT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ng = *num_heads;
+    for (i64 g = blockIdx.x * (i64)4 + wave; g < ng; g += (i64)gridDim.x * 4) {
+        const i64 h = heads[g];
+        const u64 key0 = keys[h];
+        const u64 parent = key0 >> 3;
+        const bool member = lane < 8 && h + lane < v && (keys[h + lane] >> 3) == parent;
+        const int nm = __popcll(__ballot(member));  // the leaves of one parent are consecutive
+        const int lev = asr_key_level(key0);
+        int total = GROUP_CAP + 1;
+        __builtin_amdgcn_wave_barrier();  // the LDS tables of the previous group have been read
+        if (lev > 0) {
+            int X, Y, Z, pl;
+            asr_key_coord(parent, X, Y, Z, pl);
+            const int lim = (1 << lev) - 1;
+            const int xx = 2 * X - 1 + (lane & 3), yy = 2 * Y - 1 + ((lane >> 2) & 3), zz = 2 * Z - 1 + (lane >> 4);
+            int b = 0, n = 0;
+            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
+                cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b, n);
+            total = cells_prefix<64>(b, n, lane, s_pref[wave], s_beg[wave]);
+        }
+        if (total > GROUP_CAP) {  // per-voxel kernel
+            int base = 0;
+            if (lane == 0) base = atomicAdd(fb_cnt, nm);
+            base = __shfl(base, 0, 64);
+            if (lane < nm) fb_list[base + lane] = (int32_t)(h + lane);
+            continue;
+        }
+        for (int i = lane; i < total; i += 64) {
+            int pos;
+            s_pt[wave][i] = radius_candidate<64>(sorted, s_pref[wave], s_beg[wave], i, &pos);
+            s_cpos[wave][i] = pos;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int m = 0; m < nm; ++m) {
+            const i64 q = h + m;
+            const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
+            const float r = sizes[q];
+            const float r2 = r * r;
+            i64 found = 0;
+            bool heavy = false;
+            for (int i0 = 0; i0 < total && !heavy; i0 += 64) {
+                const int i = i0 + lane;
+                bool hit = false;
+                float d = 0.f;
+                int id = 0, pos = 0;
+                if (i < total) {
+                    const float4 pt = s_pt[wave][i];
+                    d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+                    hit = d < r2;
+                    id = __float_as_int(pt.w);
+                    pos = s_cpos[wave][i];
+                }
+                const unsigned long long mk = __ballot(hit);
+                if (hit) {
+                    const i64 o = found + __popcll(mk & ((1ull << lane) - 1));
+                    if (o < RADIUS_LIGHT) {
+                        s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+                        s_pos[wave][o] = pos;
+                    }
+                }
+                found += __popcll(mk);
+                if (found > RADIUS_LIGHT) heavy = true;
+            }
+            radius_row_out(q, found, heavy, lane, s_keys[wave], s_pos[wave], counts, tmp, heavy_out, heavy_cnt, is_heavy);
+            __builtin_amdgcn_wave_barrier();  // s_keys is reused by the next voxel
+        }
+    }
+}
+
+template <int MODE, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
+                                                      const float* centers, const float* sizes,
+                                                      i64 v, CellIndex ci, AlignedQ aq, i64* counts, u64* tmp,
+                                                      int32_t* heavy_out, int* heavy_cnt,
+                                                      uint8_t* is_heavy, const int32_t* list, const int* list_cnt) {
+    constexpr int NCELL = ALIGNED ? 64 : 27;
+    __shared__ int s_pref[4][NCELL + 1];
+    __shared__ int s_beg[4][NCELL];
+    __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
+    __shared__ int s_pos[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // all queries 0..v (launch of ceil((v + 1) / 4) blocks), or -- grid-stride -- the queries of a device-side list
+    const i64 nq = list ? (i64)*list_cnt : v + 1;
+    for (i64 qi = blockIdx.x * (i64)4 + wave; qi < nq; qi += (i64)gridDim.x * 4) {
+    const i64 q = list ? (i64)list[qi] : qi;
+    if (q == v && lane == 0) counts[v] = 0;
+    if (q >= v) continue;
+    __builtin_amdgcn_wave_barrier();  // the LDS tables of the previous query have been read
+    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
+    const float r = sizes[q];
+    const float r2 = r * r;
+    const int total = ALIGNED ? aligned_cells(ci, aq, aq.keys[q], lane, s_pref[wave], s_beg[wave])
+                              : radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
+    i64 found = 0;
+    bool heavy = MODE == 2 && total > RADIUS_GIANT;
+    auto consume = [&](bool hit, float d, int id, int pos) {
+        const unsigned long long m = __ballot(hit);
+        if (MODE == 2 && hit) {
+            const i64 o = found + __popcll(m & ((1ull << lane) - 1));
+            if (o < RADIUS_LIGHT) {
+                s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+                s_pos[wave][o] = pos;
+            }
+        }
+        found += __popcll(m);
+        if (MODE == 2 && found > RADIUS_LIGHT) heavy = true;
+    };
+    for (int i0 = 0; i0 < total && !heavy; i0 += 64) {
+        const int i = i0 + lane;
+        bool hit = false;
+        float d = 0.f;
+        int id = 0, pos = 0;
+        if (i < total) {
+            const float4 pt = radius_candidate<NCELL>(sorted, s_pref[wave], s_beg[wave], i, &pos);
+            d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+            hit = d < r2;
+            id = __float_as_int(pt.w);
+        }
+        consume(hit, d, id, pos);
+    }
+    if (ALIGNED) {  // the pairs of the rounding margin (k_radius_extras): normally none at all
+        const int nex = min(*aq.extras_cnt, EXTRA_CAP);
+        for (int e0 = 0; e0 < nex && !heavy; e0 += 64) {
+            const int e = e0 + lane;
+            bool hit = false;
+            float d = 0.f;
+            int id = 0, pos = 0;
+            if (e < nex) {
+                const int2 it = aq.extras[e];
+                if (it.x == (int)q) {
+                    pos = it.y;
+                    const float4 pt = sorted[pos];
+                    d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+                    hit = d < r2;
+                    id = __float_as_int(pt.w);
+                }
+            }
+            if (__ballot(hit)) consume(hit, d, id, pos);
+        }
+    }
+    if (MODE == 0) {
+        if (lane == 0) counts[q] = found;
+        continue;
+    }
+    radius_row_out(q, found, heavy, lane, s_keys[wave], s_pos[wave], counts, tmp, heavy_out, heavy_cnt, is_heavy);
+    }
+}
+
 // Heavy rows: RADIUS_SPLIT blocks per row, each block walks 1/RADIUS_SPLIT of the candidates.
 // FILL = false: accumulates the hit count into counts[q]; FILL = true: writes the (distance, index)
 // keys at hoff[j] + cursor (any order: the rows are sorted by a segmented sort afterwards).
-template <bool FILL>
+template <bool FILL, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const float4* sorted, const float* centers,
-                                                      const float* sizes, const int32_t* heavy, CellIndex ci,
+                                                      const float* sizes, const int32_t* heavy, CellIndex ci, AlignedQ aq,
                                                       i64* counts, const i64* hoff, int* cursor, u64* keys_out,
                                                       int32_t* row_out) {
-    __shared__ int s_pref[4][28];
-    __shared__ int s_beg[4][28];
+    constexpr int NCELL = ALIGNED ? 64 : 27;
+    __shared__ int s_pref[4][NCELL + 1];
+    __shared__ int s_beg[4][NCELL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x;
     const i64 q = heavy[j];
     const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
     const float r = sizes[q];
     const float r2 = r * r;
-    const int total = radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
+    const int total = ALIGNED ? aligned_cells(ci, aq, aq.keys[q], lane, s_pref[wave], s_beg[wave])
+                              : radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
     int per = (total + RADIUS_SPLIT - 1) / RADIUS_SPLIT;
     per = (per + 255) & ~255;  // whole 4-wave rounds
     const int lo = blockIdx.y * per;
     const int hi = min(total, lo + per);
     unsigned long long found = 0;
-    for (int i0 = lo + wave * 64; i0 < hi; i0 += 256) {
-        const int i = i0 + lane;
-        bool hit = false;
-        float d = 0.f;
-        int id = 0;
-        if (i < hi) {
-            const float4 pt = radius_candidate(sorted, s_pref[wave], s_beg[wave], i);
-            d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
-            hit = d < r2;
-            id = __float_as_int(pt.w);
-        }
+    auto consume = [&](bool hit, float d, int id) {
         const unsigned long long m = __ballot(hit);
         if (FILL && m) {
             int o0 = 0;
@@ -798,6 +1086,38 @@ __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const 
             }
         }
         found += __popcll(m);
+    };
+    for (int i0 = lo + wave * 64; i0 < hi; i0 += 256) {
+        const int i = i0 + lane;
+        bool hit = false;
+        float d = 0.f;
+        int id = 0;
+        if (i < hi) {
+            const float4 pt = radius_candidate<NCELL>(sorted, s_pref[wave], s_beg[wave], i);
+            d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+            hit = d < r2;
+            id = __float_as_int(pt.w);
+        }
+        consume(hit, d, id);
+    }
+    if (ALIGNED && blockIdx.y == 0 && wave == 0) {  // pairs of the rounding margin, once per row
+        const int nex = min(*aq.extras_cnt, EXTRA_CAP);
+        for (int e0 = 0; e0 < nex; e0 += 64) {
+            const int e = e0 + lane;
+            bool hit = false;
+            float d = 0.f;
+            int id = 0;
+            if (e < nex) {
+                const int2 it = aq.extras[e];
+                if (it.x == (int)q) {
+                    const float4 pt = sorted[it.y];
+                    d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
+                    hit = d < r2;
+                    id = __float_as_int(pt.w);
+                }
+            }
+            if (__ballot(hit)) consume(hit, d, id);
+        }
     }
     if (!FILL && lane == 0 && found) atomicAdd((unsigned long long*)&counts[q], found);
 }
@@ -1502,7 +1822,7 @@ int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, con
 
 // Result: ctx->nodes / ctx->leaves (sorted) in the persist arena.
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                          const float* radii, i64 n, float radius_scale, int max_depth) {
+                          const float* radii, i64 n, float radius_scale, int max_depth, const AsrPointIndex* pre) {
     ASR_TRY(ensure_flags(ctx));
     if (max_depth > ASR_MAX_LEVEL) max_depth = ASR_MAX_LEVEL;
     if (max_depth < 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "max_depth must be >= 0");
@@ -1520,8 +1840,12 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
         if (!list || !flag) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
         if (n > 0) {
-            k_octree_insert_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
-                    *frame, pts, radii, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);
+            if (pre && pre->valid && pre->n == n && pre->srad)
+                k_octree_insert_sorted<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
+                        *frame, pre->sorted, pre->srad, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);
+            else
+                k_octree_insert_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
+                        *frame, pts, radii, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);
             ASR_CHECK_LAUNCH(ctx);
         }
         ASR_TRY(read_flags(ctx, host));
@@ -1542,6 +1866,7 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
         }
         if (overflow) continue;
         i64 num_nodes = (i64)host[0] + (host[9] ? 1 : 0);
+        ctx->leaf_lmin = ctx->leaf_lmax = -1;
         if (num_nodes == 0) {
             ctx->num_nodes = ctx->num_leaves = 0;
             ctx->nodes = ctx->leaves = nullptr;
@@ -1569,8 +1894,17 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
             ASR_HIP_CHECK(ctx, rocprim::select(tmp, tb, ctx->nodes, lflag, leaves_tmp, d_num, (size_t)num_nodes,
                                                ctx->stream));
         }
-        i64 num_leaves = 0;
-        ASR_TRY(read_i64(ctx, d_num, &num_leaves));
+        i64* d_tail = arena_alloc<i64>(ctx->scratch, 3);
+        if (!d_tail) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_leaf_tail<<<1, 1, 0, ctx->stream>>>(leaves_tmp, d_num, d_tail);
+        ASR_CHECK_LAUNCH(ctx);
+        i64 tail[3] = {0, 0, 0};
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(tail, d_tail, sizeof(tail), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const i64 num_leaves = tail[0];
+        auto level_of = [](u64 k) { return k ? (63 - __builtin_clzll(k)) / 3 : 0; };
+        ctx->leaf_lmin = level_of((u64)tail[1]);
+        ctx->leaf_lmax = level_of((u64)tail[2]);
         ctx->leaves = arena_alloc<u64>(ctx->persist, num_leaves);
         if (!ctx->leaves) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->leaves, leaves_tmp, 8 * num_leaves, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1581,9 +1915,9 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
     ASR_FAIL(ctx, ASR_HIP_ELOGIC, "octree hash table overflow after 6 growth attempts");
 }
 
-static int build_key_map(asr_hip_context* ctx, const u64* keys, i64 v, HashTab& t) {
+static int build_key_map(asr_hip_context* ctx, const u64* keys, i64 v, HashTab& t, int grow = 0) {
     ASR_TRY(ensure_flags(ctx));
-    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * v));
+    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * v)) << grow;
     ASR_TRY(make_table(ctx, ctx->scratch, cap, true, t));
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
     k_map_build<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, ctx->d_flags);
@@ -1619,27 +1953,36 @@ int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const 
 // fused variant for the whole-path driver: one map build, masks carried from count to fill.
 int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* keys, i64 v,
                              i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs) {
-    HashTab t;
-    ASR_TRY(build_key_map(ctx, keys, v, t));
-    i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
-    u64* masks = arena_alloc<u64>(ctx->scratch, v);
     i64* rs = arena_alloc<i64>(out_arena, v + 1);
-    int32_t* st_idx = arena_alloc<int32_t>(ctx->scratch, (size_t)v * NB_STAGE);
-    uint8_t* st_slot = arena_alloc<uint8_t>(ctx->scratch, (size_t)v * NB_STAGE);
-    if (!counts || !masks || !rs || !st_idx || !st_slot) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, masks, st_idx, st_slot);
-    ASR_CHECK_LAUNCH(ctx);
-    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
-    ASR_TRY(read_i64(ctx, rs + v, num_pairs));
-    int32_t* idx = arena_alloc<int32_t>(out_arena, *num_pairs);
-    uint8_t* kidx = arena_alloc<uint8_t>(out_arena, *num_pairs);
-    if (!idx || !kidx) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, masks, st_idx, st_slot, idx, kidx);
-    ASR_CHECK_LAUNCH(ctx);
-    *rs_out = rs;
-    *idx_out = idx;
-    *kidx_out = kidx;
-    return ASR_HIP_OK;
+    if (!rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    for (int grow = 0;; grow += 2) {  // a key map that overflowed (see TabProbe) is rebuilt four times the size
+        HashTab t;
+        ASR_TRY(build_key_map(ctx, keys, v, t, grow));
+        i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
+        u64* masks = arena_alloc<u64>(ctx->scratch, v);
+        int32_t* st_idx = arena_alloc<int32_t>(ctx->scratch, (size_t)v * NB_STAGE);
+        uint8_t* st_slot = arena_alloc<uint8_t>(ctx->scratch, (size_t)v * NB_STAGE);
+        if (!counts || !masks || !st_idx || !st_slot) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, masks, st_idx, st_slot);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
+        int host[16];
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(host, ctx->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_TRY(read_i64(ctx, rs + v, num_pairs));  // synchronises: the flags have arrived as well
+        if (host[1]) {
+            if (grow >= 6) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "voxel key map overflow");
+            continue;
+        }
+        int32_t* idx = arena_alloc<int32_t>(out_arena, *num_pairs);
+        uint8_t* kidx = arena_alloc<uint8_t>(out_arena, *num_pairs);
+        if (!idx || !kidx) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, masks, st_idx, st_slot, idx, kidx);
+        ASR_CHECK_LAUNCH(ctx);
+        *rs_out = rs;
+        *idx_out = idx;
+        *kidx_out = kidx;
+        return ASR_HIP_OK;
+    }
 }
 
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
@@ -1763,7 +2106,8 @@ int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_
     return ASR_HIP_OK;
 }
 int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out_keys, i64 v_out,
-                          int32_t* up_idx, uint8_t* up_kidx, i64* up_rs) {
+                          int32_t* up_idx, uint8_t* up_kidx, i64* up_rs, int32_t* down_idx, uint8_t* down_kidx,
+                          i64* down_rs) {
     ASR_TRY(ensure_flags(ctx));
     if (v <= 0) return ASR_HIP_OK;
     u64* k_u = arena_alloc<u64>(ctx->scratch, v_out);
@@ -1777,6 +2121,58 @@ int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out
     k_coarsen_up<<<grid_for(v_out, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, v_out, up_idx, up_kidx);
     ASR_CHECK_LAUNCH(ctx);
     k_iota64<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(up_rs, v + 1);
+    ASR_CHECK_LAUNCH(ctx);
+    if (down_rs) {  // the inverted lists, rows = coarse voxels
+        i64* cnt = arena_alloc<i64>(ctx->scratch, v_out + 1);
+        if (!cnt) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_coarsen_down_count<<<grid_for(v_out + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, v_out, cnt);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(scan_counts(ctx, ctx->scratch, cnt, down_rs, v_out + 1));
+        k_coarsen_down_fill<<<grid_for(v_out, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, v_out, down_rs, down_idx,
+                                                                          down_kidx);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    return ASR_HIP_OK;
+}
+
+// Whole-path variant: ONE pass over the fine keys (the emit kernel counts while it appends: no separate counting
+// kernel), one size read-back, outputs allocated from `keep`.
+int asr_geom_coarsen_build(asr_hip_context* ctx, Arena& keep, const u64* keys, i64 v, u64** out_keys, i64* v_out,
+                           int32_t** up_idx, uint8_t** up_kidx, i64** up_rs, int32_t** down_idx, uint8_t** down_kidx,
+                           i64** down_rs) {
+    ASR_TRY(ensure_flags(ctx));
+    *v_out = 0;
+    if (v <= 0) return ASR_HIP_OK;
+    u64* k_u = arena_alloc<u64>(ctx->scratch, v);  // V_out <= V
+    int32_t* s_u = arena_alloc<int32_t>(ctx->scratch, v);
+    int32_t* s_s = arena_alloc<int32_t>(ctx->scratch, v);
+    if (!k_u || !s_u || !s_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    k_coarsen_emit<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, k_u, s_u, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    int host[16];
+    ASR_TRY(read_flags(ctx, host));
+    const i64 vo = host[5];
+    *v_out = vo;
+    *out_keys = arena_alloc<u64>(keep, vo);
+    *up_idx = arena_alloc<int32_t>(keep, v);
+    *up_kidx = arena_alloc<uint8_t>(keep, v);
+    *up_rs = arena_alloc<i64>(keep, v + 1);
+    *down_idx = arena_alloc<int32_t>(keep, v);
+    *down_kidx = arena_alloc<uint8_t>(keep, v);
+    *down_rs = arena_alloc<i64>(keep, vo + 1);
+    i64* cnt = arena_alloc<i64>(ctx->scratch, vo + 1);
+    if (!*out_keys || !*up_idx || !*up_kidx || !*up_rs || !*down_idx || !*down_kidx || !*down_rs || !cnt)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, *out_keys, s_u, s_s, vo, 64)));
+    k_coarsen_up<<<grid_for(vo, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, vo, *up_idx, *up_kidx);
+    ASR_CHECK_LAUNCH(ctx);
+    k_iota64<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(*up_rs, v + 1);
+    ASR_CHECK_LAUNCH(ctx);
+    k_coarsen_down_count<<<grid_for(vo + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, vo, cnt);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(scan_counts(ctx, ctx->scratch, cnt, *down_rs, vo + 1));
+    k_coarsen_down_fill<<<grid_for(vo, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, vo, *down_rs, *down_idx, *down_kidx);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }
@@ -1813,6 +2209,12 @@ struct RadiusState {
     i64 num_heavy = 0;
     const u64* dual_leaves = nullptr;  // leaf array of the pending dual-cell count / fill pair
     i64 dual_nl = 0;
+    float* srad = nullptr;     // radii in Morton order (when the count call was given them)
+    const float* radii_src = nullptr;
+    int lsort = 0;             // the points are sorted on the code bits down to this level
+    int cell_grow = 0;         // log2 of the extra capacity of the cell table (sticky, raised after an overflow)
+    bool aligned = false;      // queries are voxel centres of `aq.keys`: half-size cells + margin pairs
+    AlignedQ aq = {nullptr, nullptr, nullptr, -1};
 };
 static RadiusState& rstate(asr_hip_context* ctx) {
     if (!ctx->radius_state) ctx->radius_state = new RadiusState();
@@ -1823,19 +2225,20 @@ void asr_geom_release(asr_hip_context* ctx) {
     ctx->radius_state = nullptr;
 }
 
-// points sorted by level-21 Morton code + hash map (cell, level) -> [start, end) for levels
-// lmin..lmax; everything lives in the scratch arena
+// points sorted by level-21 Morton code (sort_points) + hash map (cell, level) -> [start, end) for levels
+// lmin..lmax (build_cell_table)
 // `keep`: arena for the arrays that outlive the search (Morton-ordered points, ids, rank); the scratch
-// arena when null.  `want_rank`: also build the original index -> Morton position table.
-static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                             i64 n, int lmin, int lmax, RadiusState& st, Arena* keep = nullptr,
-                             bool want_rank = false, bool hash_all = true) {
-    int host[16];
+// arena when null.  `want_rank`: also build the original index -> Morton position table.  `radii`: gathered into
+// Morton order as well.  `lsort`: the points are grouped by their level-lsort cell (order inside such a cell:
+// input order); `keep_all`: the sorted codes go to `keep` too (asr_geom_presort: they outlive this call).
+static int sort_points(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts, i64 n, int lsort,
+                       RadiusState& st, Arena* keep, bool want_rank, const float* radii, bool keep_all = false) {
     st.frame = *frame;
     st.n = n;
+    st.lsort = lsort;
     Arena& ka = keep ? *keep : ctx->scratch;
     u64* codes_u = arena_alloc<u64>(ctx->scratch, n + 1);
-    u64* codes = arena_alloc<u64>(ctx->scratch, n + 1);
+    u64* codes = arena_alloc<u64>(keep_all ? ka : ctx->scratch, n + 1);
     int32_t* ids_u = arena_alloc<int32_t>(ctx->scratch, n + 1);
     int32_t* ids = arena_alloc<int32_t>(ka, n + 1);
     st.sorted = arena_alloc<float4>(ka, n + 1);
@@ -1846,19 +2249,32 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     st.ids_u = ids_u;
     st.ids_w = ids;
     st.rank = want_rank ? arena_alloc<int32_t>(ka, n + 1) : nullptr;
-    if (!codes_u || !codes || !ids_u || !ids || !st.sorted || (want_rank && !st.rank))
+    st.srad = radii ? arena_alloc<float>(keep_all ? ka : ctx->scratch, n + 1) : nullptr;
+    st.radii_src = radii;
+    if (!codes_u || !codes || !ids_u || !ids || !st.sorted || (want_rank && !st.rank) || (radii && !st.srad))
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
     if (n > 0) {
         k_point_codes<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, n, codes_u, ids_u, ctx->d_flags);
         ASR_CHECK_LAUNCH(ctx);
-        // the cell tables only cover levels lmin..lmax: the points need to be grouped by their level-lmax cell, the
-        // order inside such a cell is free (stable: input order) -- sort the top 3*lmax bits of the 63-bit code only
+        // the cell tables only cover levels up to lsort: sort the top 3*lsort bits of the 63-bit code only
         ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes_u, codes, ids_u, ids, n, 63,
-                                          3 * (ASR_MAX_LEVEL - std::max(lmax, 1)))));
-        k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted, st.rank);
+                                          3 * (ASR_MAX_LEVEL - std::max(lsort, 1)))));
+        k_gather_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(pts, ids, n, st.sorted, st.rank, radii, st.srad);
         ASR_CHECK_LAUNCH(ctx);
     }
+    return ASR_HIP_OK;
+}
+static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, RadiusState& st, bool hash_all);
+static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
+                             i64 n, int lmin, int lmax, RadiusState& st, Arena* keep = nullptr,
+                             bool want_rank = false, bool hash_all = true, const float* radii = nullptr) {
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(sort_points(ctx, frame, pts, n, lmax, st, keep, want_rank, radii));
+    return build_cell_table(ctx, n, lmin, lmax, st, hash_all);
+}
+static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, RadiusState& st, bool hash_all) {
+    int host[16];
+    const u64* codes = st.codes;
     HashTab dummy{nullptr, nullptr, 0};
     int* level_cnt = ctx->d_flags + 32;  // cells per level
     int host_lvl[ASR_MAX_LEVEL + 1] = {0};
@@ -1883,7 +2299,9 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     st.lhash = lhash;
     i64 cells = 0;
     for (int l = lmin; l <= lhash; ++l) cells += host_lvl[l];
-    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * cells));
+    // cell_grow: enlarged after an overflow (keys whose low bits are concentrated on few values -- points on a
+    // lattice -- crowd a few positions of the buckets, see TabProbe)
+    u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * cells)) << st.cell_grow;
     ASR_TRY(make_table(ctx, ctx->scratch, cap, false, st.tab));
     st.start = arena_alloc<int32_t>(ctx->scratch, cap);
     st.end = arena_alloc<int32_t>(ctx->scratch, cap);
@@ -1893,6 +2311,28 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
                 codes, n, lmin, lhash, st.tab, st.start, st.end, ctx->d_flags, nullptr);
         ASR_CHECK_LAUNCH(ctx);
     }
+    return ASR_HIP_OK;
+}
+
+constexpr int PRESORT_LEVEL = 13;  // cells of the aggregation search are rarely finer; deeper queries re-sort
+int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* frame, const float* pts,
+                     const float* radii, i64 n) {
+    ASR_TRY(ensure_flags(ctx));
+    AsrPointIndex& pi = ctx->pindex;
+    pi.valid = false;
+    if (n <= 0 || n >= (i64(1) << 31)) return ASR_HIP_OK;
+    RadiusState st;
+    ASR_TRY(sort_points(ctx, frame, pts, n, PRESORT_LEVEL, st, &keep, true, radii, true));
+    pi.pts = pts;
+    pi.radii = radii;
+    pi.n = n;
+    pi.lsort = PRESORT_LEVEL;
+    pi.sorted = st.sorted;
+    pi.ids = st.ids;
+    pi.rank = st.rank;
+    pi.srad = st.srad;
+    pi.codes = st.codes_w;
+    pi.valid = true;
     return ASR_HIP_OK;
 }
 
@@ -1913,7 +2353,8 @@ static int query_level_range(asr_hip_context* ctx, const asr_octree_frame* frame
 
 int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                           i64 n, const float* centers, const float* sizes, i64 v, i64* rs,
-                          i64* num_pairs, Arena* keep) {
+                          i64* num_pairs, Arena* keep, const float* radii, const u64* voxel_keys, int lmin_hint,
+                          int lmax_hint, const AsrPointIndex* pre) {
     ASR_TRY(ensure_flags(ctx));
     RadiusState& st = rstate(ctx);
     st.valid = false;
@@ -1925,26 +2366,109 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     if (n >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many points for int32 indices");
     int host[16];
     st.v = v;
-    int lmin, lmax;
-    ASR_TRY(query_level_range(ctx, frame, sizes, v, &lmin, &lmax));
-    ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st, keep, true, false));
+    int lmin = lmin_hint, lmax = lmax_hint;
+    if (lmin < 0 || lmax < lmin) ASR_TRY(query_level_range(ctx, frame, sizes, v, &lmin, &lmax));
+    // aligned queries (voxel_keys): half-size cells of level L + 1 for the voxel levels L <= lhalf_max (see AlignedQ)
+    st.aligned = voxel_keys != nullptr && ctx->opt.search_half != 0;
+    ExtraParams ep;
+    memset(&ep, 0, sizeof(ep));
+    int lhalf_max = -1;
+    if (st.aligned) {
+        double M = 1;
+        for (int d = 0; d < 3; ++d)
+            M = std::max(M, std::max(std::fabs((double)frame->offset[d]), std::fabs((double)(1 << ASR_MAX_LEVEL) - frame->offset[d])));
+        const int T = 2 + (int)std::floor(3.0 * (M + 1) / 16777216.0);
+        lhalf_max = ASR_MAX_LEVEL - 1;
+        while (lhalf_max >= 0 && (1 << (ASR_MAX_LEVEL - 1 - lhalf_max)) < 16 * T) --lhalf_max;
+        ep.T = T;
+        ep.lmin = lmin;
+        ep.lmax = std::min(lmax, lhalf_max);
+        for (int l = 0; l <= ASR_MAX_LEVEL; ++l)
+            ep.rho[l] = (int)std::ceil(std::sqrt(2.0 * (double)(1 << (ASR_MAX_LEVEL - l)) * T)) + 2 * T + 1;
+    }
+    const int ltab = st.aligned ? std::min(ASR_MAX_LEVEL, std::min(lmax, lhalf_max) + 1) : lmax;
+    if (pre && pre->valid && pre->pts == pts && pre->n == n && pre->lsort >= std::max(lmax, ltab) && (!radii || pre->srad)) {
+        st.frame = *frame;  // the points are already in Morton order (asr_geom_presort)
+        st.n = n;
+        st.lsort = pre->lsort;
+        st.sorted = pre->sorted;
+        st.ids = pre->ids;
+        st.rank = pre->rank;
+        st.srad = radii ? pre->srad : nullptr;
+        st.radii_src = radii;
+        st.codes = st.codes_w = pre->codes;
+        st.codes_u = nullptr;
+        st.ids_u = nullptr;
+        st.ids_w = pre->ids;
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        ASR_TRY(build_cell_table(ctx, n, lmin, std::max(lmax, ltab), st, false));
+    } else {
+        ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, std::max(lmax, ltab), st, keep, true, false, radii));
+    }
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     st.tmp = arena_alloc<u64>(ctx->scratch, (size_t)v * RADIUS_LIGHT);
     st.heavy = arena_alloc<int32_t>(ctx->scratch, v);
     st.is_heavy = arena_alloc<uint8_t>(ctx->scratch, v);
-    if (!counts || !st.tmp || !st.heavy || !st.is_heavy) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    int2* extras = arena_alloc<int2>(ctx->scratch, EXTRA_CAP);
+    if (!counts || !st.tmp || !st.heavy || !st.is_heavy || !extras) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 10, 0, sizeof(int), ctx->stream));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 15, 0, sizeof(int), ctx->stream));
+    st.aq = AlignedQ{voxel_keys, extras, ctx->d_flags + 15, lhalf_max};
     // one pass: counts, the sorted light rows (fixed slots) and the list of heavy rows
-    k_radius_query<2><<<grid_for(v + 1, 4), BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(),
-                                                                    counts, st.tmp, st.heavy, ctx->d_flags + 10,
-                                                                    st.is_heavy);
+    const bool groups = voxel_keys != nullptr && ctx->opt.search_groups != 0;
+    if (st.aligned && ep.lmax >= ep.lmin && n > 0) {
+        k_radius_extras<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(st.codes, st.sorted, n, voxel_keys, v, centers, sizes,
+                                                                  ep, extras, ctx->d_flags + 15);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    const int32_t* qlist = nullptr;
+    const int* qlist_cnt = nullptr;
+    unsigned qgrid = grid_for(v + 1, 4);
+    if (groups) {
+        // one wave per sibling group (k_radius_groups); the voxels of crowded groups come back as a list for the
+        // per-voxel kernel below, which then runs grid-stride over that list (its length stays on the device)
+        int32_t* heads = arena_alloc<int32_t>(ctx->scratch, v);
+        int32_t* fb = arena_alloc<int32_t>(ctx->scratch, v);
+        if (!heads || !fb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        int* gcnt = ctx->d_flags + 16;  // [0] groups, [1] voxels handed to the per-voxel kernel
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(gcnt, 0, 2 * sizeof(int), ctx->stream));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(counts + v, 0, sizeof(i64), ctx->stream));
+        k_group_heads<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(voxel_keys, v, heads, gcnt);
+        ASR_CHECK_LAUNCH(ctx);
+        k_radius_groups<<<3072, BLK, 0, ctx->stream>>>(st.sorted, voxel_keys, centers, sizes, v, heads, gcnt, st.index(),
+                                                       counts, st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy, fb,
+                                                       gcnt + 1);
+        ASR_CHECK_LAUNCH(ctx);
+        qlist = fb;
+        qlist_cnt = gcnt + 1;
+        qgrid = 1024;
+    }
+    if (st.aligned)
+        k_radius_query<2, true><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts,
+                                                                 st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy, qlist,
+                                                                 qlist_cnt);
+    else
+        k_radius_query<2, false><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq,
+                                                                  counts, st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy,
+                                                                  qlist, qlist_cnt);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(read_flags(ctx, host));
-    if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search cell table overflow");
+    if (host[1]) {  // retry with a table four times the size
+        if (st.cell_grow >= 6) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search cell table overflow");
+        st.cell_grow += 2;
+        return asr_geom_radius_count(ctx, frame, pts, n, centers, sizes, v, rs, num_pairs, keep, radii, voxel_keys,
+                                     lmin_hint, lmax_hint, pre);
+    }
+    if (host[15] > EXTRA_CAP) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "radius search: %d pairs in the rounding margin (cap %d)", host[15], EXTRA_CAP);
+    ctx->search_extras = host[15];
     st.num_heavy = host[10];
     if (st.num_heavy > 0) {
-        k_radius_heavy<false><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                *frame, st.sorted, centers, sizes, st.heavy, st.index(), counts, nullptr, nullptr, nullptr, nullptr);
+        if (st.aligned)
+            k_radius_heavy<false, true><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
+                    *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr);
+        else
+            k_radius_heavy<false, false><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
+                    *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr);
         ASR_CHECK_LAUNCH(ctx);
     }
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
@@ -1966,8 +2490,8 @@ int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame*
     ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, lmax, st, nullptr, false, false));
     i64* counts = arena_alloc<i64>(ctx->scratch, n + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_radius_query<0><<<grid_for(n + 1, 4), BLK, 0, ctx->stream>>>(
-            *frame, st.sorted, pts, radii, n, st.index(), counts, nullptr, nullptr, nullptr, nullptr);
+    k_radius_query<0, false><<<grid_for(n + 1, 4), BLK, 0, ctx->stream>>>(
+            *frame, st.sorted, pts, radii, n, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     ASR_CHECK_LAUNCH(ctx);
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, counts, n * sizeof(i64), hipMemcpyDeviceToDevice,
                                       ctx->stream));
@@ -2071,8 +2595,8 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         ASR_FAIL(ctx, ASR_HIP_EINVAL,
                  "asr_hip_multi_radius_search_fill must follow the matching _count call");
     if (sorted_out) *sorted_out = st.sorted;
-    float* srad = nullptr;
-    if (compat) {
+    float* srad = st.srad;  // gathered with the points when the count call had the radii
+    if (compat && !srad) {
         srad = arena_alloc<float>(ctx->scratch, n + 1);
         if (!srad) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         if (n > 0) {
@@ -2104,8 +2628,12 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         int* cursor = arena_alloc<int>(ctx->scratch, nh);
         if (!cursor) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemsetAsync(cursor, 0, (size_t)nh * sizeof(int), ctx->stream));
-        k_radius_heavy<true><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                st.frame, st.sorted, centers, sizes, st.heavy, st.index(), nullptr, hoff, cursor, k_u, t_row);
+        if (st.aligned)
+            k_radius_heavy<true, true><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
+                    st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row);
+        else
+            k_radius_heavy<true, false><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
+                    st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row);
         ASR_CHECK_LAUNCH(ctx);
         // order by (row, squared distance, index) with two stable radix sorts: by the 64-bit key, then
         // by the row (a segmented sort spends 1.6 ms on the few 10^4-entry rows)

@@ -372,3 +372,66 @@ def test_knn_radius_cell_path_equals_the_wave_path():
     finally:
         ctx.set_option("knn_deep", 1)
     assert np.array_equal(got, flat)
+
+
+@pytest.mark.parametrize("shift", [0.0, 100.0], ids=["frame-at-origin", "frame-100-units-away"])
+def test_aligned_search_finds_the_pairs_of_the_rounding_margin(gpu, shift):
+    """The aggregation search of the whole path covers the ball of voxel (x, y, z, L) with the 4^3 cells of level
+    L + 1 -- a cube without margin.  Points are planted at the poles of the balls (centre +- size along an axis, and
+    the neighbouring floats): their cell may be the first layer BEYOND the cube although the float distance test of
+    cpp/lib/nsearch.cpp:136-146 accepts them.  The result must equal the oracle's brute force (every point against
+    every voxel) bit for bit, and the margin path must have been exercised.  The planted points have a root-level
+    radius, so the octree is the one of the base cloud."""
+    from asr_hip.pipeline import ImplicitPipeline
+    from oracle import oracle as O
+    pts, _ = synth.sphere_cloud(6000, seed=5)
+    pts = (pts + np.float32(shift)).astype(np.float32)
+    rad = synth.knn_radii(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    o = O.Oracle()
+    o.build_octree(pts, rad, *bb)
+    g0 = o.create_grids(1)[0]
+    c, s = g0["voxel_centers"], g0["voxel_sizes"]
+    rng = np.random.default_rng(11)
+    pick = rng.choice(len(s), size=min(1500, len(s)), replace=False)
+    planted = []
+    for q in pick:
+        for axis in range(3):
+            for sign in (-1.0, 1.0):
+                p0 = c[q].copy()
+                p0[axis] = np.float32(c[q][axis] + np.float32(sign) * s[q])
+                for step in range(-3, 2):  # the pole and the floats around it
+                    p = p0.copy()
+                    for _ in range(abs(step)):
+                        p[axis] = np.nextafter(p[axis], np.float32(np.inf if step > 0 else -np.inf), dtype=np.float32)
+                    planted.append(p)
+    planted = np.array(planted, np.float32)
+    inside = np.all((planted >= bb[0]) & (planted <= bb[1]), axis=1)
+    planted = planted[inside]
+    allp = np.concatenate([pts, planted]).astype(np.float32)
+    edge = float((bb[1] - bb[0]).max())
+    allr = np.concatenate([rad, np.full(len(planted), 0.6 * edge, np.float32)])  # level 0: no new octree node
+    o2 = O.Oracle()
+    o2.build_octree(allp, allr, *bb)
+    assert np.array_equal(o2.leaves, o.leaves)
+    ridx, rdist, rrs, rcompat = o2.radius_search(allp, allr, c, s, brute=True)
+    pipe = ImplicitPipeline(synth.make_weights(4, seed=1), device=gpu)
+    # (half-size cells, one wave per sibling group): the default, the per-voxel kernel with half-size cells, and the
+    # per-voxel kernel with 3^3 full-size cells
+    for half, groups, presort in ((1, 0, 0), (1, 1, 1), (0, 0, 0)):
+        pipe.ctx.set_option("search_half", half)
+        pipe.ctx.set_option("search_groups", groups)
+        pipe.ctx.set_option("presort", presort)  # points sorted once, before the octree (the same results)
+        pipe.build(torch.from_numpy(allp).to(gpu), torch.from_numpy(allr).to(gpu), bb[0], bb[1])
+        assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), g0["voxel_keys"])
+        assert np.array_equal(pipe.get("aggregation_row_splits").cpu().numpy(), rrs), half
+        assert np.array_equal(pipe.get("aggregation_neighbors_index").cpu().numpy(), ridx), half
+        assert np.array_equal(pipe.get("aggregation_neighbors_dist").cpu().numpy(), rdist), half
+        margin = pipe.ctx.get_option("last_search_margin_pairs")
+        print("shift %g half %d groups %d: %d planted points, %d pairs, %d from the rounding margin" %
+              (shift, half, groups, len(planted), len(ridx), margin))
+        if half:
+            assert shift != 0.0 or margin > 0  # (far frame: the float spacing of the planted points is coarser)
+    pipe.ctx.set_option("search_half", 1)
+    pipe.ctx.set_option("search_groups", 0)
+    pipe.ctx.set_option("presort", 0)

@@ -20,6 +20,12 @@ def get_version_str():
     return __version__
 
 
+def set_print_callback_function(print_callback, levels=(0, 1, 2, 3)):
+    """asr::SetPrintCallbackFunction (cpp/lib/asr.hpp:29-34; C++ API of the reference, not in its pybind module):
+    stage banners and messages of the library go to `print_callback(str)`"""
+    _lib.set_print_callback_function(print_callback, levels)
+
+
 def _f32(a, name, shape_msg, ndim, last=None):
     a = np.ascontiguousarray(a, dtype=np.float32)  # forcecast, module.cpp:59-61
     if a.ndim != ndim or (last is not None and a.shape[-1] != last):
@@ -185,6 +191,7 @@ def reconstruct_surface(points, normals, radii=np.empty((0,), np.float32), point
     if points.shape[0] == 0:
         raise RuntimeError("points is null!\n")
     # preprocess (asr.cpp:116-135)
+    _lib.library_print("preprocessing\n", _lib.PRINT_LEVELS["INFO"])  # asr.cpp:117
     tree = KDTree(points)
     if radii.shape[0]:
         counts = _ops.radius_neighbor_count(tree._frame, tree._points, torch.from_numpy(radii).to(tree._points.device))

@@ -98,7 +98,7 @@ class ImplicitSizes(ctypes.Structure):
 # every symbol declared in include/asr_hip.h (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "asr_hip_context_create", "asr_hip_context_destroy", "asr_hip_context_set_stream",
-    "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes",
+    "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes", "asr_hip_set_print_callback", "asr_hip_print",
     "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_weights_changed", "asr_hip_context_set_option", "asr_hip_context_get_option",
     "asr_hip_sparse_conv_variant_counts", "asr_hip_sparse_conv_packed_bytes", "asr_hip_sparse_conv_pack",
     "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_convert_f16",
@@ -140,6 +140,34 @@ def load():
                                   % name)
         _lib = lib
     return _lib
+
+
+PRINT_LEVELS = {"DEBUG": 0, "INFO": 1, "WARN": 2, "ERROR": 3}  # cpp/lib/asr.hpp:27
+_PRINT_CB_TYPE = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_void_p)
+_print_keepalive = {}  # level -> ctypes thunk (must outlive its registration)
+
+
+def set_print_callback_function(print_callback, levels):
+    """asr::SetPrintCallbackFunction (cpp/lib/asr.hpp:29-34): `print_callback(str)` receives the library's messages of
+    the given verbosity levels (ints 0..3 or the names DEBUG / INFO / WARN / ERROR); None removes it.  Raises
+    RuntimeError("invalid verbosity level") like the reference (cpp/lib/asr.cpp:42-44).  No GPU needed."""
+    lv = [PRINT_LEVELS[x] if isinstance(x, str) else int(x) for x in levels]
+    thunk = None
+    if print_callback is not None:
+        thunk = _PRINT_CB_TYPE(lambda msg, user: print_callback(msg.decode() if msg else ""))
+    arr = (ctypes.c_int * len(lv))(*lv)
+    rc = load().asr_hip_set_print_callback(thunk if thunk is not None else _PRINT_CB_TYPE(), None, arr, len(lv))
+    if rc != 0:
+        raise RuntimeError("invalid verbosity level")
+    for x in lv:
+        _print_keepalive[x] = thunk
+
+
+def library_print(msg, level=1):
+    """asr::Print (cpp/lib/utils.h:26)"""
+    f = load().asr_hip_print
+    f.restype = None
+    f(msg.encode(), int(level))
 
 
 def ptr(t):

@@ -117,11 +117,32 @@ def make_plan(rank, world, csr_index, csr_row_splits, owner_out, owner_in):
     return ExchangePlan(send, recv)
 
 
+# reporting: bytes this rank sent / received and the number of grouped exchanges since the last reset; with
+# STATS["timed"] set every exchange is bracketed by device synchronisations and its wall time accumulated (an
+# instrumented extra step of bench.py, never the timed region)
+STATS = {"sent_bytes": 0, "recv_bytes": 0, "exchanges": 0, "seconds": 0.0, "timed": False}
+
+
+def reset_stats(timed=False):
+    STATS.update(sent_bytes=0, recv_bytes=0, exchanges=0, seconds=0.0, timed=bool(timed))
+
+
 def exchange(tensors, plan, group=None):
     """fills the halo rows of each tensor in `tensors` (same row space, e.g. features and importance) in
     place.  Point to point, batched: one grouped send/recv per call."""
     if not plan.send and not plan.recv:
         return
+    t0 = None
+    if STATS["timed"]:
+        import time
+        if tensors[0].is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    for t in tensors:
+        row_bytes = t.element_size() * (t.shape[1] if t.dim() > 1 else 1)
+        STATS["sent_bytes"] += row_bytes * plan.num_send
+        STATS["recv_bytes"] += row_bytes * plan.num_recv
+    STATS["exchanges"] += 1
     # gloo moves CPU tensors only: stage GPU tensors through the host (single-GPU multi-process tests)
     via_host = dist.get_backend(group) == "gloo" and tensors[0].is_cuda
     p2p, landing = [], []
@@ -138,6 +159,11 @@ def exchange(tensors, plan, group=None):
         req.wait()
     for t, rows, buf in landing:
         t.index_copy_(0, rows, buf.to(t.device))
+    if t0 is not None:
+        import time
+        if tensors[0].is_cuda:
+            torch.cuda.synchronize()
+        STATS["seconds"] += time.perf_counter() - t0
 
 
 # ---- the sharded forward ------------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include <algorithm>
+#include <mutex>
 #include <thread>
 
 #include "asr_common.h"
@@ -48,11 +49,37 @@ const OptEntry k_options[] = {
         {"search_groups", "ASR_SEARCH_GROUPS", &AsrOptions::search_groups},
         {"presort", "ASR_PRESORT", &AsrOptions::presort},
 };
+
+// asr::GetPrintCallbackFunction (cpp/lib/asr.cpp:34-37): one callback per verbosity level, process wide
+struct PrintSlot {
+    asr_hip_print_callback cb = nullptr;
+    void* user = nullptr;
+};
+std::mutex g_print_mu;
+PrintSlot g_print[4];
 }  // namespace
 
 extern "C" {
 
-const char* asr_hip_version(void) { return "0.2.0+mi355x.r1"; }
+const char* asr_hip_version(void) { return "0.2.0+mi355x.r3"; }
+
+int asr_hip_set_print_callback(asr_hip_print_callback callback, void* user, const int* levels, int num_levels) {
+    if (num_levels < 0 || (num_levels > 0 && !levels)) return ASR_HIP_EINVAL;
+    for (int i = 0; i < num_levels; ++i)
+        if (levels[i] < ASR_HIP_DEBUG || levels[i] > ASR_HIP_ERROR) return ASR_HIP_EINVAL;  // "invalid verbosity level"
+    std::lock_guard<std::mutex> lock(g_print_mu);
+    for (int i = 0; i < num_levels; ++i) g_print[levels[i]] = PrintSlot{callback, callback ? user : nullptr};
+    return ASR_HIP_OK;
+}
+void asr_hip_print(const char* msg, int level) {
+    if (!msg || level < ASR_HIP_DEBUG || level > ASR_HIP_ERROR) return;
+    PrintSlot s;
+    {
+        std::lock_guard<std::mutex> lock(g_print_mu);
+        s = g_print[level];
+    }
+    if (s.cb) s.cb(msg, s.user);
+}
 
 size_t asr_hip_struct_size(const char* name) {
     if (!name) return 0;
@@ -770,6 +797,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     ctx->sizes.num_points = n;
     if (asr_octree_frame_init(&ctx->frame, prm->bb_min, prm->bb_max) != ASR_HIP_OK)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "degenerate bounding box");
+    asr_hip_print("grid building\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:144
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->pindex.valid = false;
     if (ctx->opt.presort) ASR_TRY(asr_geom_presort(ctx, ctx->persist, &ctx->frame, points, radii, n));
@@ -797,6 +825,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     // latency-bound kernels with host round trips for the data-dependent sizes; neither fills the GPU.
     const bool want_search = ctx->opt.build_search != 0;
     const bool overlap = want_search && ctx->opt.overlap != 0;
+    if (want_search) asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264 (here: concurrent with the grids)
     asr_hip_context* sc = ctx;  // context the search runs on
     if (overlap) {
         if (!ctx->aux) {
@@ -994,6 +1023,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 
     // ---- aggregate (net_definitions_torch.py:640-653, 72-120) ----
+    asr_hip_print("network aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:314
     const asr_weight *ck, *cb;
     ASR_TRY(net.get("cconv_block_in.conv1.kernel", 5, &ck));
     ASR_TRY(net.get("cconv_block_in.conv1.bias", 1, &cb));
@@ -1024,6 +1054,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
                  (long long)P, (long long)V0);
 
     // ---- unet (net_definitions_torch.py:535-638) ----
+    asr_hip_print("network unet\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:319
     int c_enc[5], c_down[5], c_up[4], c_dec[4];
     {
         int a, b;
@@ -1112,6 +1143,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
 
     // ---- decode + sdf scale (net_definitions_torch.py:655-666, asr.cpp:324-336) ----
+    asr_hip_print("network decode\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:323
     const asr_weight *w1, *b1, *w2, *b2, *w3;
     ASR_TRY(net.get("dense_decoder1.weight", 2, &w1));
     ASR_TRY(net.get("dense_decoder1.bias", 1, &b1));

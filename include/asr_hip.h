@@ -81,6 +81,22 @@ int asr_hip_context_weights_changed(asr_hip_context* ctx);
 int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value);
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value);
 
+/* ---- print callbacks: asr::SetPrintCallbackFunction (cpp/lib/asr.hpp:25-34, asr.cpp:34-47) ------------- */
+/* Process-wide like the reference's (a static table of four callbacks).  Levels: cpp/lib/asr.hpp:27.  The whole-path
+ * entry points announce their stages at ASR_HIP_INFO with the reference's texts (cpp/lib/asr.cpp:117,144,264,
+ * 314-323): "grid building\n", "aggregate\n", "network aggregate\n", "network unet\n", "network decode\n"
+ * ("preprocessing\n" comes from the host side that runs the pre-filter).  Without a callback nothing is printed. */
+#define ASR_HIP_DEBUG 0
+#define ASR_HIP_INFO 1
+#define ASR_HIP_WARN 2
+#define ASR_HIP_ERROR 3
+typedef void (*asr_hip_print_callback)(const char* msg, void* user);
+/* installs `callback` (NULL: removes) for each of levels[0..num_levels); ASR_HIP_EINVAL for a level outside
+ * DEBUG..ERROR ("invalid verbosity level", asr.cpp:42-44) -- nothing is changed in that case */
+int asr_hip_set_print_callback(asr_hip_print_callback callback, void* user, const int* levels, int num_levels);
+/* asr::Print (cpp/lib/utils.h:26): hands msg to the callback of `level`, if one is installed */
+void asr_hip_print(const char* msg, int level);
+
 /* ---- a3: octree frame (cpp/lib/octree.cpp:20-42), host only --------------------------- */
 int asr_octree_frame_init(asr_octree_frame* frame, const float bb_min[3], const float bb_max[3]);
 

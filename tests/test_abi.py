@@ -1,5 +1,6 @@
 """The C-ABI library loads without a GPU and exports every symbol include/asr_hip.h declares;
 host-only entry points work (no compute calls)."""
+import pytest
 import ctypes
 import os
 import re
@@ -124,3 +125,22 @@ def test_model_pt_loader_reads_a_torchscript_archive(tmp_path):
     got = asr._load_weights(str(tmp_path / "w.npz"))
     assert all(np.array_equal(got[k], w[k]) for k in w)
     assert "rocPRIM" in asr.get_third_party_notices() and asr.get_version_str().startswith("0.2.0")
+
+
+def test_print_callback_registry():
+    """asr::SetPrintCallbackFunction / asr::Print (cpp/lib/asr.cpp:34-47, utils.h:26): per-level callbacks, process
+    wide; an invalid level is refused and changes nothing.  Host only."""
+    from asr_hip import _lib
+    got = []
+    _lib.set_print_callback_function(got.append, ["INFO", "WARN"])
+    _lib.library_print("grid building\n", 1)
+    _lib.library_print("dbg", 0)      # no callback on DEBUG
+    _lib.library_print("careful", 2)
+    assert got == ["grid building\n", "careful"]
+    with pytest.raises(RuntimeError, match="invalid verbosity level"):
+        _lib.set_print_callback_function(got.append, [1, 4])
+    _lib.library_print("still there", 1)
+    assert got[-1] == "still there"
+    _lib.set_print_callback_function(None, [0, 1, 2, 3])
+    _lib.library_print("silence", 1)
+    assert got[-1] == "still there"

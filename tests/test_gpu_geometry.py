@@ -435,3 +435,49 @@ def test_aligned_search_finds_the_pairs_of_the_rounding_margin(gpu, shift):
     pipe.ctx.set_option("search_half", 1)
     pipe.ctx.set_option("search_groups", 0)
     pipe.ctx.set_option("presort", 0)
+
+
+def test_six_grid_levels_vs_oracle(gpu):
+    """asr::CreateGridsFromOctree(tree, num_levels = 6, ...) (cpp/lib/grid.cpp:245-314; the "6 levels" of BASELINE
+    config C3 swept over the connectivity kernels): every array of all six grids equals the oracle's"""
+    import adaptivesurfacereconstruction as asr
+    from oracle import oracle as O
+    p, _ = synth.scan_cloud(60000, seed=77, device="cpu")
+    pts = p.numpy()
+    rad = synth.knn_radii(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    o = O.Oracle()
+    o.build_octree(pts, rad, *bb)
+    want = o.create_grids(6)
+    tree = asr.create_octree(pts, rad, bb[0], bb[1])
+    got = asr.create_grids_from_octree(tree, 6, voxel_info_all_levels=True)
+    assert len(got) == 6
+    v = [len(w["voxel_keys"]) for w in want]
+    assert v[0] > v[1] > v[2] > v[3] > v[4] >= v[5] >= 1
+    for lvl, (g, w) in enumerate(zip(got, want)):
+        for k in ("voxel_keys", "voxel_centers", "voxel_sizes", "neighbors_index", "neighbors_kernel_index",
+                  "neighbors_row_splits"):
+            assert np.array_equal(g[k], w[k]), (lvl, k)
+        if lvl < 5:
+            for k in ("up_neighbors_index", "up_neighbors_kernel_index", "up_neighbors_row_splits"):
+                assert np.array_equal(g[k], w[k]), (lvl, k)
+        else:
+            assert "up_neighbors_index" not in g  # the coarsest grid has no up lists (quirk B.5)
+
+
+def test_stage_banners_reach_the_print_callback(gpu):
+    """the whole path announces its stages like asr::ReconstructSurface (cpp/lib/asr.cpp:144,264,314-323) through the
+    callback registry (asr::SetPrintCallbackFunction, asr.cpp:34-47)"""
+    from asr_hip import _lib
+    from asr_hip.pipeline import ImplicitPipeline
+    p, q = synth.scan_cloud(3000, seed=5, device="cpu")
+    rad = torch.from_numpy(synth.knn_radii(p.numpy(), 24))
+    bb = synth.bounding_box(p.numpy(), 0.1)
+    got = []
+    _lib.set_print_callback_function(got.append, ["INFO"])
+    try:
+        pipe = ImplicitPipeline(synth.make_weights(4, seed=1), device=gpu)
+        pipe.forward(p.to(gpu), q.to(gpu), rad.to(gpu), bb[0], bb[1])
+    finally:
+        _lib.set_print_callback_function(None, ["INFO"])
+    assert got == ["grid building\n", "aggregate\n", "network aggregate\n", "network unet\n", "network decode\n"]

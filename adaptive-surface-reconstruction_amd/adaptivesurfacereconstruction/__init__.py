@@ -65,13 +65,12 @@ def create_octree(points, radii, bb_min, bb_max, radius_scale=1.0, grow_steps=0,
     radii = _f32(radii, "radii", "[N]", 1)
     if radii.shape[0] != points.shape[0]:
         raise ValueError("radii must have shape [N]")
-    if grow_steps != 0:
-        raise RuntimeError("grow_steps != 0 is never used on the reconstruction path "
-                           "(cpp/lib/asr.cpp:151-153) and is not implemented")
+    if grow_steps < 0:
+        raise ValueError("grow_steps must be >= 0")
     frame = _lib.frame_init(np.asarray(bb_min, np.float32), np.asarray(bb_max, np.float32))
     dev = torch.device("cuda")
     nodes, leaves = _ops.octree_build(frame, torch.from_numpy(points).to(dev),
-                                      torch.from_numpy(radii).to(dev), radius_scale, max_depth)
+                                      torch.from_numpy(radii).to(dev), radius_scale, max_depth, int(grow_steps))
     return Octree(frame, nodes, leaves)
 
 

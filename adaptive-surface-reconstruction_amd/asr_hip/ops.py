@@ -68,7 +68,7 @@ def point_keys(frame, points, radii, radius_scale=1.0, max_depth=21):
     return keys  # uint64 bit pattern in an int64 tensor
 
 
-def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
+def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21, grow_steps=0):
     """-> (nodes, leaves) sorted uint64 keys (as int64 tensors)"""
     points = _dev(points, torch.float32)
     radii = _dev(radii, torch.float32)
@@ -78,8 +78,8 @@ def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21):
         raise ValueError("radii must have shape [N]")
     nn, nl = i64(0), i64(0)
     ctx = context(_same_device(points, radii))
-    ctx.call("asr_hip_octree_build", ctypes.byref(frame), ptr(points), ptr(radii),
-             i64(points.shape[0]), ctypes.c_float(radius_scale), int(max_depth), ctypes.byref(nn),
+    ctx.call("asr_hip_octree_build_grow", ctypes.byref(frame), ptr(points), ptr(radii),
+             i64(points.shape[0]), ctypes.c_float(radius_scale), int(grow_steps), int(max_depth), ctypes.byref(nn),
              ctypes.byref(nl))
     nodes = torch.empty(nn.value, dtype=torch.int64, device=points.device)
     leaves = torch.empty(nl.value, dtype=torch.int64, device=points.device)

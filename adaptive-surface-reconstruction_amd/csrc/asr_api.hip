@@ -235,6 +235,19 @@ int asr_hip_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, co
     if (num_leaves) *num_leaves = ctx->num_leaves;
     return ASR_HIP_OK;
 }
+int asr_hip_octree_build_grow(asr_hip_context* ctx, const asr_octree_frame* frame, const float* points,
+                              const float* radii, int64_t n, float radius_scale, int grow_steps, int max_depth,
+                              int64_t* num_nodes, int64_t* num_leaves) {
+    CTX_GUARD(ctx);
+    if (!frame || n < 0 || (n > 0 && (!points || !radii)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree_build: null argument");
+    ctx->persist.reset();
+    ctx->named.clear();
+    ASR_TRY(asr_geom_octree_build(ctx, frame, points, radii, n, radius_scale, max_depth, nullptr, grow_steps));
+    if (num_nodes) *num_nodes = ctx->num_nodes;
+    if (num_leaves) *num_leaves = ctx->num_leaves;
+    return ASR_HIP_OK;
+}
 int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out, uint64_t* leaves_out) {
     CTX_GUARD(ctx);
     if (nodes_out && ctx->num_nodes)

@@ -223,6 +223,88 @@ __global__ void k_octree_insert_points(asr_octree_frame f, const float* pts, con
     insert_with_ancestors(t, key, cnt, list, list_cap);
 }
 
+// ------------------------------------------------------------------------------------------
+// Octree::Grow (octree.cpp:44-108), on the raw point keys: a second hash set + key list.  One iteration = two
+// kernels: the candidates of condition :87 ("not a node, has no child") are evaluated against the set as it is at
+// the START of the iteration, then candidates and siblings are inserted (what is new forms the next frontier).
+// ------------------------------------------------------------------------------------------
+__global__ void k_grow_init(asr_octree_frame f, const float* pts, const float* radii, i64 n, float radius_scale,
+                            int max_depth, HashTab t, int* cnt, u64* list, int list_cap) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!(isfinite(pts[3 * i]) && isfinite(pts[3 * i + 1]) && isfinite(pts[3 * i + 2]) && isfinite(radii[i]))) {
+        cnt[11] = 1;
+        return;
+    }
+    const u64 key = point_key(f, pts, radii, i, radius_scale, max_depth);
+    if (key == 0) return;
+    const int r = tab_insert(t, key);
+    if (r < 0) cnt[1] = 1;
+    if (r == 1) {
+        const int pos = atomicAdd(&cnt[0], 1);
+        if (pos < list_cap)
+            list[pos] = key;
+        else
+            cnt[1] = 1;
+    }
+}
+__device__ inline bool tab_has_child(const HashTab& t, u64 key) {
+    if (__clzll((long long)key) <= 1) return false;
+    for (int k = 0; k < 8; ++k)
+        if (tab_contains(t, (key << 3) + k)) return true;
+    return false;
+}
+// one thread per (frontier key, j): cand[7 i + jj] = the parent-level cell to add, or 0
+__global__ void k_grow_candidates(HashTab t, const u64* list, int lo, int count, u64* cand) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count * 7) return;
+    const u64 cur = list[lo + e / 7];
+    u64 out = 0;
+    if (cur != 1) {
+        const int cfg = 7 - (int)(cur & 7);
+        int j = e % 7;
+        if (j >= cfg) ++j;  // the eight cells of the block without the parent itself
+        int x, y, z, lev;
+        asr_key_coord(cur >> 3, x, y, z, lev);
+        const u64 key = asr_coord_key(x + (j & 1) - (cfg & 1), y + ((j >> 1) & 1) - ((cfg >> 1) & 1),
+                                      z + ((j >> 2) & 1) - ((cfg >> 2) & 1), lev);
+        if (key != 0 && !tab_contains(t, key) && !tab_has_child(t, key)) out = key;
+    }
+    cand[e] = out;
+}
+__global__ void k_grow_insert(HashTab t, u64* list, int lo, int count, const u64* cand, int* cnt, int list_cap) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count * 14) return;
+    const u64 cur = list[lo + e / 14];
+    if (cur == 1) return;
+    const int j = e % 14;
+    u64 key;
+    if (j < 7) {
+        key = cand[(e / 14) * 7 + j];
+        if (key == 0) return;
+    } else {  // siblings (:94-101)
+        const u64 first = cur & ~u64(7);
+        int sj = j - 7;
+        if (first + sj >= cur) ++sj;
+        key = first + sj;
+    }
+    const int r = tab_insert(t, key);
+    if (r < 0) cnt[1] = 1;
+    if (r == 1) {
+        const int pos = atomicAdd(&cnt[0], 1);
+        if (pos < list_cap)
+            list[pos] = key;
+        else
+            cnt[1] = 1;
+    }
+}
+// closure over an explicit key list (the grown set) instead of the points
+__global__ void k_octree_insert_keys(const u64* keys, i64 n, HashTab t, int* cnt, u64* list, int list_cap) {
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    insert_with_ancestors(t, keys[i], cnt, list, list_cap);
+}
+
 // the same from the Morton-ordered copy of the points (asr_geom_presort): runs of equal keys along a wave
 __global__ void k_octree_insert_sorted(asr_octree_frame f, const float4* sorted, const float* srad, i64 n,
                                        float radius_scale, int max_depth, HashTab t, int* cnt, u64* list, int list_cap) {
@@ -1821,13 +1903,72 @@ int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, con
 }
 
 // Result: ctx->nodes / ctx->leaves (sorted) in the persist arena.
+// Octree::Grow: the grown key set of `grow_steps` iterations as a device list in `arena` (see k_grow_*)
+static int grow_keys(asr_hip_context* ctx, Arena& arena, const asr_octree_frame* frame, const float* pts, const float* radii,
+                     i64 n, float radius_scale, int max_depth, int grow_steps, u64** keys_out, i64* count_out) {
+    int host[16];
+    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 8 * n));
+    for (int attempt = 0; attempt < 6; ++attempt, cap <<= 2) {
+        HashTab t;
+        ASR_TRY(make_table(ctx, arena, cap, false, t));
+        const int lcap = (int)std::min<u64>(cap / 2, u64(1) << 30);
+        u64* list = arena_alloc<u64>(arena, (size_t)lcap + 8);
+        if (!list) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        k_grow_init<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, radii, n, radius_scale, max_depth, t,
+                                                             ctx->d_flags, list, lcap);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(read_flags(ctx, host));
+        if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree: points / radii contain non-finite values");
+        bool overflow = host[1] != 0;
+        int lo = 0, hi = host[0];
+        for (int it = 0; it < grow_steps && !overflow && hi > lo; ++it) {
+            const int count = hi - lo;
+            if ((i64)count * 14 >= (i64(1) << 31) || (u64)(hi + (i64)count * 14) > (u64)lcap) {
+                overflow = true;  // worst case of this iteration does not fit: larger table
+                break;
+            }
+            u64* cand = arena_alloc<u64>(arena, (size_t)count * 7);
+            if (!cand) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            k_grow_candidates<<<grid_for((i64)count * 7, BLK), BLK, 0, ctx->stream>>>(t, list, lo, count, cand);
+            ASR_CHECK_LAUNCH(ctx);
+            k_grow_insert<<<grid_for((i64)count * 14, BLK), BLK, 0, ctx->stream>>>(t, list, lo, count, cand, ctx->d_flags,
+                                                                                  lcap);
+            ASR_CHECK_LAUNCH(ctx);
+            ASR_TRY(read_flags(ctx, host));
+            overflow = host[1] != 0;
+            lo = hi;
+            hi = host[0];
+        }
+        if (overflow) continue;
+        *keys_out = list;
+        *count_out = host[0];
+        return ASR_HIP_OK;
+    }
+    ASR_FAIL(ctx, ASR_HIP_ELOGIC, "octree grow: hash table overflow");
+}
+
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                          const float* radii, i64 n, float radius_scale, int max_depth, const AsrPointIndex* pre) {
+                          const float* radii, i64 n, float radius_scale, int max_depth, const AsrPointIndex* pre,
+                          int grow_steps) {
     ASR_TRY(ensure_flags(ctx));
     if (max_depth > ASR_MAX_LEVEL) max_depth = ASR_MAX_LEVEL;
     if (max_depth < 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "max_depth must be >= 0");
+    if (grow_steps < 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "grow_steps must be >= 0");
+    // Octree::Grow (octree.cpp:266) works on the raw point keys, before ancestors and siblings exist: its result
+    // replaces the points as the input of the closure below
+    u64* grown = nullptr;
+    i64 num_grown = 0;
+    Arena grow_arena;
+    grow_arena.min_slab = size_t(16) << 20;
+    struct ArenaGuard {
+        Arena& a;
+        ~ArenaGuard() { a.release(); }
+    } grow_guard{grow_arena};
+    if (grow_steps > 0 && n > 0)
+        ASR_TRY(grow_keys(ctx, grow_arena, frame, pts, radii, n, radius_scale, max_depth, grow_steps, &grown, &num_grown));
     // nodes of a scan are ~0.3 n; the table must stay at most half full (cap / 2 list entries), else retry 4x larger
-    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 2 * n));
+    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 2 * std::max(n, 4 * num_grown)));
     int host[16];
     for (int attempt = 0; attempt < 7; ++attempt, cap <<= 2) {
         ctx->scratch.reset();
@@ -1839,7 +1980,12 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
         uint8_t* flag = arena_alloc<uint8_t>(ctx->scratch, (size_t)lcap / 8 + 8);
         if (!list || !flag) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
-        if (n > 0) {
+        if (grown) {
+            if (num_grown > 0)
+                k_octree_insert_keys<<<grid_for(num_grown, BLK), BLK, 0, ctx->stream>>>(grown, num_grown, t, ctx->d_flags,
+                                                                                       list, lcap);
+            ASR_CHECK_LAUNCH(ctx);
+        } else if (n > 0) {
             if (pre && pre->valid && pre->n == n && pre->srad)
                 k_octree_insert_sorted<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
                         *frame, pre->sorted, pre->srad, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);

@@ -109,12 +109,20 @@ int asr_hip_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame,
 
 /* ---- a4: octree construction (asr::CreateOctreeFromPoints, cpp/lib/octree.cpp:230-280;
  *      pybind create_octree, cpp/pybind/module.cpp:144-161) ----------------------------- */
-/* Builds the balanced node set inside the context and reports its sizes. grow_steps of the
- * reference is always 0 on the path (cpp/lib/asr.cpp:151-153) and is not supported. */
+/* Builds the balanced node set inside the context and reports its sizes (grow_steps = 0, the value of the
+ * reconstruction path, cpp/lib/asr.cpp:151-153). */
 int asr_hip_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame,
                          const float* points_dev, const float* radii_dev, int64_t n,
                          float radius_scale, int max_depth, int64_t* num_nodes,
                          int64_t* num_leaves);
+/* the same with Octree::Grow (cpp/lib/octree.cpp:44-108) applied `grow_steps` times to the point keys before the
+ * closure, as create_octree(..., grow_steps, ...) of the pybind module does (cpp/pybind/module.cpp:144-161).  The
+ * candidate test of an iteration (:87) is evaluated against the key set at the start of the iteration; the reference
+ * walks its hash map sequentially, which only matters for grow_steps >= 2 on trees that mix levels. */
+int asr_hip_octree_build_grow(asr_hip_context* ctx, const asr_octree_frame* frame,
+                              const float* points_dev, const float* radii_dev, int64_t n,
+                              float radius_scale, int grow_steps, int max_depth, int64_t* num_nodes,
+                              int64_t* num_leaves);
 /* copies the sorted node keys / sorted leaf keys (tree.leaves) of the last build */
 int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out_dev, uint64_t* leaves_out_dev);
 

@@ -220,9 +220,68 @@ static inline bool has_first_child(const std::unordered_set<u64>& S, u64 key) {
     return S.count(key << 3) != 0;
 }
 
+// octree.cpp:44-108  Octree::Grow on the raw point keys (before ancestors / siblings exist).  Per iteration every
+// frontier key adds (a) the 7 other parent-level cells of the 2 x 2 x 2 block around the parent's corner nearest to
+// the key, unless such a cell is a node already or has a child (:73-91), and (b) its own siblings (:94-101); what was
+// inserted is the next frontier.  Condition (a) looks at keys of two levels, so with keys of several levels in one
+// frontier the reference's result for iterations >= 2 depends on its hash iteration order (an insertion of this
+// iteration can give a later candidate a child).  mode 0: the conditions are evaluated against the set at the START
+// of the iteration (what the GPU does); mode 1: the reference's sequential walk in ascending key order.
+static bool has_child(const std::unordered_set<u64>& S, u64 key) {
+    if (__builtin_clzll(key) <= 1) return false;
+    for (int k = 0; k < 8; ++k)
+        if (S.count((key << 3) + k)) return true;
+    return false;
+}
+static void grow_octree(std::unordered_set<u64>& S, int iterations, int mode) {
+    std::vector<u64> frontier(S.begin(), S.end()), next;
+    std::sort(frontier.begin(), frontier.end());
+    for (int it = 0; it < iterations; ++it) {
+        next.clear();
+        std::vector<u64> cand;
+        for (u64 cur : frontier) {
+            if (cur == 1) continue;
+            const Coord pc = key_coord(cur >> 3);
+            const int cfg = 7 - (int)(cur & 7);
+            for (int j = 0; j < 8; ++j) {
+                if (j == cfg) continue;
+                Coord c = pc;
+                c.x += (j & 1) - (cfg & 1);
+                c.y += ((j >> 1) & 1) - ((cfg >> 1) & 1);
+                c.z += ((j >> 2) & 1) - ((cfg >> 2) & 1);
+                const u64 key = coord_key(c);
+                if (key == 0) continue;
+                if (!S.count(key) && !has_child(S, key)) {
+                    if (mode == 0)
+                        cand.push_back(key);
+                    else if (S.insert(key).second)
+                        next.push_back(key);
+                }
+            }
+            if (mode == 1) {
+                const u64 first = cur & ~u64(7);
+                for (int j = 0; j < 8; ++j)
+                    if (first + j != cur && S.insert(first + j).second) next.push_back(first + j);
+            }
+        }
+        if (mode == 0) {
+            for (u64 key : cand)
+                if (S.insert(key).second) next.push_back(key);
+            for (u64 cur : frontier) {
+                if (cur == 1) continue;
+                const u64 first = cur & ~u64(7);
+                for (int j = 0; j < 8; ++j)
+                    if (first + j != cur && S.insert(first + j).second) next.push_back(first + j);
+            }
+        }
+        std::sort(next.begin(), next.end());
+        frontier.swap(next);
+    }
+}
+
 static void build_octree(Oracle& o, const float* pts, i64 n, const float* radii,
                          const float* bb_min, const float* bb_max, float radius_scale,
-                         int max_depth, int mode) {
+                         int max_depth, int mode, int grow_steps = 0) {
     frame_init(o.frame, bb_min, bb_max, 1.f);
     const OctreeFrame& f = o.frame;
     std::unordered_set<u64> S;
@@ -238,6 +297,7 @@ static void build_octree(Oracle& o, const float* pts, i64 n, const float* radii,
         if (key == 0) continue;  // deviation from the reference, see B.1
         S.insert(key);
     }
+    if (grow_steps > 0) grow_octree(S, grow_steps, mode);  // octree.cpp:266
     // ancestors + siblings
     {
         std::vector<u64> init(S.begin(), S.end());
@@ -1125,6 +1185,11 @@ i64 orc_octree_build(Oracle* o, const float* pts, i64 n, const float* radii,
                      const float* bb_min, const float* bb_max, float radius_scale,
                      int max_depth, int mode) {
     build_octree(*o, pts, n, radii, bb_min, bb_max, radius_scale, max_depth, mode);
+    return (i64)o->leaves.size();
+}
+i64 orc_octree_build_grow(Oracle* o, const float* pts, i64 n, const float* radii, const float* bb_min,
+                          const float* bb_max, float radius_scale, int max_depth, int mode, int grow_steps) {
+    build_octree(*o, pts, n, radii, bb_min, bb_max, radius_scale, max_depth, mode, grow_steps);
     return (i64)o->leaves.size();
 }
 i64 orc_num_nodes(Oracle* o) { return (i64)o->nodes.size(); }

@@ -27,7 +27,7 @@ def lib():
             build()  # never run with a library older than its source
         _LIB = ctypes.CDLL(path)
         _LIB.orc_create.restype = ctypes.c_void_p
-        for name in ("orc_octree_build", "orc_num_nodes", "orc_leaf_neighbors", "orc_create_duals",
+        for name in ("orc_octree_build", "orc_octree_build_grow", "orc_num_nodes", "orc_leaf_neighbors", "orc_create_duals",
                      "orc_radius_search"):
             getattr(_LIB, name).restype = ctypes.c_int64
         for name in ("orc_morton3d", "orc_morton_add", "orc_morton_sub", "orc_coord_key"):
@@ -92,15 +92,15 @@ class Oracle:
             pass
 
     # a3/a4 (cpp/lib/octree.cpp:230-280)
-    def build_octree(self, points, radii, bb_min, bb_max, radius_scale=1.0, max_depth=21, mode=0):
+    def build_octree(self, points, radii, bb_min, bb_max, radius_scale=1.0, max_depth=21, mode=0, grow_steps=0):
         points = _f32(points)
         radii = _f32(radii)
         self.bb_min = _f32(bb_min)
         self.bb_max = _f32(bb_max)
         n = points.shape[0]
-        nl = lib().orc_octree_build(self._h, _p(points), i64(n), _p(radii), _p(self.bb_min),
-                                    _p(self.bb_max), ctypes.c_float(radius_scale), int(max_depth),
-                                    int(mode))
+        nl = lib().orc_octree_build_grow(self._h, _p(points), i64(n), _p(radii), _p(self.bb_min),
+                                         _p(self.bb_max), ctypes.c_float(radius_scale), int(max_depth),
+                                         int(mode), int(grow_steps))
         self.leaves = np.zeros(nl, np.uint64)
         lib().orc_get_leaves(self._h, _p(self.leaves))
         nn = lib().orc_num_nodes(self._h)

@@ -481,3 +481,28 @@ def test_stage_banners_reach_the_print_callback(gpu):
     finally:
         _lib.set_print_callback_function(None, ["INFO"])
     assert got == ["grid building\n", "aggregate\n", "network aggregate\n", "network unet\n", "network decode\n"]
+
+
+@pytest.mark.parametrize("grow_steps", [1, 2, 3])
+def test_create_octree_grow_steps_vs_oracle(gpu, grow_steps):
+    """create_octree(..., grow_steps, ...) (cpp/pybind/module.cpp:144-161 -> Octree::Grow, cpp/lib/octree.cpp:44-108):
+    nodes and leaves equal the oracle's on a one-point tree, a mixed-level scan and a sphere"""
+    import adaptivesurfacereconstruction as asr
+    from oracle import oracle as O
+    clouds = [(np.array([[0.3, 0.3, 0.3]], np.float32), np.array([0.1], np.float32),
+               (np.zeros(3, np.float32), np.ones(3, np.float32)))]
+    for seed, n in ((3, 5000), (8, 40000)):
+        p, _ = synth.scan_cloud(n, seed=seed, device="cpu")
+        p = p.numpy()
+        clouds.append((p, synth.knn_radii(p, 24), synth.bounding_box(p, 0.1)))
+    p, _ = synth.sphere_cloud(20000, seed=2)
+    clouds.append((p, synth.knn_radii(p, 24), synth.bounding_box(p, 0.1)))
+    for pts, rad, bb in clouds:
+        o = O.Oracle()
+        o.build_octree(pts, rad, *bb, grow_steps=grow_steps)
+        tree = asr.create_octree(pts, rad, bb[0], bb[1], grow_steps=grow_steps)
+        assert np.array_equal(tree.nodes.cpu().numpy().view(np.uint64), o.nodes)
+        assert np.array_equal(tree.leaves.cpu().numpy().view(np.uint64), o.leaves)
+        o0 = O.Oracle()
+        o0.build_octree(pts, rad, *bb)
+        assert len(o.nodes) >= len(o0.nodes)

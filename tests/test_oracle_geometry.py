@@ -195,3 +195,48 @@ def test_invert_neighbors_list_roundtrip(c1):
     # inverting twice returns the original list
     idx2, rs2, attr2 = O.invert_neighbors_list(len(g["voxel_keys"]), idx, rs, attr)
     assert np.array_equal(idx2, g["up_neighbors_index"]) and np.array_equal(attr2, g["up_neighbors_kernel_index"])
+
+
+def test_grow_hand_worked_and_both_walks_agree():
+    """Octree::Grow (/root/reference/cpp/lib/octree.cpp:44-108) in the oracle.  Hand-worked: one point
+    (0.3, 0.3, 0.3), r 0.2 in [0,1]^3 -> level 2 (0.25 >= 0.2), cell (1,1,1), key 7 | 64 = 71.  One Grow
+    iteration on the key set {71}: parent 8 = level-1 cell (0,0,0); configuration 7 - (71 & 7) = 0, offset
+    (0,0,0), so the seven other cells of the block are parent + (1,0,0) .. (1,1,1) = keys 9..15 (none a node,
+    none with a child): inserted (:73-91); siblings 64..70 inserted (:94-101).  A second iteration: every key 9..15
+    (parent: the root, level 0) looks at level-0 cells next to the root: all outside the cube (INVALID_KEY);
+    keys 64..70 find 9..15 present.  Closure afterwards adds 8 and the root: 17 nodes either way."""
+    from oracle import oracle as O
+    pts, rad = np.array([[0.3, 0.3, 0.3]], np.float32), np.array([0.2], np.float32)
+    lo, hi = np.zeros(3, np.float32), np.ones(3, np.float32)
+    for steps in (1, 2):
+        for mode in (0, 1):
+            o = O.Oracle()
+            o.build_octree(pts, rad, lo, hi, mode=mode, grow_steps=steps)
+            assert o.nodes.tolist() == [1] + list(range(8, 16)) + list(range(64, 72))
+    # a point whose block reaches into neighbouring parents: (0.3,0.3,0.3) at level 3 -> cell (2,2,2), key
+    # Morton(2,2,2) = 56 | 512 = 568, child 0 of parent 71 = level-2 cell (1,1,1): configuration 7, offset (1,1,1):
+    # the block is parent + {-1,0}^3 without (0,0,0) = level-2 cells (0..1)^3 minus (1,1,1) = keys 64..70 (siblings of
+    # 71: the closure would add them anyway).  BalanceFaces then works as without Grow: the leaf group 568.. wants the
+    # face neighbours of its parent 71 = (1,1,1): (2,1,1) = 14|64 = 78, (1,2,1) = 21|64 = 85, (1,1,2) = 35|64 = 99 are
+    # missing -> their sibling groups 72..79, 80..87, 96..103 are inserted (octree.cpp:191-201)
+    o = O.Oracle()
+    o.build_octree(pts, np.array([0.1], np.float32), lo, hi, grow_steps=1)
+    assert o.nodes.tolist() == ([1] + list(range(8, 16)) + list(range(64, 88)) + list(range(96, 104)) +
+                                list(range(568, 576)))
+    # mixed-level scan clouds: the round-synchronous statement and the sequential walk give the same tree
+    from asr_hip import synth
+    for seed, n in ((3, 5000), (8, 20000)):
+        p, _ = synth.scan_cloud(n, seed=seed, device="cpu")
+        p = p.numpy()
+        r = synth.knn_radii(p, 24)
+        bb = synth.bounding_box(p, 0.1)
+        sizes = []
+        for steps in (0, 1, 2, 3):
+            res = []
+            for mode in (0, 1):
+                o = O.Oracle()
+                o.build_octree(p, r, *bb, mode=mode, grow_steps=steps)
+                res.append(o.nodes)
+            assert np.array_equal(res[0], res[1]), (seed, steps)
+            sizes.append(len(res[0]))
+        assert sizes[1] > sizes[0] and sizes[2] >= sizes[1]

@@ -119,6 +119,23 @@ def sphere_cloud(n, seed=0):
     return p, p.copy()
 
 
+def fused_scan_cloud(num_scans, points_per_scan, seed=0, device="cpu", spacing=4.0):
+    """C4: `num_scans` disjoint C3-style scans fused into one cloud -- scan i (seed + i) is moved to
+    cell i of a 2 x 2 x 2 .. lattice with `spacing` between the scene centres (a scene spans less than +-2).
+    Returns (points, normals) on `device`."""
+    import torch
+    pts, nrm = [], []
+    side = 1
+    while side ** 3 < num_scans:
+        side += 1
+    for i in range(num_scans):
+        p, q = scan_cloud(points_per_scan, seed=seed + i, device=device)
+        off = torch.tensor([i % side, (i // side) % side, i // (side * side)], dtype=torch.float32, device=p.device)
+        pts.append(p + off * spacing)
+        nrm.append(q)
+    return torch.cat(pts).contiguous(), torch.cat(nrm).contiguous()
+
+
 def knn_radii(points, k=24):
     """radius_i = distance to the k-th nearest neighbour including the point itself
     (cpp/lib/nsearch.cpp:30-51); exact, scipy cKDTree on the host cores."""

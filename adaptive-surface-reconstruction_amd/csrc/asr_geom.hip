@@ -178,6 +178,7 @@ __global__ void k_point_keys(asr_octree_frame f, const float* pts, const float* 
 // continues upwards; losers stop (CreateAncestorsAndSiblings, octree.cpp:110-150).
 __device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, u64* list,
                                              int list_cap) {
+    const int lane = threadIdx.x & 63;
     while (true) {
         if (a == 1) {
             int r = tab_insert(t, 1);
@@ -191,10 +192,19 @@ __device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, 
             cnt[1] = 1;
             return;
         }
-        if (r == 0) return;
+        // One list append per WAVE iteration: the lanes of the wave that are in this iteration of the loop and created
+        // a group share one atomic on the list counter (same-address atomics are the bottleneck of this kernel: one
+        // per new group was 0.37 M of them at 10 M points).  __ballot / __shfl act on the lanes that execute them.
+        const bool created = r == 1;
+        const unsigned long long m = __ballot(created);
+        if (!created) return;
         for (int j = 1; j < 8; ++j)
             if (tab_insert(t, first + j) < 0) cnt[1] = 1;
-        int pos = atomicAdd(&cnt[0], 8);
+        const int leader = __builtin_ctzll(m);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&cnt[0], 8 * __popcll(m));
+        base = __shfl(base, leader, 64);
+        const int pos = base + 8 * __popcll(m & ((1ull << lane) - 1));
         if (pos + 8 <= list_cap) {
             for (int j = 0; j < 8; ++j) list[pos + j] = first + j;
         } else {
@@ -3005,6 +3015,9 @@ __global__ void k_plan_masks_batch(PlanBatch b, uint4* __restrict__ hdr, i64* __
         counts[grow >> 4] = (i64)__popcll(m);
     }
 }
+// Thread r of a 16-thread group owns column r (its row) of every 64-byte line of the group: it walks the group's slot set
+// and its own row together (rows list their slots in ascending order, cpp/lib/grid.cpp:99-170,229-240) and writes the
+// neighbour or -1, so the 16 threads complete one line per store instruction and no line needs an initialising memset.
 __global__ void k_plan_fill_batch(PlanBatch b, const i64* __restrict__ offs, uint4* __restrict__ hdr,
                                   int32_t* __restrict__ pool) {
     const i64 grow = blockIdx.x * (i64)blockDim.x + threadIdx.x;
@@ -3014,16 +3027,25 @@ __global__ void k_plan_fill_batch(PlanBatch b, const i64* __restrict__ offs, uin
     if ((grow & 15) == 0) hdr[grp].z = off;
     const int j = plan_job_of(b, grow);
     const i64 row = grow - b.base[j];
-    if (row >= b.rows[j]) return;
     const uint2 h = *reinterpret_cast<const uint2*>(&hdr[grp]);
-    const unsigned long long m = (unsigned long long)h.x | ((unsigned long long)h.y << 32);
-    const i64 q = b.perm[j] ? b.perm[j][row] : row;
+    unsigned long long m = (unsigned long long)h.x | ((unsigned long long)h.y << 32);
+    i64 p = 0, pe = 0;
     const uint8_t* kidx = b.kidx[j];
     const int32_t* nidx = b.nidx[j];
-    for (i64 p = b.rs[j][q], pe = b.rs[j][q + 1]; p < pe; ++p) {
-        const int k = kidx[p];
-        if (k >= b.K[j]) continue;
-        pool[((i64)off + __popcll(m & ((1ull << k) - 1))) * 16 + (row & 15)] = nidx[p];
+    if (row < b.rows[j]) {
+        const i64 q = b.perm[j] ? b.perm[j][row] : row;
+        p = b.rs[j][q];
+        pe = b.rs[j][q + 1];
+    }
+    int32_t* line = pool + (i64)off * 16 + (grow & 15);
+    while (m) {
+        const int k = __builtin_ctzll(m);
+        m &= m - 1;
+        while (p < pe && kidx[p] < k) ++p;
+        int32_t v = -1;
+        if (p < pe && kidx[p] == k) v = nidx[p++];
+        *line = v;
+        line += 16;
     }
 }
 }  // namespace
@@ -3070,7 +3092,6 @@ int asr_geom_conv_plan_batch(asr_hip_context* ctx, Arena& keep, asr_conv_plan* p
     ASR_TRY(asr_prim::read_i64(ctx, offs + groups, &blocks));
     int32_t* pool = (int32_t*)keep.alloc((size_t)(blocks > 0 ? blocks : 1) * 64);
     if (!pool) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(pool, 0xFF, (size_t)(blocks > 0 ? blocks : 1) * 64, ctx->stream));
     k_plan_fill_batch<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, offs, hdr, pool);
     ASR_CHECK_LAUNCH(ctx);
     for (int t = 0; t < b.n; ++t) {

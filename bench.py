@@ -303,11 +303,16 @@ def one_scan_line(args, world, n, dt, sharded, extra):
     }
 
 
-def run_one_scan(args, world, rank, dev, weights, n, barrier, synth):
-    """timed one-scan steps + an instrumented extra step (exchange bytes / time); returns the bench line (rank 0)"""
+def run_one_scan(args, world, rank, dev, weights, n, barrier, synth, fused=0):
+    """timed one-scan steps + an instrumented extra step (exchange bytes / time); returns the bench line (rank 0).
+    fused > 0: config C4, `fused` scans of n points each in one cloud (weak scaling when fused == world)"""
     from asr_hip import sharding
     from asr_hip.sharding import ShardedImplicitPipeline
-    pts, nrm = synth.scan_cloud(n, seed=rank_seed(0), device=dev, density_variance=args.density_variance)
+    if fused:
+        pts, nrm = synth.fused_scan_cloud(fused, n, seed=rank_seed(0), device=dev)
+        n = int(pts.shape[0])
+    else:
+        pts, nrm = synth.scan_cloud(n, seed=rank_seed(0), device=dev, density_variance=args.density_variance)
     radii = synth.knn_radii_gpu(pts, 24)
     bb_min, bb_max = synth.bounding_box(pts, 0.1)
     sharded = ShardedImplicitPipeline(weights, dev, precision="bf16x3" if args.precision == "bf16x3" else "f32")
@@ -329,6 +334,10 @@ def run_one_scan(args, world, rank, dev, weights, n, barrier, synth):
              "exchange_ms_rank0": round(st["seconds"] * 1e3, 3),
              "exchange_note": "instrumented extra step (device synchronised around every exchange), outside the timed region"}
     line = one_scan_line(args, world, n, dt, sharded, extra) if rank == 0 else None
+    if line is not None and fused:
+        line["scaling"] = "weak"
+        line["config"]["workload"] = ("C4: %d scan-like clouds fused into one %d-point cloud, sharded over %d GPU(s) by "
+                                      "Morton range (as the C3 sharded line)" % (fused, n, world))
     del sharded
     torch.cuda.empty_cache()
     return line
@@ -414,6 +423,17 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
             return
+
+    # ---- config C4 (8 GPUs: eight fused scans, 80 M points, sharded): informational sub-record ------
+    c4_out = None
+    if mode == "one-scan" and one_scan_error is None and (world == 8 or os.environ.get("ASR_BENCH_C4")):
+        try:
+            import copy
+            a4 = copy.copy(args)
+            a4.steps, a4.warmup = 1, 1
+            c4_out = run_one_scan(a4, world, rank, dev, weights, n, barrier, synth, fused=world)
+        except Exception as e:
+            c4_out = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- one scan per rank: inputs (untimed), radii = exact 24-NN distance ------------------------
     pts, nrm = synth.scan_cloud(n, seed=rank_seed(rank), device=dev, density_variance=args.density_variance)
@@ -527,6 +547,9 @@ def main():
             head["roofline"] = out["roofline"]
             head["roofline"]["note"] = "dominant kernel measured in the replica run of this job (one scan per GPU)"
             head["roofline_geometry"] = out["roofline_geometry"]
+            if c4_out is not None:
+                head["config"]["c4_fused_scans"] = ({k: c4_out[k] for k in ("value", "ms_per_step", "scaling", "config")}
+                                                    if "value" in c4_out else c4_out)
             out = head
         elif one_scan_error is not None:
             out["config"]["one_scan_error"] = one_scan_error

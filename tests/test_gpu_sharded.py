@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_points, channel_div, precision, out):
+def _worker(rank, world, port, n_points, channel_div, precision, out, fused=0):
     sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd"), os.path.join(REPO, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -34,7 +34,10 @@ def _worker(rank, world, port, n_points, channel_div, precision, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from asr_hip import sharding, synth
     from asr_hip.pipeline import ImplicitPipeline
-    pts, nrm = synth.scan_cloud(n_points, seed=55, device=dev, density_variance=10.0)
+    if fused:  # config C4: `fused` disjoint scans in one cloud
+        pts, nrm = synth.fused_scan_cloud(fused, n_points // fused, seed=70, device=dev)
+    else:
+        pts, nrm = synth.scan_cloud(n_points, seed=55, device=dev, density_variance=10.0)
     rad = synth.knn_radii_gpu(pts, 24)
     bb = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(channel_div, seed=6)
@@ -71,3 +74,25 @@ def test_sharded_values_equal_single_process(gpu, world, n_points, channel_div, 
     assert r0["equal"], r0["max_abs_diff"]
     assert sum(i["owned"][0] for i in infos) == r0["v0"]
     assert all(i["halo"]["nb", 0] > 0 for i in infos)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fused_multi_scan_cloud_equals_single_process(gpu, world):
+    """BASELINE config C4 in small: eight disjoint scans fused into one cloud, cut into Morton ranges over `world`
+    processes (the cuts fall between and inside scans), bf16x3 arithmetic; the stitched values equal the monolithic
+    driver's bit for bit"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 64000, 2, "bf16x3", out, 8)) for r in range(world)]
+    for p in procs:
+        p.start()
+    infos = sorted([out.get(timeout=900) for _ in range(world)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = infos[0]
+    assert r0["equal"], r0["max_abs_diff"]
+    assert sum(i["owned"][0] for i in infos) == r0["v0"]
+    owned = [i["owned"][0] for i in infos]
+    assert max(owned) < 1.5 * min(owned)  # equal pair counts per rank give similar row counts

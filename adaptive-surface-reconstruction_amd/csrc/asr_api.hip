@@ -48,6 +48,7 @@ const OptEntry k_options[] = {
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
         {"search_groups", "ASR_SEARCH_GROUPS", &AsrOptions::search_groups},
         {"presort", "ASR_PRESORT", &AsrOptions::presort},
+        {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
 };
 
 // asr::GetPrintCallbackFunction (cpp/lib/asr.cpp:34-37): one callback per verbosity level, process wide
@@ -812,33 +813,11 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "degenerate bounding box");
     asr_hip_print("grid building\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:144
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    ctx->pindex.valid = false;
-    if (ctx->opt.presort) ASR_TRY(asr_geom_presort(ctx, ctx->persist, &ctx->frame, points, radii, n));
-    ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale,
-                                  prm->octree_max_depth, ctx->pindex.valid ? &ctx->pindex : nullptr));
-    ctx->sizes.num_nodes = ctx->num_nodes;
-    name_it(ctx, "nodes", ctx->nodes, 8 * ctx->num_nodes);
-    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if (ctx->num_leaves == 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "no point inside the bounding box");
-
-    // level-0 voxel centres / sizes first: the aggregation search only needs those
-    {
-        GridDev& g0 = ctx->grids[0];
-        g0 = GridDev();
-        g0.v = ctx->num_leaves;
-        g0.keys = ctx->leaves;
-        g0.centers = arena_alloc<float>(ctx->persist, 3 * g0.v);
-        g0.sizes = arena_alloc<float>(ctx->persist, g0.v);
-        if (!g0.centers || !g0.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g0.keys, g0.v, g0.centers, g0.sizes));
-    }
-
     // Aggregation neighbours (cpp/lib/asr.cpp:266-273) on the auxiliary context: its own stream, arenas,
     // counters and host thread, overlapped with the grid hierarchy below.  Both are chains of
     // latency-bound kernels with host round trips for the data-dependent sizes; neither fills the GPU.
     const bool want_search = ctx->opt.build_search != 0;
     const bool overlap = want_search && ctx->opt.overlap != 0;
-    if (want_search) asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264 (here: concurrent with the grids)
     asr_hip_context* sc = ctx;  // context the search runs on
     if (overlap) {
         if (!ctx->aux) {
@@ -860,9 +839,39 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         sc->persist.reset();
         sc->scratch.reset();
         sc->err.clear();
-        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));      // inputs + level-0 info are ready
+        sc->pindex.valid = false;
+        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));  // the inputs are ready
         ASR_HIP_CHECK(ctx, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
         ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_t0, sc->stream));  // the search is timed on ITS stream
+        // The search's point sort needs nothing from the octree (it sorts deep enough for any realistic leaf level,
+        // PRESORT_LEVEL): enqueued on the auxiliary stream now, it runs beside the octree construction.
+        if (ctx->opt.early_sort) ASR_TRY(asr_geom_presort(sc, sc->persist, &ctx->frame, points, radii, n));
+    }
+    ctx->pindex.valid = false;
+    if (ctx->opt.presort) ASR_TRY(asr_geom_presort(ctx, ctx->persist, &ctx->frame, points, radii, n));
+    ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale,
+                                  prm->octree_max_depth, ctx->pindex.valid ? &ctx->pindex : nullptr));
+    ctx->sizes.num_nodes = ctx->num_nodes;
+    name_it(ctx, "nodes", ctx->nodes, 8 * ctx->num_nodes);
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->num_leaves == 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "no point inside the bounding box");
+
+    // level-0 voxel centres / sizes first: the aggregation search only needs those
+    {
+        GridDev& g0 = ctx->grids[0];
+        g0 = GridDev();
+        g0.v = ctx->num_leaves;
+        g0.keys = ctx->leaves;
+        g0.centers = arena_alloc<float>(ctx->persist, 3 * g0.v);
+        g0.sizes = arena_alloc<float>(ctx->persist, g0.v);
+        if (!g0.centers || !g0.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g0.keys, g0.v, g0.centers, g0.sizes));
+    }
+
+    if (want_search) asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264 (here: concurrent with the grids)
+    if (overlap) {
+        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));  // the level-0 voxel centres / sizes are ready
+        ASR_HIP_CHECK(ctx, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
     }
     ctx->search_overlapped = overlap;
     i64 agg_pairs = 0;
@@ -880,7 +889,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         if (!ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
                                       &agg_pairs, &sc->persist, radii, g0.keys, ctx->leaf_lmin, ctx->leaf_lmax,
-                                      ctx->pindex.valid ? &ctx->pindex : nullptr));
+                                      sc->pindex.valid ? &sc->pindex : (ctx->pindex.valid ? &ctx->pindex : nullptr)));
         ctx->agg_idx = arena_alloc<int32_t>(sc->persist, agg_pairs);
         ctx->agg_dist = arena_alloc<float>(sc->persist, agg_pairs);
         ctx->agg_compat = arena_alloc<float>(sc->persist, agg_pairs);

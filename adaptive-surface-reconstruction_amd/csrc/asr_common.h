@@ -108,6 +108,7 @@ struct AsrOptions {
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
     i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
     i64 search_groups = 0;        // aggregation search: 1 = one wave per sibling group of voxels (measured slower: 3.6 vs 3.3 ms at 10 M points, the kernel is bound by the latency chain of a wave, not by its table probes)
+    i64 early_sort = 1;           // overlapped search: its point sort starts on the auxiliary stream beside the octree build
     i64 presort = 0;              // implicit_build: 1 = points sorted once, up front, for octree insertion and search (measured slower: neighbouring lanes contend for the same table slots, insertion 1.6 vs 1.1 ms)
 };
 

@@ -931,7 +931,7 @@ __global__ void k_radius_extras(const u64* codes, const float4* sorted, i64 n, c
 // are ranked inside the wave (rank = number of smaller keys, keys are unique) and written, sorted, to the row's fixed
 // slot tmp[q * RADIUS_LIGHT ..] as (distance, position in Morton order): k_radius_place turns the position back into
 // the index with a clustered read.
-__device__ inline void radius_row_out(i64 q, i64 found, bool heavy, int lane, const u64* s_keys, const int* s_pos,
+__device__ __forceinline__ void radius_row_out(i64 q, i64 found, bool heavy, int lane, const u64* s_keys, const int* s_pos,
                                       i64* counts, u64* tmp, int32_t* heavy_out, int* heavy_cnt, uint8_t* is_heavy) {
     if (heavy) {  // counted and written by k_radius_heavy
         if (lane == 0) {
@@ -1062,56 +1062,41 @@ __global__ __launch_bounds__(256) void k_radius_groups(const float4* sorted, con
     }
 }
 
+// one query of k_radius_query by one wave; s_*: the wave's LDS rows
 template <int MODE, bool ALIGNED>
-__global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
-                                                      const float* centers, const float* sizes,
-                                                      i64 v, CellIndex ci, AlignedQ aq, i64* counts, u64* tmp,
-                                                      int32_t* heavy_out, int* heavy_cnt,
-                                                      uint8_t* is_heavy, const int32_t* list, const int* list_cnt) {
+__device__ __forceinline__ void radius_query_one(const asr_octree_frame& f, const float4* sorted, const float* centers,
+                                                 const float* sizes, i64 q, const CellIndex& ci, const AlignedQ& aq,
+                                                 i64* counts, u64* tmp, int32_t* heavy_out, int* heavy_cnt, uint8_t* is_heavy,
+                                                 int lane, int* s_pref, int* s_beg, u64* s_keys, int* s_pos) {
     constexpr int NCELL = ALIGNED ? 64 : 27;
-    __shared__ int s_pref[4][NCELL + 1];
-    __shared__ int s_beg[4][NCELL];
-    __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
-    __shared__ int s_pos[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // all queries 0..v (launch of ceil((v + 1) / 4) blocks), or -- grid-stride -- the queries of a device-side list
-    const i64 nq = list ? (i64)*list_cnt : v + 1;
-    for (i64 qi = blockIdx.x * (i64)4 + wave; qi < nq; qi += (i64)gridDim.x * 4) {
-    const i64 q = list ? (i64)list[qi] : qi;
-    if (q == v && lane == 0) counts[v] = 0;
-    if (q >= v) continue;
-    __builtin_amdgcn_wave_barrier();  // the LDS tables of the previous query have been read
     const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
     const float r = sizes[q];
     const float r2 = r * r;
-    const int total = ALIGNED ? aligned_cells(ci, aq, aq.keys[q], lane, s_pref[wave], s_beg[wave])
-                              : radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
+    const int total = ALIGNED ? aligned_cells(ci, aq, aq.keys[q], lane, s_pref, s_beg)
+                              : radius_cells(f, ci, cx, cy, cz, r, lane, s_pref, s_beg);
     i64 found = 0;
     bool heavy = MODE == 2 && total > RADIUS_GIANT;
-    auto consume = [&](bool hit, float d, int id, int pos) {
-        const unsigned long long m = __ballot(hit);
-        if (MODE == 2 && hit) {
-            const i64 o = found + __popcll(m & ((1ull << lane) - 1));
-            if (o < RADIUS_LIGHT) {
-                s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
-                s_pos[wave][o] = pos;
-            }
-        }
-        found += __popcll(m);
-        if (MODE == 2 && found > RADIUS_LIGHT) heavy = true;
-    };
     for (int i0 = 0; i0 < total && !heavy; i0 += 64) {
         const int i = i0 + lane;
         bool hit = false;
         float d = 0.f;
         int id = 0, pos = 0;
         if (i < total) {
-            const float4 pt = radius_candidate<NCELL>(sorted, s_pref[wave], s_beg[wave], i, &pos);
+            const float4 pt = radius_candidate<NCELL>(sorted, s_pref, s_beg, i, &pos);
             d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
             hit = d < r2;
             id = __float_as_int(pt.w);
         }
-        consume(hit, d, id, pos);
+        const unsigned long long m = __ballot(hit);
+        if (MODE == 2 && hit) {
+            const i64 o = found + __popcll(m & ((1ull << lane) - 1));
+            if (o < RADIUS_LIGHT) {
+                s_keys[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+                s_pos[o] = pos;
+            }
+        }
+        found += __popcll(m);
+        if (MODE == 2 && found > RADIUS_LIGHT) heavy = true;
     }
     if (ALIGNED) {  // the pairs of the rounding margin (k_radius_extras): normally none at all
         const int nex = min(*aq.extras_cnt, EXTRA_CAP);
@@ -1130,14 +1115,53 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
                     id = __float_as_int(pt.w);
                 }
             }
-            if (__ballot(hit)) consume(hit, d, id, pos);
+            const unsigned long long m = __ballot(hit);
+            if (MODE == 2 && hit) {
+                const i64 o = found + __popcll(m & ((1ull << lane) - 1));
+                if (o < RADIUS_LIGHT) {
+                    s_keys[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+                    s_pos[o] = pos;
+                }
+            }
+            found += __popcll(m);
+            if (MODE == 2 && found > RADIUS_LIGHT) heavy = true;
         }
     }
     if (MODE == 0) {
         if (lane == 0) counts[q] = found;
-        continue;
+        return;
     }
-    radius_row_out(q, found, heavy, lane, s_keys[wave], s_pos[wave], counts, tmp, heavy_out, heavy_cnt, is_heavy);
+    radius_row_out(q, found, heavy, lane, s_keys, s_pos, counts, tmp, heavy_out, heavy_cnt, is_heavy);
+}
+
+// all queries 0..v (launch of ceil((v + 1) / 4) blocks, one query per wave) or -- LIST, grid-stride -- the queries of a
+// device-side list
+template <int MODE, bool ALIGNED, bool LIST = false>
+__global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
+                                                      const float* centers, const float* sizes,
+                                                      i64 v, CellIndex ci, AlignedQ aq, i64* counts, u64* tmp,
+                                                      int32_t* heavy_out, int* heavy_cnt,
+                                                      uint8_t* is_heavy, const int32_t* list, const int* list_cnt) {
+    constexpr int NCELL = ALIGNED ? 64 : 27;
+    __shared__ int s_pref[4][NCELL + 1];
+    __shared__ int s_beg[4][NCELL];
+    __shared__ u64 s_keys[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
+    __shared__ int s_pos[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kw = MODE == 2 ? wave : 0;
+    if (!LIST) {
+        const i64 q = blockIdx.x * (i64)4 + wave;
+        if (q == v && lane == 0) counts[v] = 0;
+        if (q >= v) return;
+        radius_query_one<MODE, ALIGNED>(f, sorted, centers, sizes, q, ci, aq, counts, tmp, heavy_out, heavy_cnt, is_heavy, lane,
+                                        s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
+    } else {
+        const i64 nq = *list_cnt;
+        for (i64 qi = blockIdx.x * (i64)4 + wave; qi < nq; qi += (i64)gridDim.x * 4) {
+            __builtin_amdgcn_wave_barrier();  // the LDS rows of the previous query have been read
+            radius_query_one<MODE, ALIGNED>(f, sorted, centers, sizes, list[qi], ci, aq, counts, tmp, heavy_out, heavy_cnt,
+                                            is_heavy, lane, s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
+        }
     }
 }
 
@@ -2599,14 +2623,18 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         qlist_cnt = gcnt + 1;
         qgrid = 1024;
     }
-    if (st.aligned)
-        k_radius_query<2, true><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts,
-                                                                 st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy, qlist,
-                                                                 qlist_cnt);
+#define ASR_RQ(AL_, LI_)                                                                                              \
+    k_radius_query<2, AL_, LI_><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts, \
+                                                                 st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy, qlist, qlist_cnt)
+    if (st.aligned && qlist)
+        ASR_RQ(true, true);
+    else if (st.aligned)
+        ASR_RQ(true, false);
+    else if (qlist)
+        ASR_RQ(false, true);
     else
-        k_radius_query<2, false><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq,
-                                                                  counts, st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy,
-                                                                  qlist, qlist_cnt);
+        ASR_RQ(false, false);
+#undef ASR_RQ
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(read_flags(ctx, host));
     if (host[1]) {  // retry with a table four times the size

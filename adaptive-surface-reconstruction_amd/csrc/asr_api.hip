@@ -38,6 +38,7 @@ const OptEntry k_options[] = {
         {"row_segment", "ASR_ROW_SEGMENT", &AsrOptions::row_segment},
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
+        {"sconv16_rg", "ASR_SCONV16_RG", &AsrOptions::sconv16_rg},
         {"sconv16_min_blocks", "ASR_SCONV16_MIN_BLOCKS", &AsrOptions::sconv16_min_blocks},
         {"knn_cells", "ASR_KNN_CELLS", &AsrOptions::knn_cells},
         {"knn_deep", "ASR_KNN_DEEP", &AsrOptions::knn_deep},

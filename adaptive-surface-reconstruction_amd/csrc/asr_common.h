@@ -101,6 +101,7 @@ struct AsrOptions {
     i64 search_hash_level = -1;   // >= 0: finest level of the search's cell hash table (finer: binary search); tests
     i64 knn_deep = 1;             // kNN radius: finer start levels for the points of crowded cells (0: off)
     i64 knn_cells = 1;            // kNN radius: cell-parallel fast path (0: wave per point only)
+    i64 sconv16_rg = 0;           // plan-driven bf16x3 sparse conv: two 16-row groups per wave (1 = column tiles <= 64, 2 = all, 3 = forced; measured at 10 M points: U-Net 26.95 / 28.66 ms against 26.99 with one group -- half the panel traffic buys nothing)
     i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids

@@ -102,7 +102,7 @@ EXPORTS = [
     "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_weights_changed", "asr_hip_context_set_option", "asr_hip_context_get_option",
     "asr_hip_sparse_conv_variant_counts", "asr_hip_sparse_conv_packed_bytes", "asr_hip_sparse_conv_pack",
     "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_convert_f16",
-    "asr_hip_sparse_conv_plan_create", "asr_hip_sparse_conv_plan_destroy", "asr_hip_sparse_conv_plan_bytes",
+    "asr_hip_sparse_conv_plan_create", "asr_hip_sparse_conv_plan_destroy", "asr_hip_sparse_conv_plan_bytes", "asr_hip_context_plan_arena_reset",
     "asr_octree_frame_init", "asr_hip_point_keys", "asr_hip_octree_build", "asr_hip_octree_build_grow", "asr_hip_octree_get", "asr_hip_dual_cells_count", "asr_hip_dual_cells_count_for", "asr_hip_dual_cells_fill",
     "asr_hip_contour_count", "asr_hip_contour_fill", "asr_hip_components_count", "asr_hip_components_fill",
     "asr_hip_unordered_set_order", "asr_density_inlier",
@@ -111,7 +111,7 @@ EXPORTS = [
     "asr_hip_multi_radius_search_fill", "asr_hip_knn_radius", "asr_hip_radius_neighbor_count", "asr_hip_continuous_conv_f32", "asr_hip_continuous_conv_basis_f32",
     "asr_hip_aggregation_importance", "asr_hip_sparse_conv_f32", "asr_hip_invert_neighbors_list", "asr_hip_row_groups",
     "asr_hip_reduce_subarrays_sum", "asr_hip_decode_mlp", "asr_hip_implicit_build",
-    "asr_hip_implicit_network", "asr_hip_implicit_forward", "asr_hip_implicit_get",
+    "asr_hip_implicit_network", "asr_hip_implicit_aggregate", "asr_hip_implicit_forward", "asr_hip_implicit_get",
     "asr_hip_implicit_stage_ms",
 ]
 

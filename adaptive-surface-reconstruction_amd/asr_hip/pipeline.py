@@ -149,6 +149,15 @@ class ImplicitPipeline:
                       ctypes.byref(p), ctypes.c_void_p(0))
         return self.get("values")
 
+    def aggregate(self, points, normals, bb_min, bb_max):
+        """UNet5.aggregate alone on the structures of the last build(): -> (feats1 [V0, C], importance [P_agg])"""
+        self._check(points, normals, points[:, 0].contiguous())
+        self._stream()
+        p = self._params(bb_min, bb_max)
+        self.ctx.call("asr_hip_implicit_aggregate", ptr(points), ptr(normals), ctypes.c_int64(points.shape[0]),
+                      self._table, len(self._weights), ctypes.byref(p))
+        return self.get("feats1"), self.get("importance")
+
     def get(self, name):
         """copy of one named array of the last forward (see include/asr_hip.h)"""
         base = name if name in _ARRAY_TYPES else name.rstrip("0123456789")

@@ -92,6 +92,8 @@ class ExchangePlan:
 def make_plan(rank, world, csr_index, csr_row_splits, owner_out, owner_in):
     """Halo of the consumer rows every rank owns: pairs (row, idx) whose two ends have different owners;
     the input row `idx` travels from owner_in[idx] to owner_out[row]."""
+    if world == 1:
+        return ExchangePlan({}, {})
     idx = csr_index.long()
     lens = csr_row_splits[1:] - csr_row_splits[:-1]
     row_owner = torch.repeat_interleave(owner_out, lens)
@@ -209,7 +211,7 @@ class ShardedNetwork:
                 self.g["%s_row_splits%d" % (pre, i)])
 
     def _conv(self, name, x, kind, i, out_level, imp=None, normalize=False, residual=None, dual=False,
-              imp_replicated=False):
+              imp_replicated=False, out=None):
         """one SpecialSparseConv (+ bias, ReLU; models/common_torch.py:95-148) on the owned rows of
         `out_level`; x: full-size input buffer whose owned rows are valid.  dual: conv1a + conv1b of a block
         (plain bank | importance weighted, normalised bank) -> (out, out_importance).  imp: importance of the
@@ -217,51 +219,77 @@ class ShardedNetwork:
         halo = [x] if imp is None or imp_replicated else [x, imp]
         exchange(halo, self.plans[kind, i], self.group)
         rows = self.rows[out_level]
+        kw = {"out": out} if out is not None else {}  # (a column slice of a concat buffer: backends with supports_out)
         if dual:
             return self.be.sparse_conv_ab(self.w[name + ".conv1a.kernel"], self.w[name + ".conv1a.bias"],
                                           self.w[name + ".conv1b.kernel"], self.w[name + ".conv1b.bias"], x,
-                                          self._csr(kind, i), rows, self.v[out_level], imp)
+                                          self._csr(kind, i), rows, self.v[out_level], imp, **kw)
         return self.be.sparse_conv(self.w[name + ".kernel"], self.w[name + ".bias"], x, self._csr(kind, i), rows,
-                                   self.v[out_level], imp, normalize, residual)
+                                   self.v[out_level], imp, normalize, residual, **kw)
 
-    def _block(self, name, x, i, imp, with_imp, imp_replicated=False):
-        """SparseConvBlock (net_definitions_torch.py:253-302)"""
+    def _block(self, name, x, i, imp, with_imp, imp_replicated=False, out=None):
+        """SparseConvBlock (net_definitions_torch.py:253-302); out: where conv4 writes (e.g. the encoder half of the
+        decoder's concat buffer)"""
         out_imp = None
         if with_imp:
             f, out_imp = self._conv(name, x, "nb", i, i, imp=imp, dual=True, imp_replicated=imp_replicated)
         else:
             f = self._conv(name + ".conv1", x, "nb", i, i)
-        for k in (2, 3, 4):
+        for k in (2, 3):
             f = self._conv(name + ".conv%d" % k, f, "nb", i, i)
+        f = self._conv(name + ".conv4", f, "nb", i, i, out=out)
         return f, out_imp
 
-    def forward(self, points, normals, radii, frame_or_bb, scale_sdf=True):
-        """-> (values_owned [n_owned, 2], owned_rows).  stitch() assembles the full array."""
+    def forward(self, points, normals, radii, frame_or_bb, scale_sdf=True, feats1=None, importance=None):
+        """-> (values_owned [n_owned, 2], owned_rows).  stitch() assembles the full array.
+        feats1 [V0, C] / importance [P_agg]: the aggregation of the WHOLE cloud when the caller has it (the GPU
+        pipeline runs its fast whole-cloud aggregation on every rank: cheaper than a generic search of the owned rows
+        plus the importance prefix up to ~8 ranks); else the backend aggregates the rows this rank owns."""
         g, w, be = self.g, self.w, self.be
         V0 = self.v[0]
         own0 = self.rows[0]
-        # ---- aggregate (net_definitions_torch.py:640-653): search + continuous conv for the owned voxels
-        feats1_own, _ = be.aggregate(points, normals, radii, frame_or_bb, g["voxel_centers0"][own0],
-                                     g["voxel_sizes0"][own0], w["cconv_block_in.conv1.kernel"],
-                                     w["cconv_block_in.conv1.bias"])
-        feats1 = torch.zeros((V0, feats1_own.shape[1]), dtype=feats1_own.dtype, device=feats1_own.device)
-        feats1[own0] = feats1_own
-        # SURVEY B.2 (net_definitions_torch.py:572-578 -> common_torch.py:125): encblock0 indexes the per-PAIR
-        # importance array of the aggregation with grid-0 VOXEL indices, i.e. it reads the importance of the
-        # first V0 pairs of the global CSR.  Those belong to the first few percent of the voxels in index
-        # order; every rank searches that prefix itself (replicated, no communication).
-        imp_prefix = self._importance_prefix(points, normals, radii, frame_or_bb, V0)
+        if feats1 is None:
+            # ---- aggregate (net_definitions_torch.py:640-653): search + continuous conv for the owned voxels
+            feats1_own, _ = be.aggregate(points, normals, radii, frame_or_bb, g["voxel_centers0"][own0],
+                                         g["voxel_sizes0"][own0], w["cconv_block_in.conv1.kernel"],
+                                         w["cconv_block_in.conv1.bias"])
+            feats1 = torch.zeros((V0, feats1_own.shape[1]), dtype=feats1_own.dtype, device=feats1_own.device)
+            feats1[own0] = feats1_own
+            # SURVEY B.2 (net_definitions_torch.py:572-578 -> common_torch.py:125): encblock0 indexes the per-PAIR
+            # importance array of the aggregation with grid-0 VOXEL indices, i.e. it reads the importance of the
+            # first V0 pairs of the global CSR.  Those belong to the first few percent of the voxels in index
+            # order; every rank searches that prefix itself (replicated, no communication).
+            imp_prefix = self._importance_prefix(points, normals, radii, frame_or_bb, V0)
+        else:
+            if importance.shape[0] < V0:  # the reference would index out of range here (torch raises)
+                raise RuntimeError("aggregation pairs (%d) < voxels (%d): reference indexing is out of range"
+                                   % (importance.shape[0], V0))
+            imp_prefix = importance[:V0]
+        # decoder inputs [up_i | enc_i] (:617-618): both producers write into their half of one buffer
+        direct = bool(getattr(be, "supports_out", False))
+        c_enc = [int(w["sparseconv_encblock%d.conv4.kernel" % i].shape[2]) for i in range(NUM_GRIDS)]
+        c_up = [int(w["sparseconv_up%d.conv1.kernel" % i].shape[2]) for i in range(NUM_GRIDS - 1)]
+        cat = [None] * NUM_GRIDS
+        if direct:
+            for i in (1, 2, 3):
+                cat[i] = torch.empty((self.v[i], c_up[i] + c_enc[i]), dtype=feats1.dtype, device=feats1.device)
         # ---- unet (net_definitions_torch.py:535-638)
         enc = [None] * NUM_GRIDS
         enc[0], imp = self._block("sparseconv_encblock0", feats1, 0, imp_prefix, True, imp_replicated=True)
         for i in range(1, NUM_GRIDS):
             dn = "sparseconv_down%d" % (i if i < 4 else 3)   # down3 is re-used for 3 -> 4 (:596-598)
             t, imp_d = self._conv(dn, enc[i - 1], "down", i - 1, i, imp=imp, dual=True)
-            enc[i], imp = self._block("sparseconv_encblock%d" % i, t, i, imp_d, True)
+            enc[i], imp = self._block("sparseconv_encblock%d" % i, t, i, imp_d, True,
+                                      out=cat[i][:, c_up[i]:] if cat[i] is not None else None)
         cur = enc[4]
         for i in (3, 2, 1):
-            up = self._conv("sparseconv_up%d.conv1" % i, cur, "up", i, i)
-            cur, _ = self._block("sparseconv_decblock%d" % i, torch.cat([up, enc[i]], 1), i, None, False)
+            if cat[i] is not None:
+                self._conv("sparseconv_up%d.conv1" % i, cur, "up", i, i, out=cat[i][:, :c_up[i]])
+                x = cat[i]
+            else:
+                up = self._conv("sparseconv_up%d.conv1" % i, cur, "up", i, i)
+                x = torch.cat([up, enc[i]], 1)
+            cur, _ = self._block("sparseconv_decblock%d" % i, x, i, None, False)
         f21 = self._conv("sparseconv_up0.conv1", cur, "up", 0, 0, residual=enc[0])  # :631-633
         code, _ = self._block("sparseconv_decblock0", f21, 0, None, False)
         # ---- decode + sdf scale (:655-666, cpp/lib/asr.cpp:324-336)
@@ -311,13 +339,21 @@ class HipBackend:
             raise ValueError("HipBackend: precision must be 'f32' or 'bf16x3'")
         self.device = torch.device(device)
         self.precision = precision
+        self.supports_out = True  # sparse_conv(..., out=<column slice of a wider buffer>)
         self._packed = {}   # weight tensors (by identity) -> packed 16-bit copy; kept across forwards
         self._plans = {}    # (row splits, row list) -> (int32 row list, ConvPlan); one geometry
+        self._rows32_cache = {}
         self._keep = []
 
     def new_geometry(self):
-        """the neighbour lists changed: plans of the previous geometry are dropped"""
+        """the neighbour lists changed: plans of the previous geometry are dropped (their memory, taken from the
+        context's plan arena, is recycled in one go)"""
+        from . import ops
         self._plans.clear()
+        self._rows32_cache.clear()
+        ctx = ops.context(self.device)
+        ctx.set_option("plan_arena", 1)
+        ctx.call("asr_hip_context_plan_arena_reset")
 
     def _pack(self, kernel, kernel_b=None):
         from . import ops
@@ -336,10 +372,11 @@ class HipBackend:
             self._plans[key] = (perm, ops.ConvPlan(K, idx, kidx, rs, row_perm=perm, num_rows=rows.numel()), rows)
         return self._plans[key][:2]
 
-    def sparse_conv(self, kernel, bias, x, csr, rows, v_out, imp=None, normalize=False, residual=None):
+    def sparse_conv(self, kernel, bias, x, csr, rows, v_out, imp=None, normalize=False, residual=None, out=None):
         from . import ops
         idx, kidx, rs = csr
-        out = torch.zeros((v_out, kernel.shape[2]), dtype=torch.float32, device=self.device)
+        if out is None:  # only the owned rows are written; the others are never read before an exchange fills them
+            out = torch.empty((v_out, kernel.shape[2]), dtype=torch.float32, device=self.device)
         if self.precision == "bf16x3" and x.shape[1] % 4 == 0:
             perm, plan = self._plan(kernel.shape[0], csr, rows)
             return ops.sparse_conv16("bf16x3", self._pack(kernel), kernel.shape[0], kernel.shape[1], kernel.shape[2], x,
@@ -348,14 +385,21 @@ class HipBackend:
                                      num_rows=rows.numel(), plan=plan)
         return ops.sparse_conv(kernel, x, idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias,
                                relu=True, residual=residual, out=out, return_importance=imp is not None,
-                               row_perm=rows.to(torch.int32), num_rows=rows.numel())
+                               row_perm=self._rows32(rows), num_rows=rows.numel())
 
-    def sparse_conv_ab(self, ka, ba, kb, bb, x, csr, rows, v_out, imp):
+    def _rows32(self, rows):
+        key = (rows.data_ptr(), int(rows.numel()))
+        if key not in self._rows32_cache:
+            self._rows32_cache[key] = (rows.to(torch.int32).contiguous(), rows)
+        return self._rows32_cache[key][0]
+
+    def sparse_conv_ab(self, ka, ba, kb, bb, x, csr, rows, v_out, imp, out=None):
         """conv1a + conv1b in one launch when the fused kernel takes the widths, else two launches"""
         from . import ops
         idx, kidx, rs = csr
         ca, cb = ka.shape[2], kb.shape[2]
-        out = torch.zeros((v_out, ca + cb), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((v_out, ca + cb), dtype=torch.float32, device=self.device)
         fused = ca % 16 == 8 and cb == 8 and x.shape[1] % 4 == 0
         if fused and self.precision == "bf16x3":
             perm, plan = self._plan(ka.shape[0], csr, rows)
@@ -366,7 +410,7 @@ class HipBackend:
             return out, oimp
         if fused:
             _, oimp = ops.sparse_conv(ka, x, idx, kidx, rs, inp_importance=imp, normalize=True, bias=ba, relu=True,
-                                      out=out, return_importance=True, algo=2, row_perm=rows.to(torch.int32),
+                                      out=out, return_importance=True, algo=2, row_perm=self._rows32(rows),
                                       num_rows=rows.numel(), filters_b=kb, bias_b=bb)
             return out, oimp
         a = self.sparse_conv(ka, ba, x, csr, rows, v_out)
@@ -418,7 +462,10 @@ class ShardedImplicitPipeline:
         self.pipe = ImplicitPipeline(weights, device=device, point_radius_scale=point_radius_scale,
                                      octree_max_depth=octree_max_depth, scale_sdf=scale_sdf)
         self.backend = HipBackend(self.pipe.device, precision)
-        self.pipe.ctx.set_option("build_search", 0)  # each rank searches only the rows it owns
+        # every rank runs the whole-cloud aggregation of the monolithic driver (search overlapped with the grid build,
+        # Morton-ordered continuous conv): replicated work, but cheaper than a generic search of the owned rows plus
+        # the importance prefix; whole_cloud_aggregation = False restores the owned-rows form
+        self.whole_cloud_aggregation = True
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -427,9 +474,14 @@ class ShardedImplicitPipeline:
     def forward(self, points, normals, radii, bb_min, bb_max):
         from . import _lib
         pipe = self.pipe
+        pipe.ctx.set_option("build_search", 1 if self.whole_cloud_aggregation else 0)
         pipe.build(points, radii, bb_min, bb_max)
+        feats1 = importance = None
+        if self.whole_cloud_aggregation:
+            feats1, importance = pipe.aggregate(points, normals, bb_min, bb_max)
         geom = geometry_from_pipeline(pipe)
         self.backend.new_geometry()
         self.net = ShardedNetwork(self.backend, geom, pipe._weights, self.rank, self.world, self.group)
-        values, rows = self.net.forward(points, normals, radii, _lib.frame_init(bb_min, bb_max), pipe.scale_sdf)
+        values, rows = self.net.forward(points, normals, radii, _lib.frame_init(bb_min, bb_max), pipe.scale_sdf,
+                                        feats1=feats1, importance=importance)
         return self.net.stitch(values, rows)

@@ -39,6 +39,7 @@ const OptEntry k_options[] = {
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
         {"sconv16_rg", "ASR_SCONV16_RG", &AsrOptions::sconv16_rg},
+        {"plan_arena", "ASR_PLAN_ARENA", &AsrOptions::plan_arena},
         {"sconv16_min_blocks", "ASR_SCONV16_MIN_BLOCKS", &AsrOptions::sconv16_min_blocks},
         {"knn_cells", "ASR_KNN_CELLS", &AsrOptions::knn_cells},
         {"knn_deep", "ASR_KNN_DEEP", &AsrOptions::knn_deep},
@@ -156,6 +157,7 @@ static void release_members(asr_hip_context* ctx) {
     asr_mesh_release(ctx);
     ctx->persist.release();
     ctx->scratch.release();
+    ctx->plan_arena.release();
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->ev_ok)
@@ -458,7 +460,7 @@ static int check_conv16_args(asr_hip_context* ctx, const asr_sparse_conv_args* a
     return ASR_HIP_OK;
 }
 struct asr_hip_conv_plan {
-    Arena mem;
+    Arena mem;  // empty when the plan lives in the context's plan arena
     asr_conv_plan p;
 };
 int asr_hip_sparse_conv_plan_create(asr_hip_context* ctx, const int32_t* nidx, const uint8_t* kidx, const int64_t* rs,
@@ -472,7 +474,8 @@ int asr_hip_sparse_conv_plan_create(asr_hip_context* ctx, const int32_t* nidx, c
     asr_hip_conv_plan* pl = new asr_hip_conv_plan();
     pl->mem.min_slab = size_t(1) << 20;
     ctx->scratch.reset();
-    const int rc = asr_geom_conv_plan_build(ctx, pl->mem, nidx, kidx, rs, row_perm, num_out, kernel_size, &pl->p);
+    Arena& where = ctx->opt.plan_arena ? ctx->plan_arena : pl->mem;
+    const int rc = asr_geom_conv_plan_build(ctx, where, nidx, kidx, rs, row_perm, num_out, kernel_size, &pl->p);
     if (rc != ASR_HIP_OK) {
         pl->mem.release();
         delete pl;
@@ -487,6 +490,11 @@ void asr_hip_sparse_conv_plan_destroy(asr_hip_conv_plan* plan) {
     delete plan;
 }
 size_t asr_hip_sparse_conv_plan_bytes(const asr_hip_conv_plan* plan) { return plan ? plan->mem.reserved() : 0; }
+int asr_hip_context_plan_arena_reset(asr_hip_context* ctx) {
+    CTX_GUARD(ctx);
+    ctx->plan_arena.reset();
+    return ASR_HIP_OK;
+}
 
 // 16-bit entry points: the caller's plan, or a temporary one in the scratch arena
 static int conv16_entry(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed, int mode, int out_f16) {
@@ -1026,26 +1034,21 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     return ASR_HIP_OK;
 }
 
-int implicit_network(asr_hip_context* ctx, const float* points, const float* normals, i64 n,
-                     const asr_weight* weights, int num_weights, const asr_implicit_params* prm,
-                     float* values_out) {
-    ASR_TRY(ensure_events(ctx));
+// aggregate (net_definitions_torch.py:640-653, 72-120): feats1 [V0, C0] and the per-pair importance of the last build
+int implicit_aggregate(asr_hip_context* ctx, const float* points, const float* normals, i64 n, Net& net) {
+    (void)points;
     if (n != ctx->sizes.num_points || ctx->sizes.num_voxels[0] == 0)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: no matching implicit_build");
     if (!ctx->has_search || !ctx->agg_rs || !ctx->agg_sorted)  // what the LAST BUILD did, not the option's value now
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: the build skipped the aggregation search (option build_search)");
     ctx->scratch.reset();
     if (ctx->build_mark_ok) arena_rewind(ctx->persist, ctx->build_mark);
-    Net net{ctx, {weights, num_weights}};
-    net.precision = prm->precision;
     if (net.precision != 0 && net.precision != ASR_CONV16_F16 && net.precision != ASR_CONV16_BF16X3)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: precision must be 0, ASR_CONV16_F16 or ASR_CONV16_BF16X3");
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
     const i64 P = ctx->sizes.num_agg_pairs;
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-
-    // ---- aggregate (net_definitions_torch.py:640-653, 72-120) ----
     asr_hip_print("network aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:314
     const asr_weight *ck, *cb;
     ASR_TRY(net.get("cconv_block_in.conv1.kernel", 5, &ck));
@@ -1065,9 +1068,26 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
                            ctx->agg_spos, imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1, 1));
     ctx->feats1 = feats1;
     ctx->importance = imp_pairs;
+    ctx->feats1_width = C0;
     name_it(ctx, "feats1", feats1, 4 * (size_t)V0 * C0);
     name_it(ctx, "importance", imp_pairs, 4 * (size_t)P);
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    return ASR_HIP_OK;
+}
+
+int implicit_network(asr_hip_context* ctx, const float* points, const float* normals, i64 n,
+                     const asr_weight* weights, int num_weights, const asr_implicit_params* prm,
+                     float* values_out) {
+    ASR_TRY(ensure_events(ctx));
+    Net net{ctx, {weights, num_weights}};
+    net.precision = prm->precision;
+    ASR_TRY(implicit_aggregate(ctx, points, normals, n, net));
+    GridDev* g = ctx->grids;
+    const i64 V0 = g[0].v;
+    const i64 P = ctx->sizes.num_agg_pairs;
+    float* feats1 = ctx->feats1;
+    float* imp_pairs = ctx->importance;
+    const int C0 = ctx->feats1_width;
 
     // the per-PAIR importance array is indexed with grid-0 VOXEL indices
     // (net_definitions_torch.py:572-578 -> common_torch.py:125).  torch would raise on P < V0.
@@ -1210,6 +1230,16 @@ int asr_hip_implicit_network(asr_hip_context* ctx, const float* points, const fl
     if (!points || !normals || n <= 0 || !weights || !prm)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: null argument");
     return implicit_network(ctx, points, normals, n, weights, num_weights, prm, values_out);
+}
+int asr_hip_implicit_aggregate(asr_hip_context* ctx, const float* points, const float* normals, int64_t n,
+                               const asr_weight* weights, int num_weights, const asr_implicit_params* prm) {
+    CTX_GUARD(ctx);
+    if (!points || !normals || n <= 0 || !weights || !prm)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_aggregate: null argument");
+    ASR_TRY(ensure_events(ctx));
+    Net net{ctx, {weights, num_weights}};
+    net.precision = prm->precision;
+    return implicit_aggregate(ctx, points, normals, n, net);
 }
 int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points, const float* normals,
                              const float* radii, int64_t n, const asr_weight* weights,

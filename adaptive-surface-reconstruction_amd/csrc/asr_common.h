@@ -102,6 +102,8 @@ struct AsrOptions {
     i64 knn_deep = 1;             // kNN radius: finer start levels for the points of crowded cells (0: off)
     i64 knn_cells = 1;            // kNN radius: cell-parallel fast path (0: wave per point only)
     i64 sconv16_rg = 0;           // plan-driven bf16x3 sparse conv: two 16-row groups per wave (1 = column tiles <= 64, 2 = all, 3 = forced; measured at 10 M points: U-Net 26.95 / 28.66 ms against 26.99 with one group -- half the panel traffic buys nothing)
+    i64 plan_arena = 0;           // asr_hip_sparse_conv_plan_create: 1 = memory from the context's plan arena (no hipMalloc /
+                                  // hipFree per plan; all such plans die with asr_hip_context_plan_arena_reset)
     i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
@@ -162,6 +164,7 @@ struct asr_hip_context {
     bool build_mark_ok = false;
     Arena persist;  // results that outlive a call (octree, grids, values)
     Arena scratch;  // temporaries
+    Arena plan_arena;  // row-group plans created with option "plan_arena" (asr_hip_context_plan_arena_reset)
     // last octree
     u64* nodes = nullptr;
     u64* leaves = nullptr;
@@ -182,6 +185,7 @@ struct asr_hip_context {
     int leaf_lmin = -1, leaf_lmax = -1;  // levels of the first / last leaf of the last octree
     float* values = nullptr;
     float* feats1 = nullptr;
+    int feats1_width = 0;
     float* importance = nullptr;
     float* code = nullptr;
     float stage_ms[6] = {0, 0, 0, 0, 0, 0};

@@ -327,6 +327,10 @@ int asr_hip_sparse_conv_plan_create(asr_hip_context* ctx, const int32_t* neighbo
                                     const int32_t* row_perm_dev, int64_t num_out, int kernel_size,
                                     asr_hip_conv_plan** plan_out);
 void asr_hip_sparse_conv_plan_destroy(asr_hip_conv_plan* plan);
+/* With context option "plan_arena" = 1 the plans created afterwards take their memory from an arena of the context
+ * instead of owning it (no device allocation per plan); this call invalidates ALL of them at once and recycles the
+ * memory (hosts that rebuild every plan per geometry, e.g. the one-scan sharding). */
+int asr_hip_context_plan_arena_reset(asr_hip_context* ctx);
 /* bytes of device memory a plan holds */
 size_t asr_hip_sparse_conv_plan_bytes(const asr_hip_conv_plan* plan);
 /* f32 <-> f16 conversion of an activation buffer (n elements) */
@@ -401,6 +405,11 @@ int asr_hip_implicit_network(asr_hip_context* ctx, const float* points_dev,
                              const float* normals_dev, int64_t n, const asr_weight* weights,
                              int num_weights, const asr_implicit_params* params,
                              float* values_out_dev);
+/* first stage of the network half alone (UNet5.aggregate, net_definitions_torch.py:640-653): "feats1" [V0, C] and the
+ * per-pair "importance" of the last build, readable with asr_hip_implicit_get.  For hosts that run the U-Net themselves
+ * (the one-scan sharding: every rank aggregates the whole cloud, then convolves the rows it owns). */
+int asr_hip_implicit_aggregate(asr_hip_context* ctx, const float* points_dev, const float* normals_dev, int64_t n,
+                               const asr_weight* weights, int num_weights, const asr_implicit_params* params);
 /* both halves; values live in the context afterwards (asr_hip_implicit_get "values") */
 int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points_dev,
                              const float* normals_dev, const float* radii_dev, int64_t n,

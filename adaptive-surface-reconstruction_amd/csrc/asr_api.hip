@@ -39,6 +39,7 @@ const OptEntry k_options[] = {
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
         {"sconv16_rg", "ASR_SCONV16_RG", &AsrOptions::sconv16_rg},
+        {"sconv_xcd_tiles", "ASR_SCONV_XCD_TILES", &AsrOptions::sconv_xcd_tiles},
         {"plan_arena", "ASR_PLAN_ARENA", &AsrOptions::plan_arena},
         {"sconv16_min_blocks", "ASR_SCONV16_MIN_BLOCKS", &AsrOptions::sconv16_min_blocks},
         {"knn_cells", "ASR_KNN_CELLS", &AsrOptions::knn_cells},

@@ -104,6 +104,7 @@ struct AsrOptions {
     i64 sconv16_rg = 0;           // plan-driven bf16x3 sparse conv: two 16-row groups per wave (1 = column tiles <= 64, 2 = all, 3 = forced; measured at 10 M points: U-Net 26.95 / 28.66 ms against 26.99 with one group -- half the panel traffic buys nothing)
     i64 plan_arena = 0;           // asr_hip_sparse_conv_plan_create: 1 = memory from the context's plan arena (no hipMalloc /
                                   // hipFree per plan; all such plans die with asr_hip_context_plan_arena_reset)
+    i64 sconv_xcd_tiles = 0;      // plan kernel, one column chunk: runs of 8 adjacent row tiles per XCD
     i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids

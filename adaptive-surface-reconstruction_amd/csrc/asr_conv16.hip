@@ -617,7 +617,7 @@ template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL, int RG>
 __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
                                                  : (WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4)) void k_sconv_plan16(
         asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
-        const float* __restrict__ zeros) {
+        const float* __restrict__ zeros, int xcd_tiles) {
     constexpr int TM = WAVES * 16 * RG;
     constexpr int NCOL = NT * 16;
     constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : 1;
@@ -645,6 +645,11 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
         const i64 r8 = blockIdx.x >> 3;
         ychunk = (int)(r8 % nY);
         tile = (r8 / nY) * 8 + (blockIdx.x & 7);
+    } else if (xcd_tiles) {
+        // workgroups go round-robin over the 8 XCDs: give each XCD runs of 8 ADJACENT tiles (neighbouring rows of one
+        // slot-set class share most of their gathers) instead of every eighth tile
+        const i64 b = blockIdx.x;
+        tile = (b & ~i64(63)) | ((b & 7) << 3) | ((b >> 3) & 7);
     }
     const i64 row0 = tile * TM;
     if (row0 >= a.num_out) return;
@@ -1048,14 +1053,15 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
         const int rg_ = (rg2 && M_ == ASR_CONV16_BF16X3 && !(I_)) ? 2 : 1;                                       \
         const i64 tiles_ = (a.num_out + W_ * 16 * rg_ - 1) / (W_ * 16 * rg_);                                    \
         const i64 ny_ = ctot_pad / (NT_ * 16);                                                                   \
-        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));                                  \
+        const int xt_ = use_plan && ny_ == 1 && ctx->opt.sconv_xcd_tiles != 0;                                    \
+        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : (xt_ ? (tiles_ + 63) / 64 * 64 : tiles_)));  \
         if (use_plan && rg_ == 2) {                                                                              \
             if constexpr (M_ == ASR_CONV16_BF16X3 && !(I_))                                                      \
                 k_sconv_plan16<NT_, KC_, W_, M_, I_, D_, 2><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(            \
-                        a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                           \
+                        a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros, xt_);                      \
         } else if (use_plan)                                                                                     \
             k_sconv_plan16<NT_, KC_, W_, M_, I_, D_, 1><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                \
-                    a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                               \
+                    a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros, xt_);                          \
         else                                                                                                     \
             k_sconv_mfma16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                   \
                     a, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                                   \

@@ -218,6 +218,65 @@ def exact_f32_run(weights, dev, inputs, n, steps, shapes, values=None):
             "timed_values_vs_this_kernel": dev_rel}
 
 
+def config_c2(dev, synth, steps=5):
+    """BASELINE config 2 (outside `value`): single-scale continuous conv on 1 M uniform-density points, fp32 -- octree,
+    aggregation search (a8) and continuous conv (a10) through the operator API, steady state"""
+    from asr_hip import _lib, ops
+    n = 1_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    pts = (torch.rand((n, 3), generator=g, device=dev) * 2 - 1).contiguous()
+    rad = torch.full((n,), 0.02, device=dev)
+    feats = torch.randn((n, 4), generator=g, device=dev)
+    W = torch.randn((4, 4, 4, 4, 32), generator=g, device=dev) * 0.5
+    frame = _lib.frame_init(np.full(3, -1.05, np.float32), np.full(3, 1.05, np.float32))
+
+    def once():
+        nodes, leaves = ops.octree_build(frame, pts, rad, 1.0, 21)
+        centers, sizes = ops.voxel_info(frame, leaves)
+        idx, dist, rs, compat = ops.multi_radius_search(frame, pts, rad, centers, sizes)
+        imp = ops.aggregation_importance(compat, dist)
+        out = ops.continuous_conv(W, centers, sizes, pts, feats, idx, imp, rs, True)
+        return leaves.shape[0], idx.shape[0], out
+
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        v, p, out = once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(out).all())
+    return {"points": n, "voxels": int(v), "pairs": int(p), "ms": round(dt * 1e3, 3), "points_per_s": n / dt,
+            "note": "octree + multi-radius search + continuous conv (operator API, fp32), uniform cube cloud, radius 0.02"}
+
+
+def config_c5(dev, weights, synth, n, steps=3):
+    """BASELINE config 5 (outside `value`): the mixed-density cloud (10x density variance) with f16 features"""
+    from asr_hip.pipeline import ImplicitPipeline
+    pts, nrm = synth.scan_cloud(n, seed=rank_seed(0), device=dev, density_variance=10.0)
+    radii = synth.knn_radii_gpu(pts, 24)
+    bb_min, bb_max = synth.bounding_box(pts, 0.1)
+    pipe = ImplicitPipeline(weights, device=dev, precision="f16")
+    pipe.forward(pts, nrm, radii, bb_min, bb_max)
+    torch.cuda.synchronize()
+    stage = dict.fromkeys(ImplicitPipeline.STAGES, 0.0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        v = pipe.forward(pts, nrm, radii, bb_min, bb_max)
+        for k, x in pipe.stage_ms().items():
+            stage[k] += x / steps
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(v).all())
+    out = {"points": n, "precision": "f16", "density_variance": 10.0, "ms_per_step": round(dt * 1e3, 3),
+           "points_per_s": n / dt, "voxels": [int(x) for x in pipe.sizes.num_voxels],
+           "agg_pairs": int(pipe.sizes.num_agg_pairs), "stage_ms": {k: round(x, 3) for k, x in stage.items()}}
+    del pipe
+    torch.cuda.empty_cache()
+    return out
+
+
 def mesh_stage(pipe, synth):
     """Outside the timed region and not part of `value`: the stage after the path (dual cells, dual
     contouring, component filter) on the analytic signed distance of the synthetic scene -- random
@@ -362,6 +421,9 @@ def main():
                          "exactly into three bf16 terms, six bf16 MFMAs per product, f32 accumulate (fp32-class "
                          "results, same parity bound as f32); f32 = f32-input MFMA, a bit-exact fmaf chain; "
                          "f16 = f16 activations and weights (config C5)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the informational runs of BASELINE configs C2 (1 M single-scale continuous conv) and C5 "
+                         "(mixed density, f16 features)")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the informational re-run of the same cloud on the f32-input MFMA kernel (profiling)")
     ap.add_argument("--density-variance", type=float, default=1.0,
@@ -478,6 +540,11 @@ def main():
     if world == 1 and args.precision == "bf16x3" and not args.no_exact_f32:
         exact = exact_f32_run(weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(args.steps, 2), shapes,
                               values_timed)
+    c2 = c5 = None
+    if world == 1 and rank == 0 and not args.no_other_configs and args.density_variance == 1.0:
+        c2 = config_c2(dev, synth)
+        if args.precision != "f16":
+            c5 = config_c5(dev, weights, synth, n)
     if rank == 0:
         steps = max(args.steps, 1)
         ms = dt / steps * 1e3
@@ -518,6 +585,8 @@ def main():
                                             "note": "pre-filter radius estimate + one step; radii are inputs of the "
                                                     "metric, this is the rate from a raw scan"},
                        "untimed_mesh_stage": mesh_info,
+                       "untimed_config_c2_single_scale_cconv_1m": c2,
+                       "untimed_config_c5_mixed_density_f16": c5,
                        "untimed_pipelined_two_contexts": pipelined,
                        "untimed_exact_f32_kernel": exact},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,

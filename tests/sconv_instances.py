@@ -29,7 +29,7 @@ def instances16_in_trace(path):
     out = set()
     with open(path) as f:
         for line in f:
-            m = re.match(r"k_sconv_(mfma|plan)16<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", line)
+            m = re.match(r"k_sconv_(mfma|plan)16<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, \d+)?>", line)
             if m:
                 out.add((int(m.group(2)), int(m.group(3)), int(m.group(6) == "true"), int(m.group(4)),
                          int(m.group(7) == "true"), int(m.group(5)), int(m.group(1) == "plan")))

@@ -106,7 +106,7 @@ EXPORTS = [
     "asr_octree_frame_init", "asr_hip_point_keys", "asr_hip_octree_build", "asr_hip_octree_build_grow", "asr_hip_octree_get", "asr_hip_dual_cells_count", "asr_hip_dual_cells_count_for", "asr_hip_dual_cells_fill",
     "asr_hip_contour_count", "asr_hip_contour_fill", "asr_hip_components_count", "asr_hip_components_fill",
     "asr_hip_unordered_set_order", "asr_density_inlier",
-    "asr_hip_grid_neighbors_count", "asr_hip_grid_neighbors_fill", "asr_hip_grid_coarsen_count",
+    "asr_hip_grid_neighbors_count", "asr_hip_grid_neighbors_fill", "asr_hip_grid_neighbors_rows_count", "asr_hip_grid_neighbors_rows_fill", "asr_hip_grid_coarsen_count",
     "asr_hip_grid_coarsen_fill", "asr_hip_voxel_info", "asr_hip_multi_radius_search_count",
     "asr_hip_multi_radius_search_fill", "asr_hip_knn_radius", "asr_hip_radius_neighbor_count", "asr_hip_continuous_conv_f32", "asr_hip_continuous_conv_basis_f32",
     "asr_hip_aggregation_importance", "asr_hip_sparse_conv_f32", "asr_hip_invert_neighbors_list", "asr_hip_row_groups",

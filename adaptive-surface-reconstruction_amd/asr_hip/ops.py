@@ -157,6 +157,23 @@ def grid_neighbors(keys):
     return idx, kidx, rs
 
 
+def grid_neighbors_rows(keys, rows):
+    """55-slot lists of the voxels `rows` (ascending int32 indices) only: -> (index, kernel_index, row_splits [V + 1]);
+    the rows that are not listed are empty, the entries of the listed ones compact and in row order"""
+    keys = _dev(keys, torch.int64)
+    rows = _dev(rows, torch.int32)
+    v = keys.shape[0]
+    rs = torch.empty(v + 1, dtype=torch.int64, device=keys.device)
+    p = i64(0)
+    ctx = context(_same_device(keys, rows))
+    ctx.call("asr_hip_grid_neighbors_rows_count", ptr(keys), i64(v), ptr(rows), i64(rows.shape[0]), ptr(rs), ctypes.byref(p))
+    idx = torch.empty(p.value, dtype=torch.int32, device=keys.device)
+    kidx = torch.empty(p.value, dtype=torch.uint8, device=keys.device)
+    ctx.call("asr_hip_grid_neighbors_rows_fill", ptr(keys), i64(v), ptr(rows), i64(rows.shape[0]), ptr(rs), ptr(idx),
+             ptr(kidx))
+    return idx, kidx, rs
+
+
 def grid_coarsen(keys):
     keys = _dev(keys, torch.int64)
     v = keys.shape[0]

@@ -62,6 +62,17 @@ def partition_level0(keys0, row_splits0, world):
     return owner
 
 
+def partition_by_count(keys0, world):
+    """owner[v] for the grid-0 voxels without their neighbour lists: contiguous ranges of the Morton order with equal
+    voxel counts (the sharded geometry build decides ownership BEFORE any list exists)"""
+    order = torch.argsort(normalized_codes(keys0))
+    v = keys0.shape[0]
+    owner_sorted = torch.clamp((torch.arange(v, device=keys0.device, dtype=torch.int64) * world) // max(v, 1), 0, world - 1)
+    owner = torch.empty_like(owner_sorted)
+    owner[order] = owner_sorted
+    return owner
+
+
 def coarser_owner(owner, up_index, up_kernel_index, v_coarse):
     """a coarse voxel belongs to the owner of its first child (slot 0); a voxel carried to the coarser
     grid unchanged (slot 8, cpp/lib/grid.cpp:206-242) keeps its owner"""
@@ -129,6 +140,74 @@ def reset_stats(timed=False):
     STATS.update(sent_bytes=0, recv_bytes=0, exchanges=0, seconds=0.0, timed=bool(timed))
 
 
+def make_plan_owned(rank, world, csr_index, csr_row_splits, owner):
+    """The same for a 55-slot list of which only THIS rank's rows are filled (sharded geometry build).  What to receive
+    follows from the rows as before; what to send follows from the symmetry of the neighbour relation (u is in the row
+    of v exactly when v is in the row of u, cpp/lib/grid.cpp:99-170; checked by the parity tests): rank d needs my row v
+    exactly when v has a neighbour owned by d."""
+    if world == 1:
+        return ExchangePlan({}, {})
+    idx = csr_index.long()
+    lens = csr_row_splits[1:] - csr_row_splits[:-1]
+    row = torch.repeat_interleave(torch.arange(owner.shape[0], device=owner.device), lens)
+    other = owner[idx]
+    cross = other != rank
+    send, recv = {}, {}
+    if bool(cross.any()):
+        v = owner.shape[0]
+        peer_of = other[cross]
+        need = torch.unique(peer_of * v + idx[cross])   # (owner of the input row, input row)
+        give = torch.unique(peer_of * v + row[cross])   # (rank that needs my row, my row)
+        for peer in range(world):
+            if peer == rank:
+                continue
+            m = (need // v) == peer
+            if bool(m.any()):
+                recv[peer] = need[m] - peer * v
+            m = (give // v) == peer
+            if bool(m.any()):
+                send[peer] = give[m] - peer * v
+    return ExchangePlan(send, recv)
+
+
+def sharded_geometry(frame, points, radii, rank, world, radius_scale=1.0, max_depth=21):
+    """Geometry of one rank of the one-scan sharding through the operator API: the octree, the voxel keys of the five
+    grids and the (one entry per voxel) up / down lists on every rank -- cheap integer work every rank needs to derive
+    ownership -- and the expensive parts, the 55-slot neighbour lists and their MFMA tiling orders, for the OWNED voxels
+    only (asr_hip_grid_neighbors_rows_*).  Returns the dict ShardedNetwork takes, with "owner<i>" and "owned_rows<i>"."""
+    from . import ops
+    g = {}
+    nodes, leaves = ops.octree_build(frame, points, radii, radius_scale, max_depth)
+    keys = [leaves]
+    for i in range(NUM_GRIDS - 1):
+        nxt, up_idx, up_kidx, up_rs = ops.grid_coarsen(keys[i])
+        keys.append(nxt)
+        g["up_neighbors_index%d" % i], g["up_neighbors_kernel_index%d" % i], g["up_neighbors_row_splits%d" % i] = \
+            up_idx, up_kidx, up_rs
+        d_idx, d_rs, d_attr = ops.invert_neighbors_list(nxt.shape[0], up_idx, up_rs, up_kidx)
+        g["down_neighbors_index%d" % i], g["down_neighbors_kernel_index%d" % i], g["down_neighbors_row_splits%d" % i] = \
+            d_idx, d_attr, d_rs
+    owner = [partition_by_count(keys[0], world)]
+    for i in range(NUM_GRIDS - 1):
+        owner.append(coarser_owner(owner[i], g["up_neighbors_index%d" % i], g["up_neighbors_kernel_index%d" % i],
+                                   keys[i + 1].shape[0]))
+    g["voxel_centers0"], g["voxel_sizes0"] = ops.voxel_info(frame, keys[0])
+    for i in range(NUM_GRIDS):
+        g["voxel_keys%d" % i] = keys[i]
+        g["owner%d" % i] = owner[i]
+        rows = torch.nonzero(owner[i] == rank).reshape(-1).to(torch.int32)
+        idx, kidx, rs = ops.grid_neighbors_rows(keys[i], rows)
+        g["neighbors_index%d" % i], g["neighbors_kernel_index%d" % i], g["neighbors_row_splits%d" % i] = idx, kidx, rs
+        if rows.numel():
+            # the listed rows' entries are compact and in row order: their local row splits are a gather
+            rs_local = torch.cat([rs[rows.long()], rs[-1:]])
+            perm_local = ops.row_groups(kidx, rs_local)
+            g["owned_rows%d" % i] = rows.long()[perm_local.long()]
+        else:
+            g["owned_rows%d" % i] = rows.long()
+    return g
+
+
 def exchange(tensors, plan, group=None):
     """fills the halo rows of each tensor in `tensors` (same row space, e.g. features and importance) in
     place.  Point to point, batched: one grouped send/recv per call."""
@@ -179,24 +258,33 @@ class ShardedNetwork:
         self.rank, self.world, self.group = rank, world, group
         self.v = [int(geom["voxel_keys%d" % i].shape[0]) for i in range(NUM_GRIDS)]
         g = geom
-        owner = [partition_level0(g["voxel_keys0"], g["neighbors_row_splits0"], world)]
-        for i in range(NUM_GRIDS - 1):
-            owner.append(coarser_owner(owner[i], g["up_neighbors_index%d" % i],
-                                       g["up_neighbors_kernel_index%d" % i], self.v[i + 1]))
+        self.owned_lists = "owner0" in g  # sharded_geometry(): 55-slot lists of this rank's rows only
+        if self.owned_lists:
+            owner = [g["owner%d" % i] for i in range(NUM_GRIDS)]
+            self.rows = [g["owned_rows%d" % i] for i in range(NUM_GRIDS)]
+        else:
+            owner = [partition_level0(g["voxel_keys0"], g["neighbors_row_splits0"], world)]
+            for i in range(NUM_GRIDS - 1):
+                owner.append(coarser_owner(owner[i], g["up_neighbors_index%d" % i],
+                                           g["up_neighbors_kernel_index%d" % i], self.v[i + 1]))
+            self.rows = []   # owned rows per level, in the MFMA tiling order when the geometry provides one
+            for i in range(NUM_GRIDS):
+                mine = owner[i] == rank
+                tiling = g.get("tiling%d" % i)
+                if tiling is not None:
+                    t = tiling.long()
+                    self.rows.append(t[mine[t]])
+                else:
+                    self.rows.append(torch.nonzero(mine).reshape(-1))
         self.owner = owner
-        self.rows = []   # owned rows per level, in the MFMA tiling order when the geometry provides one
-        for i in range(NUM_GRIDS):
-            mine = owner[i] == rank
-            tiling = g.get("tiling%d" % i)
-            if tiling is not None:
-                t = tiling.long()
-                self.rows.append(t[mine[t]])
-            else:
-                self.rows.append(torch.nonzero(mine).reshape(-1))
         self.plans = {}
         for i in range(NUM_GRIDS):
-            self.plans["nb", i] = make_plan(rank, world, g["neighbors_index%d" % i],
-                                            g["neighbors_row_splits%d" % i], owner[i], owner[i])
+            if self.owned_lists:
+                self.plans["nb", i] = make_plan_owned(rank, world, g["neighbors_index%d" % i],
+                                                      g["neighbors_row_splits%d" % i], owner[i])
+            else:
+                self.plans["nb", i] = make_plan(rank, world, g["neighbors_index%d" % i],
+                                                g["neighbors_row_splits%d" % i], owner[i], owner[i])
         for i in range(NUM_GRIDS - 1):
             # up lists: rows = grid i, inputs = grid i+1; down lists: rows = grid i+1, inputs = grid i
             self.plans["up", i] = make_plan(rank, world, g["up_neighbors_index%d" % i],
@@ -466,6 +554,11 @@ class ShardedImplicitPipeline:
         # Morton-ordered continuous conv): replicated work, but cheaper than a generic search of the owned rows plus
         # the importance prefix; whole_cloud_aggregation = False restores the owned-rows form
         self.whole_cloud_aggregation = True
+        # sharded_geometry: octree + voxel keys on every rank, neighbour lists, tiling orders, aggregation search and
+        # continuous conv for the owned voxels only (sharded_geometry()); None: from 4 ranks on
+        import os
+        env = os.environ.get("ASR_SHARDED_GEOMETRY")
+        self.sharded_geometry = None if env is None else bool(int(env))
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -474,6 +567,15 @@ class ShardedImplicitPipeline:
     def forward(self, points, normals, radii, bb_min, bb_max):
         from . import _lib
         pipe = self.pipe
+        use_sg = self.sharded_geometry if self.sharded_geometry is not None else self.world >= 4
+        if use_sg:
+            frame = _lib.frame_init(bb_min, bb_max)
+            geom = sharded_geometry(frame, points, radii, self.rank, self.world, pipe.point_radius_scale,
+                                    pipe.octree_max_depth)
+            self.backend.new_geometry()
+            self.net = ShardedNetwork(self.backend, geom, pipe._weights, self.rank, self.world, self.group)
+            values, rows = self.net.forward(points, normals, radii, frame, pipe.scale_sdf)
+            return self.net.stitch(values, rows)
         pipe.ctx.set_option("build_search", 1 if self.whole_cloud_aggregation else 0)
         pipe.build(points, radii, bb_min, bb_max)
         feats1 = importance = None

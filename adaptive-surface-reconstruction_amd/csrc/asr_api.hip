@@ -341,6 +341,23 @@ int asr_hip_grid_neighbors_fill(asr_hip_context* ctx, const uint64_t* keys, int6
     ctx->scratch.reset();
     return asr_geom_neighbors_fill(ctx, keys, v, row_splits, index_out, kernel_index_out);
 }
+int asr_hip_grid_neighbors_rows_count(asr_hip_context* ctx, const uint64_t* keys, int64_t v, const int32_t* rows,
+                                      int64_t num_rows, int64_t* row_splits_out, int64_t* num_pairs) {
+    CTX_GUARD(ctx);
+    if (v < 0 || num_rows < 0 || !row_splits_out || !num_pairs || (v > 0 && !keys) || (num_rows > 0 && !rows))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "grid_neighbors_rows_count: null argument");
+    ctx->scratch.reset();
+    return asr_geom_neighbors_rows_count(ctx, keys, v, rows, num_rows, row_splits_out, num_pairs);
+}
+int asr_hip_grid_neighbors_rows_fill(asr_hip_context* ctx, const uint64_t* keys, int64_t v, const int32_t* rows,
+                                     int64_t num_rows, const int64_t* row_splits, int32_t* index_out,
+                                     uint8_t* kernel_index_out) {
+    CTX_GUARD(ctx);
+    if (v < 0 || num_rows < 0 || (num_rows > 0 && (!keys || !rows || !row_splits || !index_out || !kernel_index_out)))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "grid_neighbors_rows_fill: null argument");
+    ctx->scratch.reset();
+    return asr_geom_neighbors_rows_fill(ctx, keys, v, rows, num_rows, row_splits, index_out, kernel_index_out);
+}
 int asr_hip_grid_coarsen_count(asr_hip_context* ctx, const uint64_t* keys, int64_t v,
                                int64_t* v_out) {
     CTX_GUARD(ctx);

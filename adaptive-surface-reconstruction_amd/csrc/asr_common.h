@@ -317,6 +317,10 @@ int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* 
 int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* rs, i64* num_pairs);
 int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const i64* rs,
                             int32_t* idx, uint8_t* kidx);
+int asr_geom_neighbors_rows_count(asr_hip_context* ctx, const u64* keys, i64 v, const int32_t* rows, i64 nrows, i64* rs,
+                                  i64* num_pairs);
+int asr_geom_neighbors_rows_fill(asr_hip_context* ctx, const u64* keys, i64 v, const int32_t* rows, i64 nrows,
+                                 const i64* rs, int32_t* idx, uint8_t* kidx);
 int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* keys, i64 v,
                              i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs);
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,

@@ -513,6 +513,51 @@ __global__ void k_neighbors_fill(const u64* keys, i64 v, HashTab t, const i64* r
     }
 }
 
+// The same for a LIST of rows (a rank of the one-scan sharding builds the lists of the voxels it owns): counts of
+// the other rows stay 0, so the row splits keep their full length and the entries of the listed rows are compact.
+__device__ inline int neighbors_of_row(const u64* keys, i64 i, const HashTab& t, int32_t* nidx, uint8_t* nkidx) {
+    const u64 key = keys[i];
+    int x, y, z, lev;
+    asr_key_coord(key, x, y, z, lev);
+    u64 m = 0;
+    int n = 0;
+    if (nidx) {
+        nidx[0] = (int32_t)i;
+        nkidx[0] = 0;
+    }
+    ++n;
+    for (int c = 0; c < 36; ++c) {
+        if (c >= 6) {  // a same-level neighbour across a face rules out its children and its parent (see above)
+            const int face = c < 30 ? (c - 6) >> 2 : c - 30;
+            if ((m >> face) & 1) continue;
+        }
+        int slot = 0;
+        const int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
+        if (idx < 0) continue;
+        m |= u64(1) << c;
+        if (nidx) {
+            nidx[n] = idx;
+            nkidx[n] = (uint8_t)slot;
+        }
+        ++n;
+    }
+    return n;
+}
+__global__ void k_neighbors_count_rows(const u64* keys, HashTab t, const int32_t* rows, i64 nrows, i64* counts) {
+    const i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const i64 i = rows[r];
+    counts[i] = neighbors_of_row(keys, i, t, nullptr, nullptr);
+}
+__global__ void k_neighbors_fill_rows(const u64* keys, HashTab t, const int32_t* rows, i64 nrows, const i64* rs,
+                                      int32_t* nidx, uint8_t* nkidx) {
+    const i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const i64 i = rows[r];
+    const i64 o = rs[i];
+    (void)neighbors_of_row(keys, i, t, nidx + o, nkidx + o);
+}
+
 // ------------------------------------------------------------------------------------------
 // a6: CombineSiblings.  grid.cpp:177-243
 // ------------------------------------------------------------------------------------------
@@ -2127,6 +2172,38 @@ int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const 
     HashTab t;
     ASR_TRY(build_key_map(ctx, keys, v, t));
     k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, nullptr, nullptr, nullptr, idx, kidx);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
+}
+int asr_geom_neighbors_rows_count(asr_hip_context* ctx, const u64* keys, i64 v, const int32_t* rows, i64 nrows, i64* rs,
+                                  i64* num_pairs) {
+    *num_pairs = 0;
+    if (v <= 0) {
+        if (rs) ASR_HIP_CHECK(ctx, hipMemsetAsync(rs, 0, sizeof(i64), ctx->stream));
+        return ASR_HIP_OK;
+    }
+    HashTab t;
+    ASR_TRY(build_key_map(ctx, keys, v, t));
+    i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
+    if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, (v + 1) * sizeof(i64), ctx->stream));
+    if (nrows > 0) {
+        k_neighbors_count_rows<<<grid_for(nrows, BLK), BLK, 0, ctx->stream>>>(keys, t, rows, nrows, counts);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
+    int host[16];
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(host, ctx->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ASR_TRY(read_i64(ctx, rs + v, num_pairs));
+    if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "voxel key map overflow");
+    return ASR_HIP_OK;
+}
+int asr_geom_neighbors_rows_fill(asr_hip_context* ctx, const u64* keys, i64 v, const int32_t* rows, i64 nrows,
+                                 const i64* rs, int32_t* idx, uint8_t* kidx) {
+    if (v <= 0 || nrows <= 0) return ASR_HIP_OK;
+    HashTab t;
+    ASR_TRY(build_key_map(ctx, keys, v, t));
+    k_neighbors_fill_rows<<<grid_for(nrows, BLK), BLK, 0, ctx->stream>>>(keys, t, rows, nrows, rs, idx, kidx);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }

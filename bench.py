@@ -336,7 +336,8 @@ def one_scan_line(args, world, n, dt, sharded, extra):
     steps = max(args.steps, 1)
     net = sharded.net
     cfg = {"workload": "C3 sharded: one %d-point scan-like synthetic cloud over %d GPU(s) by Morton range; octree + grids "
-                       "replicated, aggregation + 53 sparse convs + decoder on owned rows, halo exchange per convolution "
+                       "replicated (from 4 ranks on: neighbour lists, tiling orders and aggregation for the owned voxels "
+                       "only), 53 sparse convs + decoder on owned rows, halo exchange per convolution "
                        "(RCCL grouped send/recv), values stitched by all-reduce" % (n, world),
            "precision": args.precision,
            "points": n,
@@ -383,7 +384,7 @@ def run_one_scan(args, world, rank, dev, weights, n, barrier, synth, fused=0):
         values = sharded.forward(pts, nrm, radii, bb_min, bb_max)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
-    assert values.shape[0] == sharded.pipe.sizes.num_voxels[0] and bool(torch.isfinite(values).all())
+    assert values.shape[0] == sharded.net.v[0] and bool(torch.isfinite(values).all())
     sharding.reset_stats(timed=True)   # one more step, instrumented: bytes and wall time of the halo exchanges
     sharded.forward(pts, nrm, radii, bb_min, bb_max)
     st = dict(sharding.STATS)

@@ -179,6 +179,16 @@ int asr_hip_grid_neighbors_fill(asr_hip_context* ctx, const uint64_t* keys_dev, 
                                 const int64_t* row_splits_dev, int32_t* index_out_dev,
                                 uint8_t* kernel_index_out_dev);
 
+/* The same for a list of rows (ascending voxel indices, int32): row_splits keeps its full length V + 1 with empty
+ * rows for the voxels that are not listed, index / kernel_index hold the listed rows' entries only.  A rank of the
+ * one-scan sharding builds the lists of the voxels it owns. */
+int asr_hip_grid_neighbors_rows_count(asr_hip_context* ctx, const uint64_t* keys_dev, int64_t v,
+                                      const int32_t* rows_dev, int64_t num_rows, int64_t* row_splits_out_dev,
+                                      int64_t* num_pairs);
+int asr_hip_grid_neighbors_rows_fill(asr_hip_context* ctx, const uint64_t* keys_dev, int64_t v,
+                                     const int32_t* rows_dev, int64_t num_rows, const int64_t* row_splits_dev,
+                                     int32_t* index_out_dev, uint8_t* kernel_index_out_dev);
+
 /* ---- a6: CombineSiblings (cpp/lib/grid.cpp:177-243) ----------------------------------- */
 int asr_hip_grid_coarsen_count(asr_hip_context* ctx, const uint64_t* keys_dev, int64_t v,
                                int64_t* v_out);

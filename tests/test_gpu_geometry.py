@@ -506,3 +506,26 @@ def test_create_octree_grow_steps_vs_oracle(gpu, grow_steps):
         o0 = O.Oracle()
         o0.build_octree(pts, rad, *bb)
         assert len(o.nodes) >= len(o0.nodes)
+
+
+def test_neighbor_lists_of_a_row_subset(gpu):
+    """asr_hip_grid_neighbors_rows_*: the 55-slot lists of a subset of the voxels equal the corresponding rows of the
+    full lists (cpp/lib/grid.cpp:43-175); the other rows are empty"""
+    from asr_hip import ops
+    p, _ = synth.scan_cloud(30000, seed=12, device="cpu")
+    pts = p.numpy()
+    rad = synth.knn_radii(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    frame = _lib.frame_init(bb[0], bb[1])
+    nodes, leaves = ops.octree_build(frame, torch.from_numpy(pts).to(gpu), torch.from_numpy(rad).to(gpu))
+    idx, kidx, rs = (t.cpu().numpy() for t in ops.grid_neighbors(leaves))
+    v = leaves.shape[0]
+    rng = np.random.default_rng(3)
+    for rows in (np.sort(rng.choice(v, size=v // 3, replace=False)), np.arange(v), np.zeros(0, np.int64), np.array([v - 1])):
+        i2, k2, r2 = (t.cpu().numpy() for t in ops.grid_neighbors_rows(leaves, torch.from_numpy(rows.astype(np.int32)).to(gpu)))
+        lens = np.zeros(v, np.int64)
+        lens[rows] = (rs[1:] - rs[:-1])[rows]
+        assert np.array_equal(r2, np.concatenate([[0], np.cumsum(lens)]))
+        want_i = np.concatenate([idx[rs[q]:rs[q + 1]] for q in rows]) if len(rows) else np.zeros(0, np.int32)
+        want_k = np.concatenate([kidx[rs[q]:rs[q + 1]] for q in rows]) if len(rows) else np.zeros(0, np.uint8)
+        assert np.array_equal(i2, want_i) and np.array_equal(k2, want_k)

@@ -25,7 +25,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_points, channel_div, precision, out, fused=0):
+def _worker(rank, world, port, n_points, channel_div, precision, out, fused=0, sharded_geometry=False):
     sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd"), os.path.join(REPO, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -42,6 +42,7 @@ def _worker(rank, world, port, n_points, channel_div, precision, out, fused=0):
     bb = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(channel_div, seed=6)
     sp = sharding.ShardedImplicitPipeline(weights, dev, precision=precision)
+    sp.sharded_geometry = bool(sharded_geometry)
     full = sp.forward(pts, nrm, rad, bb[0], bb[1])
     info = {"rank": rank, "owned": [int(r.numel()) for r in sp.net.rows], "halo": sp.net.halo_rows()}
     if rank == 0:
@@ -96,3 +97,26 @@ def test_sharded_fused_multi_scan_cloud_equals_single_process(gpu, world):
     assert sum(i["owned"][0] for i in infos) == r0["v0"]
     owned = [i["owned"][0] for i in infos]
     assert max(owned) < 1.5 * min(owned)  # equal pair counts per rank give similar row counts
+
+
+@pytest.mark.parametrize("world,fused,precision", [(2, 0, "bf16x3"), (3, 8, "bf16x3"), (3, 0, "f32")])
+def test_sharded_geometry_equals_single_process(gpu, world, fused, precision):
+    """The geometry itself sharded (asr_hip.sharding.sharded_geometry): octree and voxel keys on every rank, 55-slot
+    neighbour lists (asr_hip_grid_neighbors_rows_*), tiling orders, aggregation search and continuous conv only for the
+    voxels a rank owns, send lists from the symmetry of the neighbour relation.  Stitched values equal the monolithic
+    driver's bit for bit."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 48000, 2, precision, out, fused, True))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    infos = sorted([out.get(timeout=900) for _ in range(world)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = infos[0]
+    assert r0["equal"], r0["max_abs_diff"]
+    assert sum(i["owned"][0] for i in infos) == r0["v0"]
+    assert all(i["halo"]["nb", 0] > 0 for i in infos)

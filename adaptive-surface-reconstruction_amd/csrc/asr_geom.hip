@@ -3000,24 +3000,34 @@ int asr_geom_invert(asr_hip_context* ctx, i64 num_points, const int32_t* idx, co
 // row-group plans for the plan-driven sparse conv (layout: asr_common.h, consumer: asr_conv16.hip)
 // ==========================================================================================
 namespace {
+constexpr i64 PLAN_DUP_FLAG = i64(1) << 40;
 __global__ void k_plan_masks(const uint8_t* __restrict__ kidx, const i64* __restrict__ rs,
                              const int32_t* __restrict__ perm, i64 num_out, int K, i64 groups_pad,
                              uint4* __restrict__ hdr, i64* __restrict__ counts) {
     const i64 row = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     unsigned long long m = 0;
+    int dup = 0;  // a slot that occurs twice in a row: the plan holds ONE neighbour per (row, slot)
     if (row < num_out) {
         const i64 q = perm ? perm[row] : row;
+        int n = 0;
         for (i64 p = rs[q], pe = rs[q + 1]; p < pe; ++p) {
             const int k = kidx[p];
-            if (k < K) m |= 1ull << k;
+            if (k < K) {
+                m |= 1ull << k;
+                ++n;
+            }
         }
+        dup = n != __popcll(m);
     }
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) m |= __shfl_xor(m, o, 64);
+    for (int o = 1; o < 16; o <<= 1) {
+        m |= __shfl_xor(m, o, 64);
+        dup |= __shfl_xor(dup, o, 64);
+    }
     const i64 grp = row >> 4;
     if ((threadIdx.x & 15) == 0 && grp < groups_pad) {
         hdr[grp] = make_uint4((unsigned)m, (unsigned)(m >> 32), 0u, 0u);
-        counts[grp] = (i64)__popcll(m);
+        counts[grp] = (i64)__popcll(m) + (dup ? PLAN_DUP_FLAG : 0);  // the host sees the flag in the block total
     }
 }
 
@@ -3215,5 +3225,9 @@ int asr_geom_conv_plan_build(asr_hip_context* ctx, Arena& keep, const int32_t* n
     if (num_out <= 0) return ASR_HIP_OK;
     i64 blocks = 0;
     ASR_TRY(asr_prim::read_i64(ctx, plan->offs + plan->groups_pad, &blocks));
+    if (blocks >= PLAN_DUP_FLAG)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL,
+                 "sparse_conv plan: a row lists a kernel slot twice; the 16-bit kernels take one neighbour per (row, slot) "
+                 "(use asr_hip_sparse_conv_f32 with algo = 1 for such lists)");
     return asr_geom_conv_plan_fill(ctx, keep, plan, blocks);
 }

@@ -316,7 +316,9 @@ int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t c
  *   terms < 2^-23 per product) at 2.7x the f32 matrix peak.  args as for asr_hip_sparse_conv_f32.
  * Both take the filters re-packed by asr_hip_sparse_conv_pack (16-bit, [plane][K][cin panel][cout padded to
  * 16][panel depth] in the kernels' LDS order; bank b appended as columns); args->filters / filters_b are
- * ignored, cout_b > 0 selects the two-bank form.  cin and the row strides must be multiples of 8 (f16) / 4 (f32) elements. */
+ * ignored, cout_b > 0 selects the two-bank form.  cin and the row strides must be multiples of 8 (f16) / 4 (f32) elements.
+ * A row may name every kernel slot at most once (true for all lists of the reference's grids, cpp/lib/grid.cpp:99-170,
+ * 229-240); a list that does not is refused with ASR_HIP_EINVAL when its plan is built. */
 #define ASR_CONV16_F16 1
 #define ASR_CONV16_BF16X3 2
 size_t asr_hip_sparse_conv_packed_bytes(int mode, int kernel_size, int cin, int cout, int cout_b);

@@ -364,3 +364,26 @@ def test_two_row_groups_per_wave_variant(geo, gpu):
             assert len(key) == 1 and len(key[0]) == 8 and key[0][7] == 2 and key[0][0] == nt and key[0][3] == waves, key
     finally:
         ctx.set_option("sconv16_rg", 0)
+
+
+def test_duplicate_slot_in_a_row_is_refused(gpu):
+    """the 16-bit kernels keep one neighbour per (row, slot); a list that names a slot twice in one row (legal for
+    open3d::sparse_conv, never produced by the reference's grids, cpp/lib/grid.cpp:99-170) is refused when its plan is
+    built instead of silently losing a contribution"""
+    from asr_hip import ops
+    from asr_hip._lib import AsrHipError
+    rng = np.random.default_rng(1)
+    v, c = 64, 32
+    idx = np.repeat(np.arange(v, dtype=np.int32), 2)
+    kidx = np.zeros(2 * v, np.uint8)
+    kidx[1::2] = 1
+    kidx[11] = 0  # row 5 lists slot 0 twice
+    rs = np.arange(0, 2 * v + 1, 2, dtype=np.int64)
+    W = rng.standard_normal((3, c, c)).astype(np.float32)
+    f = rng.standard_normal((v, c)).astype(np.float32)
+    packed = ops.pack_filters(_t(W, gpu), "bf16x3")
+    with pytest.raises(AsrHipError, match="slot twice"):
+        ops.sparse_conv16("bf16x3", packed, 3, c, c, _t(f, gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu))
+    kidx[11] = 1
+    out = ops.sparse_conv16("bf16x3", packed, 3, c, c, _t(f, gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu))
+    _close(out.cpu().numpy(), O.sparse_conv(W, f, idx, kidx, None, rs, False))

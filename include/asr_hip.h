@@ -76,7 +76,7 @@ int asr_hip_context_weights_changed(asr_hip_context* ctx);
  * after the grid hierarchy (a rank of a sharded run searches only the rows it owns).  Results never depend
  * on the tuning options; "sconv_dry" is the exception: it skips work and produces garbage, for timing only.
  * "search_half" (1): the aggregation search of asr_hip_implicit_build covers a voxel's ball with 4^3 half-size
- * cells (0: 3^3 full-size cells).  get_option also answers the read-only "last_search_margin_pairs": pairs the last
+ * cells for the rows with many candidates (2: for every voxel, 0: 3^3 full-size cells throughout).  get_option also answers the read-only "last_search_margin_pairs": pairs the last
  * such search found in the rounding margin of the half-size cells. */
 int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value);
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value);

@@ -418,7 +418,7 @@ def test_aligned_search_finds_the_pairs_of_the_rounding_margin(gpu, shift):
     pipe = ImplicitPipeline(synth.make_weights(4, seed=1), device=gpu)
     # (half-size cells, one wave per sibling group): the default, the per-voxel kernel with half-size cells, and the
     # per-voxel kernel with 3^3 full-size cells
-    for half, groups, presort in ((1, 0, 0), (1, 1, 1), (0, 0, 0)):
+    for half, groups, presort in ((1, 0, 0), (2, 0, 0), (2, 1, 1), (0, 0, 0)):
         pipe.ctx.set_option("search_half", half)
         pipe.ctx.set_option("search_groups", groups)
         pipe.ctx.set_option("presort", presort)  # points sorted once, before the octree (the same results)

@@ -87,6 +87,24 @@ def octree_build(frame, points, radii, radius_scale=1.0, max_depth=21, grow_step
     return nodes, leaves
 
 
+def octree_build_parts(frame, points, radii, radius_scale=1.0, max_depth=21, extra_keys=None, balance=True):
+    """asr_hip_octree_build_parts: closure of the keys of `points` (may be empty) and of `extra_keys` (int64 tensor of
+    node keys), balanced unless balance is False -> (nodes, leaves)"""
+    points = _dev(points, torch.float32).reshape(-1, 3)
+    radii = _dev(radii, torch.float32).reshape(-1)
+    ek = _dev(extra_keys, torch.int64) if extra_keys is not None and extra_keys.numel() else None
+    nn, nl = i64(0), i64(0)
+    ctx = context(_same_device(points, radii, ek))
+    ctx.call("asr_hip_octree_build_parts", ctypes.byref(frame), ptr(points) if points.shape[0] else ctypes.c_void_p(0),
+             ptr(radii) if points.shape[0] else ctypes.c_void_p(0), i64(points.shape[0]), ctypes.c_float(radius_scale),
+             int(max_depth), ptr(ek), i64(ek.shape[0] if ek is not None else 0), int(bool(balance)), ctypes.byref(nn),
+             ctypes.byref(nl))
+    nodes = torch.empty(nn.value, dtype=torch.int64, device=points.device)
+    leaves = torch.empty(nl.value, dtype=torch.int64, device=points.device)
+    ctx.call("asr_hip_octree_get", ptr(nodes), ptr(leaves))
+    return nodes, leaves
+
+
 def dual_cells(device, ctx=None, nodes=None, leaves=None):
     """dual_vertex_indices [D,8] (int64): of the octree built last on this context, or of the octree given by
     its sorted node / leaf key tensors (any tree that is still alive)"""

@@ -170,14 +170,47 @@ def make_plan_owned(rank, world, csr_index, csr_row_splits, owner):
     return ExchangePlan(send, recv)
 
 
-def sharded_geometry(frame, points, radii, rank, world, radius_scale=1.0, max_depth=21):
+def all_gather_variable(t, group=None):
+    """concatenation of every rank's 1-D tensor `t` (lengths differ), in rank order"""
+    world = dist.get_world_size(group)
+    via_host = dist.get_backend(group) == "gloo" and t.is_cuda
+    work = t.cpu() if via_host else t
+    n = torch.tensor([work.shape[0]], dtype=torch.int64, device=work.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(sizes + [1])
+    pad = torch.zeros(cap, dtype=work.dtype, device=work.device)
+    pad[:work.shape[0]] = work
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:s] for p, s in zip(parts, sizes)]).to(t.device)
+
+
+def sharded_octree(frame, points, radii, rank, world, radius_scale=1.0, max_depth=21, group=None):
+    """The octree of the whole cloud with the insertion spread over the ranks: every rank closes the keys of ITS share of
+    the points under "all siblings, all ancestors" (no balancing: a group that is a leaf of a partial tree may be inner in
+    the whole one), the node lists are all-gathered, and every rank closes and 2:1-balances the union
+    (asr_hip_octree_build_parts).  Closure commutes with union, so the result is the tree of the whole cloud bit for bit."""
+    from . import ops
+    n = points.shape[0]
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    local, _ = ops.octree_build_parts(frame, points[lo:hi], radii[lo:hi], radius_scale, max_depth, balance=False)
+    union = all_gather_variable(local, group)
+    return ops.octree_build_parts(frame, points[:0], radii[:0], radius_scale, max_depth, extra_keys=union, balance=True)
+
+
+def sharded_geometry(frame, points, radii, rank, world, radius_scale=1.0, max_depth=21, group=None):
     """Geometry of one rank of the one-scan sharding through the operator API: the octree, the voxel keys of the five
     grids and the (one entry per voxel) up / down lists on every rank -- cheap integer work every rank needs to derive
     ownership -- and the expensive parts, the 55-slot neighbour lists and their MFMA tiling orders, for the OWNED voxels
     only (asr_hip_grid_neighbors_rows_*).  Returns the dict ShardedNetwork takes, with "owner<i>" and "owned_rows<i>"."""
     from . import ops
     g = {}
-    nodes, leaves = ops.octree_build(frame, points, radii, radius_scale, max_depth)
+    if world > 1:
+        nodes, leaves = sharded_octree(frame, points, radii, rank, world, radius_scale, max_depth, group)
+    else:
+        nodes, leaves = ops.octree_build(frame, points, radii, radius_scale, max_depth)
     keys = [leaves]
     for i in range(NUM_GRIDS - 1):
         nxt, up_idx, up_kidx, up_rs = ops.grid_coarsen(keys[i])
@@ -571,7 +604,7 @@ class ShardedImplicitPipeline:
         if use_sg:
             frame = _lib.frame_init(bb_min, bb_max)
             geom = sharded_geometry(frame, points, radii, self.rank, self.world, pipe.point_radius_scale,
-                                    pipe.octree_max_depth)
+                                    pipe.octree_max_depth, self.group)
             self.backend.new_geometry()
             self.net = ShardedNetwork(self.backend, geom, pipe._weights, self.rank, self.world, self.group)
             values, rows = self.net.forward(points, normals, radii, frame, pipe.scale_sdf)

@@ -253,6 +253,21 @@ int asr_hip_octree_build_grow(asr_hip_context* ctx, const asr_octree_frame* fram
     if (num_leaves) *num_leaves = ctx->num_leaves;
     return ASR_HIP_OK;
 }
+int asr_hip_octree_build_parts(asr_hip_context* ctx, const asr_octree_frame* frame, const float* points,
+                               const float* radii, int64_t n, float radius_scale, int max_depth,
+                               const uint64_t* extra_keys, int64_t num_extra, int balance, int64_t* num_nodes,
+                               int64_t* num_leaves) {
+    CTX_GUARD(ctx);
+    if (!frame || n < 0 || num_extra < 0 || (n > 0 && (!points || !radii)) || (num_extra > 0 && !extra_keys))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree_build_parts: null argument");
+    ctx->persist.reset();
+    ctx->named.clear();
+    ASR_TRY(asr_geom_octree_build(ctx, frame, points, radii, n, radius_scale, max_depth, nullptr, 0, extra_keys, num_extra,
+                                  balance != 0));
+    if (num_nodes) *num_nodes = ctx->num_nodes;
+    if (num_leaves) *num_leaves = ctx->num_leaves;
+    return ASR_HIP_OK;
+}
 int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out, uint64_t* leaves_out) {
     CTX_GUARD(ctx);
     if (nodes_out && ctx->num_nodes)

@@ -310,7 +310,8 @@ int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, con
 // pre: the same points in Morton order (asr_geom_presort) -- inserted in that order, or nullptr
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                           const float* radii, i64 n, float radius_scale, int max_depth,
-                          const AsrPointIndex* pre = nullptr, int grow_steps = 0);
+                          const AsrPointIndex* pre = nullptr, int grow_steps = 0, const u64* extra_keys = nullptr,
+                          i64 num_extra = 0, bool balance = true);
 // Morton order of the points (+ radii) into ctx->pindex, arrays in `keep`
 int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* frame, const float* pts,
                      const float* radii, i64 n);

@@ -2029,7 +2029,7 @@ static int grow_keys(asr_hip_context* ctx, Arena& arena, const asr_octree_frame*
 
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                           const float* radii, i64 n, float radius_scale, int max_depth, const AsrPointIndex* pre,
-                          int grow_steps) {
+                          int grow_steps, const u64* extra_keys, i64 num_extra, bool balance) {
     ASR_TRY(ensure_flags(ctx));
     if (max_depth > ASR_MAX_LEVEL) max_depth = ASR_MAX_LEVEL;
     if (max_depth < 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "max_depth must be >= 0");
@@ -2047,7 +2047,7 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
     if (grow_steps > 0 && n > 0)
         ASR_TRY(grow_keys(ctx, grow_arena, frame, pts, radii, n, radius_scale, max_depth, grow_steps, &grown, &num_grown));
     // nodes of a scan are ~0.3 n; the table must stay at most half full (cap / 2 list entries), else retry 4x larger
-    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 2 * std::max(n, 4 * num_grown)));
+    u64 cap = next_pow2((u64)std::max<i64>(i64(1) << 16, 2 * std::max(std::max(n, 4 * num_grown), num_extra)));
     int host[16];
     for (int attempt = 0; attempt < 7; ++attempt, cap <<= 2) {
         ctx->scratch.reset();
@@ -2073,11 +2073,16 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
                         *frame, pts, radii, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);
             ASR_CHECK_LAUNCH(ctx);
         }
+        if (num_extra > 0) {  // node keys of other builds (the local octrees of the other ranks): same closure
+            k_octree_insert_keys<<<grid_for(num_extra, BLK), BLK, 0, ctx->stream>>>(extra_keys, num_extra, t, ctx->d_flags,
+                                                                                   list, lcap);
+            ASR_CHECK_LAUNCH(ctx);
+        }
         ASR_TRY(read_flags(ctx, host));
         if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree: points / radii contain non-finite values");
         bool overflow = host[1] != 0 || (u64)host[0] * 2 > cap;
         int lo = 0, hi = host[0];
-        while (!overflow && hi > lo) {
+        while (balance && !overflow && hi > lo) {
             int ngroups = (hi - lo) / 8;
             k_balance_classify<<<grid_for(ngroups, BLK), BLK, 0, ctx->stream>>>(t, list, lo, ngroups, flag);
             ASR_CHECK_LAUNCH(ctx);

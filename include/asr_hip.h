@@ -123,6 +123,15 @@ int asr_hip_octree_build_grow(asr_hip_context* ctx, const asr_octree_frame* fram
                               const float* points_dev, const float* radii_dev, int64_t n,
                               float radius_scale, int grow_steps, int max_depth, int64_t* num_nodes,
                               int64_t* num_leaves);
+/* An octree in parts, for builds that are spread over several processes: the node set is the closure (all siblings,
+ * all ancestors; cpp/lib/octree.cpp:110-150) of the keys of `points` AND of `extra_keys` (node keys of other builds),
+ * then 2:1 balanced (:152-206) unless balance == 0.  Closure commutes with union, so every rank can close the keys of its
+ * share of the points (balance = 0), the ranks exchange their node lists, and each rank closes and balances the union
+ * (n = 0, extra_keys = all lists): the tree of the whole cloud, bit for bit. */
+int asr_hip_octree_build_parts(asr_hip_context* ctx, const asr_octree_frame* frame, const float* points_dev,
+                               const float* radii_dev, int64_t n, float radius_scale, int max_depth,
+                               const uint64_t* extra_keys_dev, int64_t num_extra, int balance,
+                               int64_t* num_nodes, int64_t* num_leaves);
 /* copies the sorted node keys / sorted leaf keys (tree.leaves) of the last build */
 int asr_hip_octree_get(asr_hip_context* ctx, uint64_t* nodes_out_dev, uint64_t* leaves_out_dev);
 

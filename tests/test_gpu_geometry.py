@@ -529,3 +529,25 @@ def test_neighbor_lists_of_a_row_subset(gpu):
         want_i = np.concatenate([idx[rs[q]:rs[q + 1]] for q in rows]) if len(rows) else np.zeros(0, np.int32)
         want_k = np.concatenate([kidx[rs[q]:rs[q + 1]] for q in rows]) if len(rows) else np.zeros(0, np.uint8)
         assert np.array_equal(i2, want_i) and np.array_equal(k2, want_k)
+
+
+def test_octree_in_parts_equals_the_whole(gpu):
+    """asr_hip_octree_build_parts: three shares of a cloud closed separately (no balancing), their node lists
+    concatenated, closed and balanced as a whole -> the nodes and leaves of CreateOctreeFromPoints on the whole cloud
+    (cpp/lib/octree.cpp:230-280)"""
+    from asr_hip import ops
+    p, _ = synth.scan_cloud(40000, seed=31, device="cpu", density_variance=10.0)
+    pts = p.numpy()
+    rad = synth.knn_radii(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    frame = _lib.frame_init(bb[0], bb[1])
+    dp, dr = torch.from_numpy(pts).to(gpu), torch.from_numpy(rad).to(gpu)
+    nodes, leaves = ops.octree_build(frame, dp, dr)
+    cuts = [0, 9000, 9001, 40000]
+    parts = [ops.octree_build_parts(frame, dp[a:b], dr[a:b], balance=False)[0] for a, b in zip(cuts[:-1], cuts[1:])]
+    assert all(part.shape[0] < nodes.shape[0] for part in parts)
+    n2, l2 = ops.octree_build_parts(frame, dp[:0], dr[:0], extra_keys=torch.cat(parts), balance=True)
+    assert torch.equal(n2, nodes) and torch.equal(l2, leaves)
+    o = O.Oracle()
+    o.build_octree(pts, rad, *bb)
+    assert np.array_equal(n2.cpu().numpy().view(np.uint64), o.nodes)

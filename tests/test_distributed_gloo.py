@@ -37,6 +37,22 @@ def _worker(rank, world, port, out):
     dt_job = bench.max_over_ranks(dt, world, torch.device("cpu"))
     gathered = [None] * world
     dist.all_gather_object(gathered, digest)
+    # variable-length all-gather of the sharded octree build (node lists of the local octrees) and the send lists
+    # derived from the symmetry of the neighbour relation
+    from asr_hip import sharding
+    mine = torch.arange(10 * rank, 10 * rank + 3 + 4 * rank, dtype=torch.int64)
+    allk = sharding.all_gather_variable(mine)
+    want = torch.cat([torch.arange(10 * r, 10 * r + 3 + 4 * r, dtype=torch.int64) for r in range(world)])
+    assert torch.equal(allk, want)
+    # a ring of 6 voxels, ranks own 0-2 / 3-5; rows of THIS rank only (sharded geometry): i <-> i +- 1
+    owner = torch.tensor([0, 0, 0, 1, 1, 1])
+    lens = torch.tensor([3 if owner[i] == rank else 0 for i in range(6)])
+    rs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+    idx = torch.tensor([j % 6 for i in range(6) if owner[i] == rank for j in (i, i - 1, i + 1)], dtype=torch.int32)
+    plan = sharding.make_plan_owned(rank, world, idx, rs, owner)
+    other = 1 - rank
+    assert plan.recv[other].tolist() == ([3, 5] if rank == 0 else [0, 2])
+    assert plan.send[other].tolist() == ([0, 2] if rank == 0 else [3, 5])
     if rank == 0:
         out.put((dt_job, bench.job_value(world, 2000, 3, dt_job), gathered))
     dist.destroy_process_group()

@@ -38,8 +38,6 @@ const OptEntry k_options[] = {
         {"row_segment", "ASR_ROW_SEGMENT", &AsrOptions::row_segment},
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
-        {"sconv16_rg", "ASR_SCONV16_RG", &AsrOptions::sconv16_rg},
-        {"sconv_xcd_tiles", "ASR_SCONV_XCD_TILES", &AsrOptions::sconv_xcd_tiles},
         {"plan_arena", "ASR_PLAN_ARENA", &AsrOptions::plan_arena},
         {"sconv16_min_blocks", "ASR_SCONV16_MIN_BLOCKS", &AsrOptions::sconv16_min_blocks},
         {"knn_cells", "ASR_KNN_CELLS", &AsrOptions::knn_cells},
@@ -49,8 +47,6 @@ const OptEntry k_options[] = {
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
-        {"search_groups", "ASR_SEARCH_GROUPS", &AsrOptions::search_groups},
-        {"presort", "ASR_PRESORT", &AsrOptions::presort},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
 };
 
@@ -248,7 +244,7 @@ int asr_hip_octree_build_grow(asr_hip_context* ctx, const asr_octree_frame* fram
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree_build: null argument");
     ctx->persist.reset();
     ctx->named.clear();
-    ASR_TRY(asr_geom_octree_build(ctx, frame, points, radii, n, radius_scale, max_depth, nullptr, grow_steps));
+    ASR_TRY(asr_geom_octree_build(ctx, frame, points, radii, n, radius_scale, max_depth, grow_steps));
     if (num_nodes) *num_nodes = ctx->num_nodes;
     if (num_leaves) *num_leaves = ctx->num_leaves;
     return ASR_HIP_OK;
@@ -262,7 +258,7 @@ int asr_hip_octree_build_parts(asr_hip_context* ctx, const asr_octree_frame* fra
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree_build_parts: null argument");
     ctx->persist.reset();
     ctx->named.clear();
-    ASR_TRY(asr_geom_octree_build(ctx, frame, points, radii, n, radius_scale, max_depth, nullptr, 0, extra_keys, num_extra,
+    ASR_TRY(asr_geom_octree_build(ctx, frame, points, radii, n, radius_scale, max_depth, 0, extra_keys, num_extra,
                                   balance != 0));
     if (num_nodes) *num_nodes = ctx->num_nodes;
     if (num_leaves) *num_leaves = ctx->num_leaves;
@@ -890,9 +886,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         if (ctx->opt.early_sort) ASR_TRY(asr_geom_presort(sc, sc->persist, &ctx->frame, points, radii, n));
     }
     ctx->pindex.valid = false;
-    if (ctx->opt.presort) ASR_TRY(asr_geom_presort(ctx, ctx->persist, &ctx->frame, points, radii, n));
-    ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale,
-                                  prm->octree_max_depth, ctx->pindex.valid ? &ctx->pindex : nullptr));
+    ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale, prm->octree_max_depth));
     ctx->sizes.num_nodes = ctx->num_nodes;
     name_it(ctx, "nodes", ctx->nodes, 8 * ctx->num_nodes);
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -931,7 +925,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         if (!ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
                                       &agg_pairs, &sc->persist, radii, g0.keys, ctx->leaf_lmin, ctx->leaf_lmax,
-                                      sc->pindex.valid ? &sc->pindex : (ctx->pindex.valid ? &ctx->pindex : nullptr)));
+                                      sc->pindex.valid ? &sc->pindex : nullptr));
         ctx->agg_idx = arena_alloc<int32_t>(sc->persist, agg_pairs);
         ctx->agg_dist = arena_alloc<float>(sc->persist, agg_pairs);
         ctx->agg_compat = arena_alloc<float>(sc->persist, agg_pairs);

@@ -101,19 +101,15 @@ struct AsrOptions {
     i64 search_hash_level = -1;   // >= 0: finest level of the search's cell hash table (finer: binary search); tests
     i64 knn_deep = 1;             // kNN radius: finer start levels for the points of crowded cells (0: off)
     i64 knn_cells = 1;            // kNN radius: cell-parallel fast path (0: wave per point only)
-    i64 sconv16_rg = 0;           // plan-driven bf16x3 sparse conv: two 16-row groups per wave (1 = column tiles <= 64, 2 = all, 3 = forced; measured at 10 M points: U-Net 26.95 / 28.66 ms against 26.99 with one group -- half the panel traffic buys nothing)
     i64 plan_arena = 0;           // asr_hip_sparse_conv_plan_create: 1 = memory from the context's plan arena (no hipMalloc /
                                   // hipFree per plan; all such plans die with asr_hip_context_plan_arena_reset)
-    i64 sconv_xcd_tiles = 0;      // plan kernel, one column chunk: runs of 8 adjacent row tiles per XCD
     i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
     i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
-    i64 search_groups = 0;        // aggregation search: 1 = one wave per sibling group of voxels (measured slower: 3.6 vs 3.3 ms at 10 M points, the kernel is bound by the latency chain of a wave, not by its table probes)
     i64 early_sort = 1;           // overlapped search: its point sort starts on the auxiliary stream beside the octree build
-    i64 presort = 0;              // implicit_build: 1 = points sorted once, up front, for octree insertion and search (measured slower: neighbouring lanes contend for the same table slots, insertion 1.6 vs 1.1 ms)
 };
 
 // Row-group plan of a neighbour list for the plan-driven 16-bit sparse conv (asr_conv16.hip): per 16
@@ -307,11 +303,9 @@ __device__ static inline u64 asr_hash64(u64 k) {
 // internal entry points shared between translation units
 int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                         const float* radii, i64 n, float radius_scale, int max_depth, u64* keys);
-// pre: the same points in Morton order (asr_geom_presort) -- inserted in that order, or nullptr
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                          const float* radii, i64 n, float radius_scale, int max_depth,
-                          const AsrPointIndex* pre = nullptr, int grow_steps = 0, const u64* extra_keys = nullptr,
-                          i64 num_extra = 0, bool balance = true);
+                          const float* radii, i64 n, float radius_scale, int max_depth, int grow_steps = 0,
+                          const u64* extra_keys = nullptr, i64 num_extra = 0, bool balance = true);
 // Morton order of the points (+ radii) into ctx->pindex, arrays in `keep`
 int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* frame, const float* pts,
                      const float* radii, i64 n);

@@ -552,73 +552,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
 //   * LDS holds only the two panel buffers, so three 8-wave blocks fit a CU.
 // Row weights (conv1b: importance of the neighbour) are read per (row, slot) through the plan as well.
 // ------------------------------------------------------------------------------------------
-// products of one step for RG row groups of a wave: every B fragment read from LDS feeds the MFMAs of all active groups
-template <int NT, int KC, int MODE, bool IMP, bool DUAL, int PLANES, int NJ, int RG>
-__device__ inline void sconv16_products_rg(const u32x4 (&fa)[RG][NJ][PLANES], const u32x4* __restrict__ sb,
-                                           f32x4 (&acc)[RG][NT], f32x4 (&tacc)[RG][IMP ? NT : 1], bool has_b, int ncol, int g,
-                                           const bool (&act)[RG]) {
-    constexpr int SLOTS = KC / 8;
-    constexpr int PLANE_PIECES = NT * 16 * SLOTS;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-            const int col = nb * 16 + ncol;
-            const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
-            if constexpr (MODE == ASR_CONV16_F16) {
-                const f16x8 bf = __builtin_bit_cast(f16x8, sb[piece]);
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg) {
-                    if (!act[rg]) continue;
-                    const f16x8 af = __builtin_bit_cast(f16x8, fa[rg][j][0]);
-                    if (IMP) {
-                        tacc[rg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[rg][nb], 0, 0, 0);
-                    } else {
-                        acc[rg][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[rg][nb], 0, 0, 0);
-                        if (DUAL && has_b && nb == NT - 1)
-                            tacc[rg][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[rg][0], 0, 0, 0);
-                    }
-                }
-            } else {
-                const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);
-#define ASR_SIX_RG(ACC_, A0_, A1_, A2_)                                                  \
-    {                                                                                    \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0_, b2, ACC_, 0, 0, 0);          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1_, b1, ACC_, 0, 0, 0);          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0_, b1, ACC_, 0, 0, 0);          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2_, b0, ACC_, 0, 0, 0);          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1_, b0, ACC_, 0, 0, 0);          \
-        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0_, b0, ACC_, 0, 0, 0);          \
-    }
-#pragma unroll
-                for (int rg = 0; rg < RG; ++rg) {
-                    if (!act[rg]) continue;
-                    const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[rg][j][0]);
-                    const bf16x8 a1 = __builtin_bit_cast(bf16x8, fa[rg][j][PLANES > 1 ? 1 : 0]);
-                    const bf16x8 a2 = __builtin_bit_cast(bf16x8, fa[rg][j][PLANES > 2 ? 2 : 0]);
-                    if (IMP) {
-                        ASR_SIX_RG(tacc[rg][nb], a0, a1, a2)
-                    } else {
-                        ASR_SIX_RG(acc[rg][nb], a0, a1, a2)
-                        if (DUAL && has_b && nb == NT - 1) { ASR_SIX_RG(tacc[rg][0], a0, a1, a2) }
-                    }
-                }
-#undef ASR_SIX_RG
-            }
-        }
-    }
-}
-
-// RG: 16-row groups per wave (1 or 2).  With RG = 2 a block covers WAVES * 32 rows: half the weight-panel traffic and
-// half the LDS fragment reads per MFMA (a fragment feeds both groups), at the price of a second set of accumulators.
-template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL, int RG>
-__global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
-                                                 : (WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4)) void k_sconv_plan16(
+template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4) void k_sconv_plan16(
         asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
-        const float* __restrict__ zeros, int xcd_tiles) {
-    constexpr int TM = WAVES * 16 * RG;
+        const float* __restrict__ zeros) {
+    constexpr int TM = WAVES * 16;
     constexpr int NCOL = NT * 16;
     constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : 1;
     constexpr int SLOTS = KC / 8;
@@ -645,11 +583,6 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
         const i64 r8 = blockIdx.x >> 3;
         ychunk = (int)(r8 % nY);
         tile = (r8 / nY) * 8 + (blockIdx.x & 7);
-    } else if (xcd_tiles) {
-        // workgroups go round-robin over the 8 XCDs: give each XCD runs of 8 ADJACENT tiles (neighbouring rows of one
-        // slot-set class share most of their gathers) instead of every eighth tile
-        const i64 b = blockIdx.x;
-        tile = (b & ~i64(63)) | ((b & 7) << 3) | ((b >> 3) & 7);
     }
     const i64 row0 = tile * TM;
     if (row0 >= a.num_out) return;
@@ -663,21 +596,15 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
     const int r = lane & 15, g = lane >> 4;
     const int ncol = r;
 
-    // group headers: wave-uniform
-    unsigned long long wmask[RG];
-    unsigned woff[RG];
-    unsigned long long wany = 0;
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-        const i64 grp = (tile * WAVES + wave) * RG + rg;
-        uint4 h = make_uint4(0, 0, 0, 0);
-        if (grp < plan.groups) h = plan.hdr[grp];
-        wmask[rg] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.x) |
-                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.y) << 32)) & ((1ull << K) - 1);
-        woff[rg] = (unsigned)__builtin_amdgcn_readfirstlane((int)h.z);
-        wany |= wmask[rg];
-    }
-    if (lane == 0) s_wm[wave] = wany;
+    // group header: wave-uniform
+    const i64 grp = tile * WAVES + wave;
+    uint4 h = make_uint4(0, 0, 0, 0);
+    if (grp < plan.groups) h = plan.hdr[grp];
+    const unsigned long long wmask =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.x) |
+             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.y) << 32)) & ((1ull << K) - 1);
+    const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane((int)h.z);
+    if (lane == 0) s_wm[wave] = wmask;
     __syncthreads();
     unsigned long long bmask = 0;
 #pragma unroll
@@ -685,20 +612,14 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
     bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
 
-    f32x4 acc[RG][NT];
-    f32x4 tacc[RG][IMP ? NT : 1];
-    f32x4 acc_b[RG];
-    float norm4[RG][4];
+    f32x4 acc[NT];
+    f32x4 tacc[IMP ? NT : 1];
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
+    for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[rg][t] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < (IMP ? NT : 1); ++t) tacc[rg][t] = {0.f, 0.f, 0.f, 0.f};
-        acc_b[rg] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) norm4[rg][i] = 0.f;
-    }
+    for (int t = 0; t < (IMP ? NT : 1); ++t) tacc[t] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_b = {0.f, 0.f, 0.f, 0.f};
+    float norm4[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int npanel = (cin + KC - 1) / KC;
     const i64 plane_stride = (i64)K * ctot_pad * cin_pad;
@@ -739,86 +660,68 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
         }
     };
     // neighbour index of this lane's row for slot k (wave-uniform k): one 64-byte block of the pool.  The load
-    // is issued whether or not the group has the slot (offset beyond the pool -> 0), so that every step has the
+    // is issued whether or not the wave has the slot (offset beyond the pool -> 0), so that every step has the
     // same sequence of memory instructions; has_slot() tells the two apart.
-    auto has_slot = [&](const int rg, const int k) __attribute__((always_inline)) -> bool {
-        return k >= 0 && ((wmask[rg] >> k) & 1);
-    };
-    auto pool_off = [&](const int rg, const int k) __attribute__((always_inline)) -> unsigned {
+    auto has_slot = [&](const int k) __attribute__((always_inline)) -> bool { return k >= 0 && ((wmask >> k) & 1); };
+    auto pool_off = [&](const int k) __attribute__((always_inline)) -> unsigned {
         const int kk = k < 0 ? 0 : k;
-        return (woff[rg] + (unsigned)__popcll(wmask[rg] & ((1ull << kk) - 1))) * 64u;
+        return (woff + (unsigned)__popcll(wmask & ((1ull << kk) - 1))) * 64u;
     };
-    auto load_idx = [&](const int rg, const int k) __attribute__((always_inline)) -> int {
-        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, has_slot(rg, k) ? r * 4 : (int)OOB_OFF, (int)pool_off(rg, k), 0);
+    auto load_idx = [&](const int k) __attribute__((always_inline)) -> int {
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, has_slot(k) ? r * 4 : (int)OOB_OFF, (int)pool_off(k), 0);
     };
-    auto load_idx4 = [&](const int rg, const int k) __attribute__((always_inline)) -> u32x4 {  // rows 4 g .. 4 g + 3
-        return __builtin_amdgcn_raw_buffer_load_b128(rs_p, has_slot(rg, k) ? g * 16 : (int)OOB_OFF, (int)pool_off(rg, k), 0);
+    auto load_idx4 = [&](const int k) __attribute__((always_inline)) -> u32x4 {  // rows 4 g .. 4 g + 3
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_p, has_slot(k) ? g * 16 : (int)OOB_OFF, (int)pool_off(k), 0);
     };
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.inp_features, 0, (int)(unsigned)(a.num_inp > 0 ? ((a.num_inp - 1) * a.inp_ld + cin) * ESZ : 0),
             RSRC_FLAGS);
     int cache_k = -2;
-    unsigned cache_off[RG];
-    int pref_idx[RG];  // index for the slot after the one being gathered, in flight
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-        cache_off[rg] = OOB_OFF;
-        pref_idx[rg] = -1;
-    }
+    unsigned cache_off = OOB_OFF;
+    int pref_idx = -1;  // index for the slot after the one being gathered, in flight
     // (the launcher sends matrices of 4 GB and more and cin that is not a multiple of KC to k_sconv_mfma16)
-    auto gather_a = [&](const int qk, const int qp, u32x4 (&aq)[RG][NJ * AW], const bool first) __attribute__((always_inline)) {
+    auto gather_a = [&](const int qk, const int qp, u32x4 (&aq)[NJ * AW], const bool first) __attribute__((always_inline)) {
         const bool sw = qk != cache_k;
+        int idx = pref_idx;
+        if (first) idx = load_idx(qk);
         const unsigned long long rest = qk < 0 ? 0ull : (bmask >> qk) >> 1;
         const int kn = rest ? qk + 1 + __builtin_ctzll(rest) : -1;
+        if (sw) {  // once per slot: take the prefetched index, prefetch the one of the slot after it
+            cache_k = qk;
+            const bool valid = has_slot(qk) && idx >= 0;
+            cache_off = valid ? (unsigned)idx * (unsigned)(a.inp_ld * ESZ) + (unsigned)(8 * g * ESZ) : OOB_OFF;
+            pref_idx = load_idx(kn);
+        }
         const int soff = qp * KC * ESZ;
 #pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-            int idx = pref_idx[rg];
-            if (first) idx = load_idx(rg, qk);
-            if (sw) {  // once per slot: take the prefetched index, prefetch the one of the slot after it
-                const bool valid = has_slot(rg, qk) && idx >= 0;
-                cache_off[rg] = valid ? (unsigned)idx * (unsigned)(a.inp_ld * ESZ) + (unsigned)(8 * g * ESZ) : OOB_OFF;
-                pref_idx[rg] = load_idx(rg, kn);
-            }
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int hh = 0; hh < AW; ++hh)
-                    aq[rg][j * AW + hh] =
-                            __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off[rg] + (32 * j + 4 * hh) * ESZ, soff, 0);
-        }
-        if (sw) cache_k = qk;
+            for (int hh = 0; hh < AW; ++hh)
+                aq[j * AW + hh] =
+                        __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off + (32 * j + 4 * hh) * ESZ, soff, 0);
     };
 
-    // Feature gathers run two steps ahead, or one step ahead where the registers that saves buy another
-    // block per CU (plain 8-wave instances; all two-group instances)
-    constexpr int DEPTH = ((WAVES == 8 && !IMP && !DUAL) || RG == 2) ? 1 : 2;
-    u32x4 a_q0[RG][NJ * AW], a_q1[DEPTH == 2 ? RG : 1][DEPTH == 2 ? NJ * AW : 1];
+    // Feature gathers run two steps ahead, or one step ahead where the eight registers that saves buy another
+    // block per CU (plain 8-wave instances: 80 registers -> three blocks of NT = 8; measured per layer)
+    constexpr int DEPTH = (WAVES == 8 && !IMP && !DUAL) ? 1 : 2;
+    u32x4 a_q0[NJ * AW], a_q1[DEPTH == 2 ? NJ * AW : 1];
     unsigned long long todo1 = bmask;
     int k_cur = bmask ? __builtin_ctzll(bmask) : -1, p_cur = 0;
     int k1 = k_cur, p1 = 0;
     ASR_SEQ_ADVANCE(todo1, k1, p1)
-    u32x4 idx4_cur[RG], idx4_next[RG];
-#pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-        idx4_cur[rg] = {~0u, ~0u, ~0u, ~0u};
-        idx4_next[rg] = {~0u, ~0u, ~0u, ~0u};
-    }
+    u32x4 idx4_cur = {~0u, ~0u, ~0u, ~0u}, idx4_next = {~0u, ~0u, ~0u, ~0u};
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     if (k_cur >= 0) {
         dma_panel(k_cur, p_cur, B0());
-        if (ROWW && roww) {
-#pragma unroll
-            for (int rg = 0; rg < RG; ++rg) idx4_next[rg] = load_idx4(rg, k_cur);
-        }
+        if (ROWW && roww) idx4_next = load_idx4(k_cur);
         gather_a(k_cur, p_cur, a_q0, true);
         if constexpr (DEPTH == 2) gather_a(k1, p1, a_q1, false);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    auto step = [&](u32x4 (&aq)[RG][NJ * AW], auto bufc) __attribute__((always_inline)) {
+    auto step = [&](u32x4 (&aq)[NJ * AW], auto bufc) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value;
         int k2 = k1, p2 = p1;
         ASR_SEQ_ADVANCE(todo1, k2, p2)
@@ -826,57 +729,41 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
         // its reads).  Issued before every other load of this step: the wait at the end of the step counts on it.
         dma_panel(k1, p1, std::integral_constant<int, BUF ^ 1>());
         __builtin_amdgcn_sched_barrier(0);
-        bool active[RG];
-        bool any = false;
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-            active[rg] = (wmask[rg] >> k_cur) & 1;
-            any |= active[rg];
-        }
-        float w4[RG][4];
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w4[rg][i] = 0.f;
+        const bool active = (wmask >> k_cur) & 1;
+        float w4[4] = {0.f, 0.f, 0.f, 0.f};
         const bool slot_end = p_cur == npanel - 1;
         if (ROWW && roww) {
             // only where they are needed (wave-uniform branches): the wait at the end of the step needs at least the
-            // gathers after the panel DMA, more loads in between only make it wait for them as well
+            // NJ*AW gathers after the panel DMA, more loads in between only make it wait for them as well
+            if (p_cur == 0) idx4_cur = idx4_next;
+            if (p1 == 0) idx4_next = load_idx4(k1);  // first step of the next slot is the next step
+            if (slot_end && active) {
 #pragma unroll
-            for (int rg = 0; rg < RG; ++rg) {
-                if (p_cur == 0) idx4_cur[rg] = idx4_next[rg];
-                if (p1 == 0) idx4_next[rg] = load_idx4(rg, k1);  // first step of the next slot is the next step
-                if (slot_end && active[rg]) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)  // idx -1 -> beyond the buffer -> 0
-                        w4[rg][i] = __uint_as_float(
-                                __builtin_amdgcn_raw_buffer_load_b32(rs_i, (int)(idx4_cur[rg][i] * 4u), 0, 0));
-                }
+                for (int i = 0; i < 4; ++i)  // idx -1 -> beyond the buffer -> 0
+                    w4[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_i, (int)(idx4_cur[i] * 4u), 0, 0));
             }
         }
-        u32x4 fa[RG][NJ][PLANES];
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-            if (!active[rg]) continue;
+        u32x4 fa[NJ][PLANES];
+        if (active) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if constexpr (MODE == ASR_CONV16_F16) {
-                    fa[rg][j][0] = aq[rg][j];
+                    fa[j][0] = aq[j];
                 } else {
                     unsigned p0[4], p1v[4], p2v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const f32x2 v = {__uint_as_float(aq[rg][j * 2 + (i >> 1)][2 * (i & 1)]),
-                                         __uint_as_float(aq[rg][j * 2 + (i >> 1)][2 * (i & 1) + 1])};
+                        const f32x2 v = {__uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1)]),
+                                         __uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1) + 1])};
                         p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
                         const f32x2 r1 = {v.x - __uint_as_float(p0[i] << 16), v.y - __uint_as_float(p0[i] & 0xffff0000u)};
                         p1v[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
                         const f32x2 r2 = {r1.x - __uint_as_float(p1v[i] << 16), r1.y - __uint_as_float(p1v[i] & 0xffff0000u)};
                         p2v[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
                     }
-                    fa[rg][j][0] = (u32x4){p0[0], p0[1], p0[2], p0[3]};
-                    fa[rg][j][PLANES > 1 ? 1 : 0] = (u32x4){p1v[0], p1v[1], p1v[2], p1v[3]};
-                    fa[rg][j][PLANES > 2 ? 2 : 0] = (u32x4){p2v[0], p2v[1], p2v[2], p2v[3]};
+                    fa[j][0] = (u32x4){p0[0], p0[1], p0[2], p0[3]};
+                    fa[j][PLANES > 1 ? 1 : 0] = (u32x4){p1v[0], p1v[1], p1v[2], p1v[3]};
+                    fa[j][PLANES > 2 ? 2 : 0] = (u32x4){p2v[0], p2v[1], p2v[2], p2v[3]};
                 }
             }
         }
@@ -884,37 +771,30 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
             gather_a(k2, p2, aq, false);
         else
             gather_a(k1, p1, aq, false);
-        if (any) {
+        if (active) {
             const u32x4* sb = BUF ? s_B1 : s_B0;
             __builtin_amdgcn_s_setprio(1);
-            if constexpr (RG == 1)  // (the one-group form keeps its B fragments for three MFMAs only)
-                sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa[0], sb, acc[0], tacc[0], has_b, ncol, g);
-            else
-                sconv16_products_rg<NT, KC, MODE, IMP, DUAL, PLANES, NJ, RG>(fa, sb, acc, tacc, has_b, ncol, g, active);
+            sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa, sb, acc, tacc, has_b, ncol, g);
             __builtin_amdgcn_s_setprio(0);
             if (ROWW && roww && slot_end) {
 #pragma unroll
-                for (int rg = 0; rg < RG; ++rg) {
-                    if (!active[rg]) continue;
+                for (int i = 0; i < 4; ++i) norm4[i] += w4[i];
+                if (IMP) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) norm4[rg][i] += w4[rg][i];
-                    if (IMP) {
+                    for (int nb = 0; nb < NT; ++nb) {
 #pragma unroll
-                        for (int nb = 0; nb < NT; ++nb) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[rg][nb][i] += w4[rg][i] * tacc[rg][nb][i];
-                            tacc[rg][nb] = {0.f, 0.f, 0.f, 0.f};
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc_b[rg][i] += w4[rg][i] * tacc[rg][0][i];
-                        tacc[rg][0] = {0.f, 0.f, 0.f, 0.f};
+                        for (int i = 0; i < 4; ++i) acc[nb][i] += w4[i] * tacc[nb][i];
+                        tacc[nb] = {0.f, 0.f, 0.f, 0.f};
                     }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc_b[i] += w4[i] * tacc[0][i];
+                    tacc[0] = {0.f, 0.f, 0.f, 0.f};
                 }
             }
         }
-        // the panel DMA of this step has landed once at most the gather loads issued after it are in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ * AW * RG) : "memory");
+        // the panel DMA of this step has landed once at most the NJ*AW gather loads issued after it are in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ * AW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         k_cur = k1;
@@ -932,21 +812,18 @@ __global__ __launch_bounds__(WAVES * 64, RG == 2 ? (WAVES == 8 ? 2 : 3)
     }
 #undef ASR_SEQ_ADVANCE
 
+    // output rows of this lane's four accumulator rows (-1: beyond the list)
+    int q4[4];
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg) {
-        // output rows of this lane's four accumulator rows (-1: beyond the list)
-        int q4[4];
+    for (int i = 0; i < 4; ++i) {
+        const i64 lr = row0 + wave * 16 + 4 * g + i;
+        q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
+    }
+    sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, q4, norm4, n0, ncol, ca, cout, has_b, out_f16, zeros);
+    if (ROWW && a.out_importance && ncol == 0 && (DUAL ? has_b : ychunk == 0)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i64 lr = row0 + (wave * RG + rg) * 16 + 4 * g + i;
-            q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
-        }
-        sconv16_epilogue<NT, MODE, DUAL>(a, acc[rg], acc_b[rg], q4, norm4[rg], n0, ncol, ca, cout, has_b, out_f16, zeros);
-        if (ROWW && a.out_importance && ncol == 0 && (DUAL ? has_b : ychunk == 0)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (q4[i] >= 0) a.out_importance[q4[i]] = norm4[rg][i];
-        }
+        for (int i = 0; i < 4; ++i)
+            if (q4[i] >= 0) a.out_importance[q4[i]] = norm4[i];
     }
 }
 
@@ -1040,28 +917,14 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
             ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: the plan was built for another list");
         pv = plan->view();
     }
-    // two 16-row groups per wave (k_sconv_plan16<..., RG = 2>): plan-driven bf16x3 launches without per-slot
-    // accumulators, where the launch still has enough blocks; option sconv16_rg: 0 off, 1 = column tiles up to 64
-    // (default: the level-0 layers, bound by weight-panel and gather traffic), 2 = every width
-    const i64 rg_opt = ctx->opt.sconv16_rg;  // 3: wherever the instance exists (tests)
-    const bool rg_shape = use_plan && mode == ASR_CONV16_BF16X3 && !(imp && !dual);
-    const bool rg2 = rg_shape && (rg_opt == 3 || (rg_opt != 0 && (nt <= 4 || rg_opt >= 2) && !a.force_nt && !(dual && wide) &&
-                                                  ((a.num_out + (wide ? 255 : 127)) / (wide ? 256 : 128)) *
-                                                                  (ctot_pad / (nt * 16)) >= 1024));
 #define ASR_L16(NT_, KC_, W_, M_, I_, D_)                                                                        \
     {                                                                                                            \
-        const int rg_ = (rg2 && M_ == ASR_CONV16_BF16X3 && !(I_)) ? 2 : 1;                                       \
-        const i64 tiles_ = (a.num_out + W_ * 16 * rg_ - 1) / (W_ * 16 * rg_);                                    \
+        const i64 tiles_ = (a.num_out + W_ * 16 - 1) / (W_ * 16);                                                \
         const i64 ny_ = ctot_pad / (NT_ * 16);                                                                   \
-        const int xt_ = use_plan && ny_ == 1 && ctx->opt.sconv_xcd_tiles != 0;                                    \
-        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : (xt_ ? (tiles_ + 63) / 64 * 64 : tiles_)));  \
-        if (use_plan && rg_ == 2) {                                                                              \
-            if constexpr (M_ == ASR_CONV16_BF16X3 && !(I_))                                                      \
-                k_sconv_plan16<NT_, KC_, W_, M_, I_, D_, 2><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(            \
-                        a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros, xt_);                      \
-        } else if (use_plan)                                                                                     \
-            k_sconv_plan16<NT_, KC_, W_, M_, I_, D_, 1><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                \
-                    a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros, xt_);                          \
+        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));                                  \
+        if (use_plan)                                                                                            \
+            k_sconv_plan16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                   \
+                    a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                               \
         else                                                                                                     \
             k_sconv_mfma16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                   \
                     a, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                                   \
@@ -1099,13 +962,9 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
 #undef ASR_L16
     ASR_CHECK_LAUNCH(ctx);
     {
-        char key[64];  // NT,KC,IMP,WAVES,DUAL,MODE,PLAN[,RG] (k_sconv_mfma16 / k_sconv_plan16 instance; RG when 2)
-        if (rg2)
-            snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d,2", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
-                     dual ? 1 : 0, mode, use_plan ? 1 : 0);
-        else
-            snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
-                     dual ? 1 : 0, mode, use_plan ? 1 : 0);
+        char key[64];  // NT,KC,IMP,WAVES,DUAL,MODE,PLAN (k_sconv_mfma16 / k_sconv_plan16 instance)
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
+                 dual ? 1 : 0, mode, use_plan ? 1 : 0);
         ++ctx->sconv_launches[key];
     }
     return ASR_HIP_OK;

@@ -315,31 +315,6 @@ __global__ void k_octree_insert_keys(const u64* keys, i64 n, HashTab t, int* cnt
     insert_with_ancestors(t, keys[i], cnt, list, list_cap);
 }
 
-// the same from the Morton-ordered copy of the points (asr_geom_presort): runs of equal keys along a wave
-__global__ void k_octree_insert_sorted(asr_octree_frame f, const float4* sorted, const float* srad, i64 n,
-                                       float radius_scale, int max_depth, HashTab t, int* cnt, u64* list, int list_cap) {
-    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    u64 key = 0;
-    if (i < n) {
-        const float4 p = sorted[i];
-        const float r = srad[i];
-        if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(r))) {
-            cnt[11] = 1;
-        } else if (!(p.x < f.bb_min[0] || p.y < f.bb_min[1] || p.z < f.bb_min[2] || p.x > f.bb_max[0] ||
-                     p.y > f.bb_max[1] || p.z > f.bb_max[2])) {
-            int level = level_from_scale(f, radius_scale * r);
-            level = level < max_depth ? level : max_depth;
-            int x, y, z;
-            frame_coord(f, p.x, p.y, p.z, level, x, y, z);
-            key = asr_coord_key(x, y, z, level);
-        }
-    }
-    const u64 left = __shfl_up(key, 1, 64);
-    if ((threadIdx.x & 63) != 0 && left == key) return;
-    if (key == 0) return;
-    insert_with_ancestors(t, key, cnt, list, list_cap);
-}
-
 // BalanceFaces (octree.cpp:152-206), one round: the frontier is the list range [lo, hi) of sibling
 // groups.  Leaf test against the node set at round start (octree.cpp:175) ...
 __global__ void k_balance_classify(HashTab t, const u64* list, int lo, int ngroups, uint8_t* flag) {
@@ -1011,102 +986,6 @@ __device__ __forceinline__ void radius_row_out(i64 q, i64 found, bool heavy, int
         if (lane + 64 * u < h) tmp[q * RADIUS_LIGHT + rank[u]] = (mine[u] & 0xffffffff00000000ull) | (u32)mypos[u];
 }
 
-// ------------------------------------------------------------------------------------------
-// Aggregation search, one wave per SIBLING GROUP of voxels.  The leaves that share a parent (X, Y, Z) of level
-// L - 1 are consecutive in the sorted key array; their balls (radius = cell size s of level L, centres at the cell
-// centres) lie inside the 4 x 4 x 4 block of level-L cells [2X-1, 2X+2]^3 with half a cell of margin on every side.
-// The wave looks those 64 cells up ONCE (8 table probes per voxel instead of 27 .. 64), stages their points in LDS
-// and tests them against each of its up to eight voxels from there.  On a surface-like cloud the block holds about
-// as many points as two separate 3^3 blocks.  Blocks with more than GROUP_CAP points (dense spots next to coarse
-// voxels) hand their voxels to the per-voxel kernel through a list.
-// ------------------------------------------------------------------------------------------
-constexpr int GROUP_CAP = 512;
-__global__ void k_group_heads(const u64* keys, i64 v, int32_t* heads, int* cnt) {
-    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    const bool head = i < v && (i == 0 || (keys[i] >> 3) != (keys[i - 1] >> 3));
-    const int o = block_append(head, cnt);
-    if (head) heads[o] = (int32_t)i;
-}
-__global__ __launch_bounds__(256) void k_radius_groups(const float4* sorted, const u64* keys, const float* centers,
-                                                       const float* sizes, i64 v, const int32_t* heads, const int* num_heads,
-                                                       CellIndex ci, i64* counts, u64* tmp, int32_t* heavy_out,
-                                                       int* heavy_cnt, uint8_t* is_heavy, int32_t* fb_list, int* fb_cnt) {
-    __shared__ int s_pref[4][65];
-    __shared__ int s_beg[4][64];
-    __shared__ float4 s_pt[4][GROUP_CAP];
-    __shared__ int s_cpos[4][GROUP_CAP];
-    __shared__ u64 s_keys[4][RADIUS_LIGHT];
-    __shared__ int s_pos[4][RADIUS_LIGHT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ng = *num_heads;
-    for (i64 g = blockIdx.x * (i64)4 + wave; g < ng; g += (i64)gridDim.x * 4) {
-        const i64 h = heads[g];
-        const u64 key0 = keys[h];
-        const u64 parent = key0 >> 3;
-        const bool member = lane < 8 && h + lane < v && (keys[h + lane] >> 3) == parent;
-        const int nm = __popcll(__ballot(member));  // the leaves of one parent are consecutive
-        const int lev = asr_key_level(key0);
-        int total = GROUP_CAP + 1;
-        __builtin_amdgcn_wave_barrier();  // the LDS tables of the previous group have been read
-        if (lev > 0) {
-            int X, Y, Z, pl;
-            asr_key_coord(parent, X, Y, Z, pl);
-            const int lim = (1 << lev) - 1;
-            const int xx = 2 * X - 1 + (lane & 3), yy = 2 * Y - 1 + ((lane >> 2) & 3), zz = 2 * Z - 1 + (lane >> 4);
-            int b = 0, n = 0;
-            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
-                cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b, n);
-            total = cells_prefix<64>(b, n, lane, s_pref[wave], s_beg[wave]);
-        }
-        if (total > GROUP_CAP) {  // per-voxel kernel
-            int base = 0;
-            if (lane == 0) base = atomicAdd(fb_cnt, nm);
-            base = __shfl(base, 0, 64);
-            if (lane < nm) fb_list[base + lane] = (int32_t)(h + lane);
-            continue;
-        }
-        for (int i = lane; i < total; i += 64) {
-            int pos;
-            s_pt[wave][i] = radius_candidate<64>(sorted, s_pref[wave], s_beg[wave], i, &pos);
-            s_cpos[wave][i] = pos;
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int m = 0; m < nm; ++m) {
-            const i64 q = h + m;
-            const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
-            const float r = sizes[q];
-            const float r2 = r * r;
-            i64 found = 0;
-            bool heavy = false;
-            for (int i0 = 0; i0 < total && !heavy; i0 += 64) {
-                const int i = i0 + lane;
-                bool hit = false;
-                float d = 0.f;
-                int id = 0, pos = 0;
-                if (i < total) {
-                    const float4 pt = s_pt[wave][i];
-                    d = sqdist3(pt.x, pt.y, pt.z, cx, cy, cz);
-                    hit = d < r2;
-                    id = __float_as_int(pt.w);
-                    pos = s_cpos[wave][i];
-                }
-                const unsigned long long mk = __ballot(hit);
-                if (hit) {
-                    const i64 o = found + __popcll(mk & ((1ull << lane) - 1));
-                    if (o < RADIUS_LIGHT) {
-                        s_keys[wave][o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
-                        s_pos[wave][o] = pos;
-                    }
-                }
-                found += __popcll(mk);
-                if (found > RADIUS_LIGHT) heavy = true;
-            }
-            radius_row_out(q, found, heavy, lane, s_keys[wave], s_pos[wave], counts, tmp, heavy_out, heavy_cnt, is_heavy);
-            __builtin_amdgcn_wave_barrier();  // s_keys is reused by the next voxel
-        }
-    }
-}
-
 // one query of k_radius_query by one wave; s_*: the wave's LDS rows
 template <int MODE, bool ALIGNED>
 __device__ __forceinline__ void radius_query_one(const asr_octree_frame& f, const float4* sorted, const float* centers,
@@ -1179,14 +1058,13 @@ __device__ __forceinline__ void radius_query_one(const asr_octree_frame& f, cons
     radius_row_out(q, found, heavy, lane, s_keys, s_pos, counts, tmp, heavy_out, heavy_cnt, is_heavy);
 }
 
-// all queries 0..v (launch of ceil((v + 1) / 4) blocks, one query per wave) or -- LIST, grid-stride -- the queries of a
-// device-side list
-template <int MODE, bool ALIGNED, bool LIST = false>
+// all queries 0..v (launch of ceil((v + 1) / 4) blocks), one query per wave
+template <int MODE, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const float4* sorted,
                                                       const float* centers, const float* sizes,
                                                       i64 v, CellIndex ci, AlignedQ aq, i64* counts, u64* tmp,
                                                       int32_t* heavy_out, int* heavy_cnt,
-                                                      uint8_t* is_heavy, const int32_t* list, const int* list_cnt) {
+                                                      uint8_t* is_heavy) {
     constexpr int NCELL = ALIGNED ? 64 : 27;
     __shared__ int s_pref[4][NCELL + 1];
     __shared__ int s_beg[4][NCELL];
@@ -1194,20 +1072,11 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
     __shared__ int s_pos[MODE == 2 ? 4 : 1][RADIUS_LIGHT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kw = MODE == 2 ? wave : 0;
-    if (!LIST) {
-        const i64 q = blockIdx.x * (i64)4 + wave;
-        if (q == v && lane == 0) counts[v] = 0;
-        if (q >= v) return;
-        radius_query_one<MODE, ALIGNED>(f, sorted, centers, sizes, q, ci, aq, counts, tmp, heavy_out, heavy_cnt, is_heavy, lane,
-                                        s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
-    } else {
-        const i64 nq = *list_cnt;
-        for (i64 qi = blockIdx.x * (i64)4 + wave; qi < nq; qi += (i64)gridDim.x * 4) {
-            __builtin_amdgcn_wave_barrier();  // the LDS rows of the previous query have been read
-            radius_query_one<MODE, ALIGNED>(f, sorted, centers, sizes, list[qi], ci, aq, counts, tmp, heavy_out, heavy_cnt,
-                                            is_heavy, lane, s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
-        }
-    }
+    const i64 q = blockIdx.x * (i64)4 + wave;
+    if (q == v && lane == 0) counts[v] = 0;
+    if (q >= v) return;
+    radius_query_one<MODE, ALIGNED>(f, sorted, centers, sizes, q, ci, aq, counts, tmp, heavy_out, heavy_cnt, is_heavy, lane,
+                                    s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
 }
 
 // Heavy rows: RADIUS_SPLIT blocks per row, each block walks 1/RADIUS_SPLIT of the candidates.
@@ -2028,8 +1897,8 @@ static int grow_keys(asr_hip_context* ctx, Arena& arena, const asr_octree_frame*
 }
 
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
-                          const float* radii, i64 n, float radius_scale, int max_depth, const AsrPointIndex* pre,
-                          int grow_steps, const u64* extra_keys, i64 num_extra, bool balance) {
+                          const float* radii, i64 n, float radius_scale, int max_depth, int grow_steps,
+                          const u64* extra_keys, i64 num_extra, bool balance) {
     ASR_TRY(ensure_flags(ctx));
     if (max_depth > ASR_MAX_LEVEL) max_depth = ASR_MAX_LEVEL;
     if (max_depth < 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "max_depth must be >= 0");
@@ -2065,12 +1934,8 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
                                                                                        list, lcap);
             ASR_CHECK_LAUNCH(ctx);
         } else if (n > 0) {
-            if (pre && pre->valid && pre->n == n && pre->srad)
-                k_octree_insert_sorted<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
-                        *frame, pre->sorted, pre->srad, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);
-            else
-                k_octree_insert_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(
-                        *frame, pts, radii, n, radius_scale, max_depth, t, ctx->d_flags, list, lcap);
+            k_octree_insert_points<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, radii, n, radius_scale, max_depth,
+                                                                              t, ctx->d_flags, list, lcap);
             ASR_CHECK_LAUNCH(ctx);
         }
         if (num_extra > 0) {  // node keys of other builds (the local octrees of the other ranks): same closure
@@ -2682,46 +2547,18 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 15, 0, sizeof(int), ctx->stream));
     st.aq = AlignedQ{voxel_keys, extras, ctx->d_flags + 15, lhalf_max};
     // one pass: counts, the sorted light rows (fixed slots) and the list of heavy rows
-    const bool groups = voxel_keys != nullptr && ctx->opt.search_groups != 0;
     if (st.aligned && ep.lmax >= ep.lmin && n > 0) {
         k_radius_extras<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(st.codes, st.sorted, n, voxel_keys, v, centers, sizes,
                                                                   ep, extras, ctx->d_flags + 15);
         ASR_CHECK_LAUNCH(ctx);
     }
-    const int32_t* qlist = nullptr;
-    const int* qlist_cnt = nullptr;
-    unsigned qgrid = grid_for(v + 1, 4);
-    if (groups) {
-        // one wave per sibling group (k_radius_groups); the voxels of crowded groups come back as a list for the
-        // per-voxel kernel below, which then runs grid-stride over that list (its length stays on the device)
-        int32_t* heads = arena_alloc<int32_t>(ctx->scratch, v);
-        int32_t* fb = arena_alloc<int32_t>(ctx->scratch, v);
-        if (!heads || !fb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        int* gcnt = ctx->d_flags + 16;  // [0] groups, [1] voxels handed to the per-voxel kernel
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(gcnt, 0, 2 * sizeof(int), ctx->stream));
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(counts + v, 0, sizeof(i64), ctx->stream));
-        k_group_heads<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(voxel_keys, v, heads, gcnt);
-        ASR_CHECK_LAUNCH(ctx);
-        k_radius_groups<<<3072, BLK, 0, ctx->stream>>>(st.sorted, voxel_keys, centers, sizes, v, heads, gcnt, st.index(),
-                                                       counts, st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy, fb,
-                                                       gcnt + 1);
-        ASR_CHECK_LAUNCH(ctx);
-        qlist = fb;
-        qlist_cnt = gcnt + 1;
-        qgrid = 1024;
-    }
-#define ASR_RQ(AL_, LI_)                                                                                              \
-    k_radius_query<2, AL_, LI_><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts, \
-                                                                 st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy, qlist, qlist_cnt)
-    if (st.aligned_main && qlist)
-        ASR_RQ(true, true);
-    else if (st.aligned_main)
-        ASR_RQ(true, false);
-    else if (qlist)
-        ASR_RQ(false, true);
+    const unsigned qgrid = grid_for(v + 1, 4);
+    if (st.aligned_main)
+        k_radius_query<2, true><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts,
+                                                                st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy);
     else
-        ASR_RQ(false, false);
-#undef ASR_RQ
+        k_radius_query<2, false><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts,
+                                                                 st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(read_flags(ctx, host));
     if (host[1]) {  // retry with a table four times the size
@@ -2762,7 +2599,7 @@ int asr_geom_radius_neighbor_count(asr_hip_context* ctx, const asr_octree_frame*
     i64* counts = arena_alloc<i64>(ctx->scratch, n + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     k_radius_query<0, false><<<grid_for(n + 1, 4), BLK, 0, ctx->stream>>>(
-            *frame, st.sorted, pts, radii, n, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            *frame, st.sorted, pts, radii, n, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr);
     ASR_CHECK_LAUNCH(ctx);
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(counts_out, counts, n * sizeof(i64), hipMemcpyDeviceToDevice,
                                       ctx->stream));

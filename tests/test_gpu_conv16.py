@@ -325,47 +325,6 @@ def test_plan_kernel_equals_table_kernel_on_random_lists(gpu):
             assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max())), case
 
 
-def test_two_row_groups_per_wave_variant(geo, gpu):
-    """option sconv16_rg = 3 forces k_sconv_plan16<..., RG = 2> (two 16-row groups per wave, a B fragment feeds both):
-    same results as the oracle on plain and two-bank layers; the launch counters name the variant"""
-    from asr_hip import ops
-    ctx = ops.context(gpu)
-    ctx.set_option("sconv16_rg", 3)
-    try:
-        rng = np.random.default_rng(5)
-        for level, cin, ca, cb, nt, waves in ((0, 64, 64, 0, 4, 8), (0, 32, 56, 8, 4, 4), (1, 128, 128, 0, 8, 4),
-                                              (0, 32, 32, 0, 2, 8)):
-            idx, kidx, rs, num_inp = _csr(geo, "nb", level)
-            v = len(rs) - 1
-            f = rng.standard_normal((num_inp, cin)).astype(np.float32)
-            Wa = (rng.standard_normal((55, cin, ca)) * np.sqrt(2.0 / (8 * cin))).astype(np.float32)
-            ba = (rng.standard_normal(ca) * 0.1).astype(np.float32)
-            imp = rng.uniform(0.05, 1.0, size=num_inp).astype(np.float32)
-            Wb = (rng.standard_normal((55, cin, cb)) * np.sqrt(2.0 / (8 * cin))).astype(np.float32) if cb else None
-            bb = (rng.standard_normal(cb) * 0.1).astype(np.float32) if cb else None
-            packed = ops.pack_filters(_t(Wa, gpu), "bf16x3", _t(Wb, gpu) if cb else None)
-            with O.precise():
-                ref = np.maximum(O.sparse_conv(Wa, f, idx, kidx, None, rs, False) + ba, 0)
-                if cb:
-                    refb = np.maximum(O.sparse_conv(Wb, f, idx, kidx, imp[idx.astype(np.int64)], rs, True) + bb, 0)
-                    ref = np.concatenate([ref, refb], 1)
-            ctx.sconv_variant_counts(reset=True)
-            kw = dict(bias=_t(ba, gpu), relu=True, force_nt=nt, force_waves=waves)
-            if cb:
-                out, oimp = ops.sparse_conv16("bf16x3", packed, 55, cin, ca, _t(f, gpu), _t(idx, gpu), _t(kidx, gpu),
-                                              _t(rs, gpu), inp_importance=_t(imp, gpu), normalize=True, cout_b=cb,
-                                              bias_b=_t(bb, gpu), return_importance=True, **kw)
-                _close(oimp.cpu().numpy(), O.reduce_subarrays_sum(imp[idx.astype(np.int64)], rs))
-            else:
-                out = ops.sparse_conv16("bf16x3", packed, 55, cin, ca, _t(f, gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu),
-                                        **kw)
-            _close(out.cpu().numpy(), ref)
-            key = list(ctx.sconv_variant_counts())
-            assert len(key) == 1 and len(key[0]) == 8 and key[0][7] == 2 and key[0][0] == nt and key[0][3] == waves, key
-    finally:
-        ctx.set_option("sconv16_rg", 0)
-
-
 def test_duplicate_slot_in_a_row_is_refused(gpu):
     """the 16-bit kernels keep one neighbour per (row, slot); a list that names a slot twice in one row (legal for
     open3d::sparse_conv, never produced by the reference's grids, cpp/lib/grid.cpp:99-170) is refused when its plan is

@@ -416,25 +416,20 @@ def test_aligned_search_finds_the_pairs_of_the_rounding_margin(gpu, shift):
     assert np.array_equal(o2.leaves, o.leaves)
     ridx, rdist, rrs, rcompat = o2.radius_search(allp, allr, c, s, brute=True)
     pipe = ImplicitPipeline(synth.make_weights(4, seed=1), device=gpu)
-    # (half-size cells, one wave per sibling group): the default, the per-voxel kernel with half-size cells, and the
-    # per-voxel kernel with 3^3 full-size cells
-    for half, groups, presort in ((1, 0, 0), (2, 0, 0), (2, 1, 1), (0, 0, 0)):
+    # half-size cells for the heavy rows only (the default), for every row, and 3^3 full-size cells throughout
+    for half in (1, 2, 0):
         pipe.ctx.set_option("search_half", half)
-        pipe.ctx.set_option("search_groups", groups)
-        pipe.ctx.set_option("presort", presort)  # points sorted once, before the octree (the same results)
         pipe.build(torch.from_numpy(allp).to(gpu), torch.from_numpy(allr).to(gpu), bb[0], bb[1])
         assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), g0["voxel_keys"])
         assert np.array_equal(pipe.get("aggregation_row_splits").cpu().numpy(), rrs), half
         assert np.array_equal(pipe.get("aggregation_neighbors_index").cpu().numpy(), ridx), half
         assert np.array_equal(pipe.get("aggregation_neighbors_dist").cpu().numpy(), rdist), half
         margin = pipe.ctx.get_option("last_search_margin_pairs")
-        print("shift %g half %d groups %d: %d planted points, %d pairs, %d from the rounding margin" %
-              (shift, half, groups, len(planted), len(ridx), margin))
+        print("shift %g half %d: %d planted points, %d pairs, %d from the rounding margin" %
+              (shift, half, len(planted), len(ridx), margin))
         if half:
             assert shift != 0.0 or margin > 0  # (far frame: the float spacing of the planted points is coarser)
     pipe.ctx.set_option("search_half", 1)
-    pipe.ctx.set_option("search_groups", 0)
-    pipe.ctx.set_option("presort", 0)
 
 
 def test_six_grid_levels_vs_oracle(gpu):

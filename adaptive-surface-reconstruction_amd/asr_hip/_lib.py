@@ -14,7 +14,8 @@ ASR_MAX_LEVEL = 21
 ASR_NUM_GRIDS = 5
 CONV16_F16 = 1      # ASR_CONV16_F16: f16 activations + weights, f32 accumulate (config C5)
 CONV16_BF16X3 = 2   # ASR_CONV16_BF16X3: exact three-way bf16 split, fp32-class results
-PRECISIONS = {"f32": 0, "f16": CONV16_F16, "bf16x3": CONV16_BF16X3}
+CONV16_F16X2 = 3    # ASR_CONV16_F16X2: scaled two-way f16 split, fp32-class results from three MFMAs per product
+PRECISIONS = {"f32": 0, "f16": CONV16_F16, "bf16x3": CONV16_BF16X3, "f16x2": CONV16_F16X2}
 
 
 class AsrHipError(RuntimeError):
@@ -62,6 +63,8 @@ class SparseConvArgs(ctypes.Structure):
         ("force_nt", ctypes.c_int),
         ("force_waves", ctypes.c_int),
         ("plan", ctypes.c_void_p),
+        ("inp_absmax", ctypes.c_void_p),
+        ("out_absmax", ctypes.c_void_p),
     ]
 
 
@@ -101,7 +104,8 @@ EXPORTS = [
     "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes", "asr_hip_set_print_callback", "asr_hip_print",
     "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_weights_changed", "asr_hip_context_set_option", "asr_hip_context_get_option",
     "asr_hip_sparse_conv_variant_counts", "asr_hip_sparse_conv_packed_bytes", "asr_hip_sparse_conv_pack",
-    "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_convert_f16",
+    "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_sparse_conv_f16x2",
+    "asr_hip_absmax_f32", "asr_hip_convert_f16",
     "asr_hip_sparse_conv_plan_create", "asr_hip_sparse_conv_plan_destroy", "asr_hip_sparse_conv_plan_bytes", "asr_hip_context_plan_arena_reset",
     "asr_octree_frame_init", "asr_hip_point_keys", "asr_hip_octree_build", "asr_hip_octree_build_grow", "asr_hip_octree_build_parts", "asr_hip_octree_get", "asr_hip_dual_cells_count", "asr_hip_dual_cells_count_for", "asr_hip_dual_cells_fill",
     "asr_hip_contour_count", "asr_hip_contour_fill", "asr_hip_components_count", "asr_hip_components_fill",
@@ -221,7 +225,7 @@ class Context:
 
     def sconv_variant_counts(self, reset=False):
         """{(NT, KC, IMP, WAVES, DUAL): launches} of k_sconv_mfma since the last reset; launches of the 16-bit
-        kernels have a sixth field, the mode (1 = f16, 2 = bf16x3), and a seventh: 1 = k_sconv_plan16 (plan-driven),
+        kernels have a sixth field, the mode (1 = f16, 2 = bf16x3, 3 = f16x2), and a seventh: 1 = k_sconv_plan16 (plan-driven),
         0 = k_sconv_mfma16 (neighbour table in LDS)"""
         buf = ctypes.create_string_buffer(4096)
         self.call("asr_hip_sparse_conv_variant_counts", buf, ctypes.c_size_t(4096), int(bool(reset)))

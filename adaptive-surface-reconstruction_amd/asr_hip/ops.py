@@ -401,7 +401,7 @@ def sparse_conv(filters, inp_features, neighbors_index, neighbors_kernel_index,
 
 def pack_filters(filters, mode, filters_b=None):
     """re-packed 16-bit copy of a filter tensor [K, cin, cout] (+ second bank [K, cin, cout_b]) for
-    sparse_conv16 (asr_hip_sparse_conv_pack); mode: "f16" or "bf16x3".  Pack once per weight tensor."""
+    sparse_conv16 (asr_hip_sparse_conv_pack); mode: "f16", "bf16x3" or "f16x2".  Pack once per weight tensor."""
     m = _lib.PRECISIONS[mode]
     filters = _dev(filters, torch.float32)
     fb = _dev(filters_b, torch.float32) if filters_b is not None else None
@@ -452,11 +452,14 @@ class ConvPlan:
 def sparse_conv16(mode, packed, kernel_size, cin, cout, inp_features, neighbors_index, neighbors_kernel_index,
                   neighbors_row_splits, inp_importance=None, normalize=False, bias=None, relu=False, residual=None,
                   out=None, out_dtype=None, return_importance=False, neighbors_importance=None, row_perm=None,
-                  num_rows=None, cout_b=0, bias_b=None, force_nt=0, force_waves=0, plan=None):
-    """SpecialSparseConv.forward on the 16-bit matrix cores (asr_hip_sparse_conv_f16 / _bf16x3).
+                  num_rows=None, cout_b=0, bias_b=None, force_nt=0, force_waves=0, plan=None, inp_absmax=None,
+                  out_absmax=None):
+    """SpecialSparseConv.forward on the 16-bit matrix cores (asr_hip_sparse_conv_f16 / _bf16x3 / _f16x2).
     mode "f16": inp_features / residual are float16 tensors, out is float16 (default) or float32;
-    mode "bf16x3": float32 in and out, fp32-class result.  packed: pack_filters(filters, mode[, filters_b]).
-    plan: ConvPlan of this list (one is built for the call otherwise)."""
+    mode "bf16x3" / "f16x2": float32 in and out, fp32-class result.  packed: pack_filters(filters, mode[, filters_b]).
+    plan: ConvPlan of this list (one is built for the call otherwise).
+    inp_absmax / out_absmax: int32 device scalars with the f32 bits of the largest |element| of the input (f16x2; None:
+    computed by one pass) and the running maximum of what is written to out (new_absmax(); the caller zeroes it)."""
     m = _lib.PRECISIONS[mode]
     act = torch.float16 if mode == "f16" else torch.float32
     inp_features = _dev(inp_features, act)
@@ -506,12 +509,27 @@ def sparse_conv16(mode, packed, kernel_size, cin, cout, inp_features, neighbors_
                 (plan.perm.data_ptr() if plan.perm is not None else None) != (perm.data_ptr() if perm is not None else None):
             raise RuntimeError("sparse_conv16: the plan belongs to other neighbour arrays")
         a.plan = plan.handle
+    a.inp_absmax = inp_absmax.data_ptr() if inp_absmax is not None else None
+    a.out_absmax = out_absmax.data_ptr() if out_absmax is not None else None
     ctx = context(_same_device(packed, inp_features, nidx, nk, rs, imp, nimp, b, bb, res, out, perm))
     if mode == "f16":
         ctx.call("asr_hip_sparse_conv_f16", ctypes.byref(a), ptr(packed), int(out.dtype == torch.float16))
+    elif mode == "f16x2":
+        ctx.call("asr_hip_sparse_conv_f16x2", ctypes.byref(a), ptr(packed))
     else:
         ctx.call("asr_hip_sparse_conv_bf16x3", ctypes.byref(a), ptr(packed))
     return (out, oimp) if return_importance else out
+
+
+def absmax(x, out=None):
+    """f32 bits of the largest |element| of a float32 matrix as an int32 device scalar (asr_hip_absmax_f32): the
+    inp_absmax of sparse_conv16 in mode "f16x2" """
+    x = _dev(x, torch.float32)
+    if out is None:
+        out = torch.zeros(1, dtype=torch.int32, device=x.device)
+    context(x.device).call("asr_hip_absmax_f32", ptr(x), i64(x.shape[0]), ctypes.c_int(x.shape[1]), i64(x.stride(0)),
+                           ptr(out))
+    return out
 
 
 def row_groups(neighbors_kernel_index, neighbors_row_splits, segment_rows=0):

@@ -157,6 +157,7 @@ static void release_members(asr_hip_context* ctx) {
     ctx->plan_arena.release();
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
+    if (ctx->d_absmax) (void)hipFree(ctx->d_absmax);
     if (ctx->ev_ok)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
 }
@@ -473,7 +474,9 @@ int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* a)
     return asr_conv_sparse(ctx, a);
 }
 size_t asr_hip_sparse_conv_packed_bytes(int mode, int K, int cin, int cout, int cout_b) {
-    if ((mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3) || K < 1 || cin < 1 || cout < 1 || cout_b < 0) return 0;
+    if ((mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3 && mode != ASR_CONV16_F16X2) || K < 1 || cin < 1 || cout < 1 ||
+        cout_b < 0)
+        return 0;
     return asr_conv16_packed_bytes(mode, K, cin, cout, cout_b);
 }
 int asr_hip_sparse_conv_pack(asr_hip_context* ctx, int mode, const float* filters, const float* filters_b, int K,
@@ -545,6 +548,16 @@ int asr_hip_sparse_conv_f16(asr_hip_context* ctx, const asr_sparse_conv_args* a,
 int asr_hip_sparse_conv_bf16x3(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed) {
     CTX_GUARD(ctx);
     return conv16_entry(ctx, a, packed, ASR_CONV16_BF16X3, 0);
+}
+int asr_hip_sparse_conv_f16x2(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed) {
+    CTX_GUARD(ctx);
+    return conv16_entry(ctx, a, packed, ASR_CONV16_F16X2, 0);
+}
+int asr_hip_absmax_f32(asr_hip_context* ctx, const float* x, int64_t rows, int cols, int64_t ld, uint32_t* out) {
+    CTX_GUARD(ctx);
+    if (!out || rows < 0 || cols < 0 || ld < cols || (rows > 0 && cols > 0 && !x))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "absmax_f32: bad argument");
+    return asr_conv16_absmax(ctx, x, rows, cols, ld, out);
 }
 int asr_hip_convert_f16(asr_hip_context* ctx, const void* in, int64_t n, void* out, int to_f16) {
     CTX_GUARD(ctx);
@@ -630,12 +643,28 @@ struct Feat {
     float* p;  // f16 data when the network runs with ASR_CONV16_F16 activations (see Net::esz)
     i64 ld;    // row stride in elements
     int c;
+    unsigned* amax = nullptr;  // ASR_CONV16_F16X2: device scalar with the f32 bits of the buffer's largest magnitude,
+                               // kept by the epilogues of the convolutions that write the buffer (Net::new_amax)
 };
 
 struct Net {
     asr_hip_context* ctx;
     WeightTable wt;
-    int precision = 0;  // 0 = exact f32 MFMA, ASR_CONV16_F16, ASR_CONV16_BF16X3 (asr_implicit_params.precision)
+    int precision = 0;  // 0 = exact f32 MFMA, ASR_CONV16_F16, ASR_CONV16_BF16X3, ASR_CONV16_F16X2 (asr_implicit_params.precision)
+    int num_amax = 0;
+
+    // f16x2: a zeroed device scalar for the running maximum of one activation buffer (nullptr in the other modes)
+    unsigned* new_amax() {
+        if (precision != ASR_CONV16_F16X2 || !ctx->d_absmax || num_amax >= 255) return nullptr;
+        return ctx->d_absmax + num_amax++;
+    }
+    int begin_amax() {
+        num_amax = 0;
+        if (precision != ASR_CONV16_F16X2) return ASR_HIP_OK;
+        if (!ctx->d_absmax) ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_absmax, 256 * sizeof(unsigned)));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_absmax, 0, 256 * sizeof(unsigned), ctx->stream));
+        return ASR_HIP_OK;
+    }
 
     size_t esz() const { return precision == ASR_CONV16_F16 ? 2 : 4; }  // bytes per activation element
     // activation buffer [rows, c] in the scratch arena (element type per precision)
@@ -689,7 +718,7 @@ struct Net {
     int conv(const std::string& prefix, int K, Feat in, const int32_t* nidx, const uint8_t* nk,
              const i64* rs, const int32_t* perm, i64 num_out, i64 num_inp, const float* imp,
              int normalize, float* out, i64 out_ld, int expect_cout, float* out_imp,
-             const float* residual, i64 residual_ld, bool out_f32 = false) {
+             const float* residual, i64 residual_ld, bool out_f32 = false, unsigned* out_amax = nullptr) {
         const asr_weight *k, *b;
         ASR_TRY(get(prefix + ".kernel", 3, &k));
         ASR_TRY(get(prefix + ".bias", 1, &b));
@@ -721,13 +750,15 @@ struct Net {
         a.out_ld = out_ld;
         a.out_importance = out_imp;
         a.row_perm = perm;
+        a.inp_absmax = in.amax;
+        a.out_absmax = out_amax;
         return launch(a, k, nullptr, out_f32);
     }
     // conv1a + conv1b of a block in one launch (second filter bank of asr_sparse_conv_args): same
     // gather, one extra column tile.  Falls back to two launches for widths the fused kernel does not take.
     int conv_ab(const std::string& name, int K, Feat in, const int32_t* nidx, const uint8_t* nk, const i64* rs,
                 const int32_t* perm, i64 num_out, i64 num_inp, const float* imp, float* out, i64 out_ld, int ca,
-                int cb, float* out_imp) {
+                int cb, float* out_imp, unsigned* out_amax) {
         const asr_weight *ka, *ba, *kb, *bb;
         ASR_TRY(get(name + ".conv1a.kernel", 3, &ka));
         ASR_TRY(get(name + ".conv1a.bias", 1, &ba));
@@ -740,9 +771,9 @@ struct Net {
                            (uintptr_t)in.p % 16 == 0;
         if (!fused) {
             ASR_TRY(conv(name + ".conv1a", K, in, nidx, nk, rs, perm, num_out, num_inp, nullptr, 0, out, out_ld, ca,
-                         nullptr, nullptr, 0));
+                         nullptr, nullptr, 0, false, out_amax));
             return conv(name + ".conv1b", K, in, nidx, nk, rs, perm, num_out, num_inp, imp, 1, col(out, ca), out_ld,
-                        cb, out_imp, nullptr, 0);
+                        cb, out_imp, nullptr, 0, false, out_amax);
         }
         asr_sparse_conv_args a;
         memset(&a, 0, sizeof(a));
@@ -769,6 +800,8 @@ struct Net {
         a.out_importance = out_imp;
         a.row_perm = perm;
         a.algo = 2;
+        a.inp_absmax = in.amax;
+        a.out_absmax = out_amax;
         return launch(a, ka, kb, false);
     }
     int cout_of(const std::string& prefix, int* c) {
@@ -787,26 +820,30 @@ struct Net {
         float* t1 = act(g.v, C);
         float* t2 = act(g.v, C);
         if (!t1 || !t2) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
+        int ca_ = 0, cb_ = 0;
+        float* oi_ = nullptr;
         if (with_imp) {
-            int ca, cb;
-            ASR_TRY(cout_of(name + ".conv1a", &ca));
-            ASR_TRY(cout_of(name + ".conv1b", &cb));
-            if (ca + cb != C) ASR_FAIL(c, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != block width", name.c_str());
-            float* oi = arena_alloc<float>(c->scratch, g.v);
-            if (!oi) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
-            ASR_TRY(conv_ab(name, 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, imp, t1, C, ca, cb, oi));
-            *out_imp = oi;
+            ASR_TRY(cout_of(name + ".conv1a", &ca_));
+            ASR_TRY(cout_of(name + ".conv1b", &cb_));
+            if (ca_ + cb_ != C) ASR_FAIL(c, ASR_HIP_EWEIGHT, "%s: conv1a+conv1b != block width", name.c_str());
+            oi_ = arena_alloc<float>(c->scratch, g.v);
+            if (!oi_) ASR_FAIL(c, ASR_HIP_EHIP, "arena allocation failed");
+        }
+        // t1 is written twice (conv1, conv3): one running maximum per use
+        Feat f1{t1, C, C, new_amax()}, f2{t2, C, C, new_amax()}, f3{t1, C, C, new_amax()};
+        if (with_imp) {
+            ASR_TRY(conv_ab(name, 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, imp, t1, C, ca_, cb_, oi_, f1.amax));
+            *out_imp = oi_;
         } else {
             ASR_TRY(conv(name + ".conv1", 55, in, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C,
-                         C, nullptr, nullptr, 0));
+                         C, nullptr, nullptr, 0, false, f1.amax));
         }
-        Feat f1{t1, C, C}, f2{t2, C, C};
         ASR_TRY(conv(name + ".conv2", 55, f1, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t2, C, C,
-                     nullptr, nullptr, 0));
+                     nullptr, nullptr, 0, false, f2.amax));
         ASR_TRY(conv(name + ".conv3", 55, f2, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, t1, C, C,
-                     nullptr, nullptr, 0));
-        ASR_TRY(conv(name + ".conv4", 55, f1, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, out.p,
-                     out.ld, C, nullptr, nullptr, 0, out_f32));
+                     nullptr, nullptr, 0, false, f3.amax));
+        ASR_TRY(conv(name + ".conv4", 55, f3, g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, g.v, nullptr, 0, out.p,
+                     out.ld, C, nullptr, nullptr, 0, out_f32, out.amax));
         return ASR_HIP_OK;
     }
     // SparseConvTransitionBlock down (conv1a/conv1b): net_definitions_torch.py:357-387
@@ -819,7 +856,7 @@ struct Net {
         float* oi = arena_alloc<float>(ctx->scratch, coarse.v);
         if (!oi) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(conv_ab(name, 9, in, fine.down_idx, fine.down_kidx, fine.down_rs, fine.perm_down, coarse.v, fine.v,
-                        imp, out.p, out.ld, ca, cb, oi));
+                        imp, out.p, out.ld, ca, cb, oi, out.amax));
         *out_imp = oi;
         return ASR_HIP_OK;
     }
@@ -827,7 +864,7 @@ struct Net {
     int up(const std::string& name, Feat in, const GridDev& fine, const GridDev& coarse, Feat out,
            const float* residual, i64 residual_ld) {
         return conv(name + ".conv1", 9, in, fine.up_idx, fine.up_kidx, fine.up_rs, fine.perm_up, fine.v, coarse.v,
-                    nullptr, 0, out.p, out.ld, out.c, nullptr, residual, residual_ld);
+                    nullptr, 0, out.p, out.ld, out.c, nullptr, residual, residual_ld, false, out.amax);
     }
 };
 
@@ -1070,8 +1107,10 @@ int implicit_aggregate(asr_hip_context* ctx, const float* points, const float* n
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: the build skipped the aggregation search (option build_search)");
     ctx->scratch.reset();
     if (ctx->build_mark_ok) arena_rewind(ctx->persist, ctx->build_mark);
-    if (net.precision != 0 && net.precision != ASR_CONV16_F16 && net.precision != ASR_CONV16_BF16X3)
-        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: precision must be 0, ASR_CONV16_F16 or ASR_CONV16_BF16X3");
+    if (net.precision != 0 && net.precision != ASR_CONV16_F16 && net.precision != ASR_CONV16_BF16X3 &&
+        net.precision != ASR_CONV16_F16X2)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL,
+                 "implicit_network: precision must be 0, ASR_CONV16_F16, ASR_CONV16_BF16X3 or ASR_CONV16_F16X2");
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
     const i64 P = ctx->sizes.num_agg_pairs;
@@ -1159,10 +1198,14 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     float* f10 = buf(g[4].v, c_enc[4]);
     if (!f2 || !f10) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
 
+    // f16x2: every activation buffer has a running maximum, kept by the convolutions that write it (a concat buffer
+    // by both of its producers) and read by the ones that consume it; feats1 comes from the continuous conv: one pass
+    ASR_TRY(net.begin_amax());
+    unsigned* cat_amax[4] = {nullptr, net.new_amax(), net.new_amax(), net.new_amax()};
     Feat enc_out[5];
-    enc_out[0] = Feat{f2, c_enc[0], c_enc[0]};
-    for (int i = 1; i <= 3; ++i) enc_out[i] = Feat{net.col(cat[i], c_up[i]), cat_ld[i], c_enc[i]};
-    enc_out[4] = Feat{f10, c_enc[4], c_enc[4]};
+    enc_out[0] = Feat{f2, c_enc[0], c_enc[0], net.new_amax()};
+    for (int i = 1; i <= 3; ++i) enc_out[i] = Feat{net.col(cat[i], c_up[i]), cat_ld[i], c_enc[i], cat_amax[i]};
+    enc_out[4] = Feat{f10, c_enc[4], c_enc[4], net.new_amax()};
 
     float* imp = nullptr;
     float* feats1_in = feats1;
@@ -1171,30 +1214,32 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
         if (!feats1_in) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_conv16_convert(ctx, feats1, V0 * (i64)C0, feats1_in, 1));
     }
-    ASR_TRY(net.block("sparseconv_encblock0", Feat{feats1_in, C0, C0}, g[0], imp_pairs, true, enc_out[0],
-                      &imp));
+    Feat f_in{feats1_in, C0, C0, net.new_amax()};
+    if (f_in.amax) ASR_TRY(asr_conv16_absmax(ctx, feats1_in, V0, C0, C0, f_in.amax));
+    ASR_TRY(net.block("sparseconv_encblock0", f_in, g[0], imp_pairs, true, enc_out[0], &imp));
     for (int i = 1; i <= 4; ++i) {
         std::string dn = "sparseconv_down" + std::to_string(i < 4 ? i : 3);
         float* t = buf(g[i].v, c_down[i]);
         if (!t) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         float* imp_d = nullptr;
-        ASR_TRY(net.down(dn, enc_out[i - 1], g[i - 1], g[i], imp, Feat{t, c_down[i], c_down[i]}, &imp_d));
+        const Feat ft{t, c_down[i], c_down[i], net.new_amax()};
+        ASR_TRY(net.down(dn, enc_out[i - 1], g[i - 1], g[i], imp, ft, &imp_d));
         float* imp_e = nullptr;
-        ASR_TRY(net.block("sparseconv_encblock" + std::to_string(i), Feat{t, c_down[i], c_down[i]},
-                          g[i], imp_d, true, enc_out[i], &imp_e));
+        ASR_TRY(net.block("sparseconv_encblock" + std::to_string(i), ft, g[i], imp_d, true, enc_out[i], &imp_e));
         imp = imp_e;
     }
     // decoder
     Feat cur = enc_out[4];
     for (int i = 3; i >= 1; --i) {
         ASR_TRY(net.up("sparseconv_up" + std::to_string(i), cur, g[i], g[i + 1],
-                       Feat{cat[i], cat_ld[i], c_up[i]}, nullptr, 0));
+                       Feat{cat[i], cat_ld[i], c_up[i], cat_amax[i]}, nullptr, 0));
         float* d = buf(g[i].v, c_dec[i]);
         if (!d) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         float* dummy = nullptr;
-        ASR_TRY(net.block("sparseconv_decblock" + std::to_string(i), Feat{cat[i], cat_ld[i], cat_ld[i]},
-                          g[i], nullptr, false, Feat{d, c_dec[i], c_dec[i]}, &dummy));
-        cur = Feat{d, c_dec[i], c_dec[i]};
+        const Feat fd{d, c_dec[i], c_dec[i], net.new_amax()};
+        ASR_TRY(net.block("sparseconv_decblock" + std::to_string(i), Feat{cat[i], cat_ld[i], cat_ld[i], cat_amax[i]},
+                          g[i], nullptr, false, fd, &dummy));
+        cur = fd;
     }
     if (c_up[0] != c_enc[0])
         ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "residual skip needs up0 width == encblock0 width");
@@ -1202,10 +1247,11 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     float* code = arena_alloc<float>(ctx->persist, (size_t)V0 * c_dec[0]);
     if (!f21 || !code) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     // feats21 = relu(up0(feats19)) + feats2   (net_definitions_torch.py:631-633)
-    ASR_TRY(net.up("sparseconv_up0", cur, g[0], g[1], Feat{f21, c_up[0], c_up[0]}, f2, c_enc[0]));
+    const Feat ff21{f21, c_up[0], c_up[0], net.new_amax()};
+    ASR_TRY(net.up("sparseconv_up0", cur, g[0], g[1], ff21, f2, c_enc[0]));
     {
         float* dummy = nullptr;
-        ASR_TRY(net.block("sparseconv_decblock0", Feat{f21, c_up[0], c_up[0]}, g[0], nullptr, false,
+        ASR_TRY(net.block("sparseconv_decblock0", ff21, g[0], nullptr, false,
                           Feat{code, c_dec[0], c_dec[0]}, &dummy, true));  // `code` is f32 in every mode
     }
     ctx->code = code;

@@ -190,6 +190,7 @@ struct asr_hip_context {
     bool ev_ok = false;
     int* d_flags = nullptr;  // small device scratch for counters (persistent)
     float* d_zeros = nullptr;  // 4 KB of zeros: target of masked-out loads
+    unsigned* d_absmax = nullptr;  // f16x2: running maxima of the network's activation buffers; [255]: one-off inputs
     void* radius_state = nullptr;  // RadiusState of asr_geom.hip (between _count and _fill)
     void* mesh_state = nullptr;    // MeshState of asr_mesh.hip (between _count and _fill)
     std::map<std::string, std::pair<const void*, size_t>> named;  // asr_hip_implicit_get
@@ -400,6 +401,7 @@ size_t asr_conv16_packed_bytes(int mode, int K, int cin, int cout, int cout_b);
 int asr_conv16_pack(asr_hip_context* ctx, int mode, const float* wa, const float* wb, int K, int cin, int ca, int cb,
                     void* out);
 int asr_conv16_convert(asr_hip_context* ctx, const void* in, i64 n, void* out, int to_f16);
+int asr_conv16_absmax(asr_hip_context* ctx, const float* x, i64 rows, int c, i64 ld, unsigned* out);
 int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed, int mode,
                       int out_f16, const asr_conv_plan* plan);
 int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gidx, const i64* rs,

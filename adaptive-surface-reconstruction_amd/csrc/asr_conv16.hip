@@ -10,6 +10,15 @@
 //                      one fp32 rounding.  6 MFMAs at 16x the f32-MFMA rate = 2.7x the f32 matrix peak for
 //                      the same algorithmic FLOP.
 //
+//   ASR_CONV16_F16X2   fp32-class results from HALF the MFMAs of bf16x3: both operands are scaled by a power of two
+//                      (per tensor: the largest magnitude goes to [2^14, 2^15), exact) and split into two f16
+//                      terms (a = a0 + a1, 11 mantissa bits each, round to nearest), a*b = a0*b0 + a1*b0 + a0*b1.
+//                      What is dropped (a1*b1 and the rounding of the two low terms) stays below 2^-21 |a*b| for
+//                      every element within 2^-17 of its tensor's maximum and below 2^-38 max|a| max|b| for the
+//                      rest -- the f16 range never matters because of the scaling.  The scale of the activations
+//                      comes from a device-side running maximum that the PRODUCING kernel's epilogue maintains
+//                      (asr_sparse_conv_args.out_absmax -> the consumer's inp_absmax); nothing is read back.
+//
 // Weights are re-packed once per weight tensor (asr_conv16_pack): [plane][slot k][column][cin] with cin
 // contiguous and padded to 32, so that a B fragment (8 consecutive k of one column) is one 16-byte piece in
 // HBM, in the LDS panel and in the register.  Same tiling / slot-skipping / two-filter-bank scheme as
@@ -52,10 +61,40 @@ __device__ inline int swz(int col, int slot) {  // 16-byte piece index inside a 
 
 // kc = panel depth the kernels will use for this tensor (asr_conv16_panel_depth); element (k, column, c) of
 // plane pl goes to  pl * plane + ((k * npanel + c / kc) * ctot_pad + column) * kc + swizzled(c % kc)
+// Exponent s of the power-of-two scale 2^s that takes a tensor with the given largest magnitude (f32 bits) to
+// [2^14, 2^15): the rounded-up f16 of the largest element stays finite.  0, denormal, inf and nan: 0.  |s| <= 100, so
+// that 2^s, 2^-s and the halves of the sum of two such exponents are normal f32 numbers (tensors below 2^-86 or above
+// 2^114 lose accuracy).
+__device__ inline int f16x2_scale_exp(unsigned absmax_bits) {
+    const int e = (int)((absmax_bits >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 0;
+    const int s = 14 - (e - 127);
+    return s < -100 ? -100 : (s > 100 ? 100 : s);
+}
+__device__ inline float f16x2_pow2(int s) { return __uint_as_float((unsigned)(127 + s) << 23); }  // |s| <= 126
+
+// largest |x| of a strided matrix as f32 bits (non-negative floats order like their bit patterns)
+__global__ void k_absmax(const float* __restrict__ x, i64 rows, int c, i64 ld, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    const i64 total = rows * c;
+    for (i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(x[(e / c) * ld + e % c]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+}
+
 __global__ void k_pack_filters(const float* __restrict__ wa, const float* __restrict__ wb, int K, int cin, int ca,
-                               int cb, int cin_pad, int ctot_pad, int mode, int kc, u16* __restrict__ out) {
+                               int cb, int cin_pad, int ctot_pad, int mode, int kc, u16* __restrict__ out,
+                               const unsigned* __restrict__ w_absmax) {
     const i64 total = (i64)K * ctot_pad * cin_pad;
     const int npanel = cin_pad / kc;
+    float wscale = 1.f;
+    if (mode == ASR_CONV16_F16X2) {  // trailer: what the conv kernel multiplies its sums with
+        const int sw = f16x2_scale_exp(*w_absmax);
+        wscale = f16x2_pow2(sw);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *(int*)(out + 2 * total) = sw;
+    }
     for (i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
         const int c = (int)(e % cin_pad);
         const int col = (int)((e / cin_pad) % ctot_pad);
@@ -72,6 +111,11 @@ __global__ void k_pack_filters(const float* __restrict__ wa, const float* __rest
         const i64 o = (((i64)k * npanel + pn) * ctot_pad + col) * kc + piece * 8 + (cc & 7);
         if (mode == ASR_CONV16_F16) {
             out[o] = f32_to_f16_bits(w);
+        } else if (mode == ASR_CONV16_F16X2) {
+            const float ws = w * wscale;
+            const u16 h = f32_to_f16_bits(ws);
+            out[o] = h;
+            out[total + o] = f32_to_f16_bits(ws - (float)__builtin_bit_cast(_Float16, h));
         } else {  // exact three-way bf16 split, round to nearest (w = b0 + b1 + b2)
             const u16 b0 = f32_to_bf16_bits(w);
             const float r1 = w - __uint_as_float((unsigned)b0 << 16);
@@ -91,6 +135,24 @@ __global__ void k_f32_to_f16(const float* __restrict__ in, i64 n, u16* __restric
 __global__ void k_f16_to_f32(const u16* __restrict__ in, i64 n, float* __restrict__ out) {
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = (float)__builtin_bit_cast(_Float16, in[i]);
+}
+
+// f16x2: the 8 gathered f32 of a lane (two 16-byte pieces), scaled, as two f16 fragments hi = rn(x), lo = rn(x - hi)
+// (v_cvt_pk_f16_f32: two values per instruction, round to nearest even)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sconv16_split_f16x2(const u32x4& q0, const u32x4& q1, float scale, u32x4& hi, u32x4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32x4& q = i < 2 ? q0 : q1;
+        const f32x2 v = {__uint_as_float(q[2 * (i & 1)]) * scale, __uint_as_float(q[2 * (i & 1) + 1]) * scale};
+        const f16x2 hv = __builtin_convertvector(v, f16x2);
+        const f32x2 r = {v.x - (float)hv.x, v.y - (float)hv.y};
+        h[i] = __builtin_bit_cast(unsigned, hv);
+        l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    }
+    hi = (u32x4){h[0], h[1], h[2], h[3]};
+    lo = (u32x4){l[0], l[1], l[2], l[3]};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -120,6 +182,29 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
                     if (DUAL && has_b && nb == NT - 1)
                         tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);
                 }
+            }
+        } else if constexpr (MODE == ASR_CONV16_F16X2) {
+            const f16x8 a0 = __builtin_bit_cast(f16x8, fa[j][0]);
+            const f16x8 a1 = __builtin_bit_cast(f16x8, fa[j][PLANES > 1 ? 1 : 0]);
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb) {
+                const int col = nb * 16 + ncol;
+                const int piece = col * SLOTS + swz<KC>(col, 4 * j + g);
+#define ASR_THREE(ACC_)                                                                                 \
+    {                                                                                                   \
+        const f16x8 b1 = __builtin_bit_cast(f16x8, sb[PLANE_PIECES + piece]);                           \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, ACC_, 0, 0, 0);                           \
+        const f16x8 b0 = __builtin_bit_cast(f16x8, sb[piece]);                                          \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, ACC_, 0, 0, 0);                           \
+        ACC_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, ACC_, 0, 0, 0);                           \
+    }
+                if (IMP) {
+                    ASR_THREE(tacc[nb])
+                } else {
+                    ASR_THREE(acc[nb])
+                    if (DUAL && has_b && nb == NT - 1) { ASR_THREE(tacc[0]) }
+                }
+#undef ASR_THREE
             }
         } else {
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[j][0]);
@@ -162,8 +247,9 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
 template <int NT, int MODE, bool DUAL>
 __device__ inline void sconv16_epilogue(const asr_sparse_conv_args& a, const f32x4 (&acc)[NT], const f32x4& acc_b,
                                         const int (&rows)[4], const float (&norms)[4], int n0, int ncol, int ca, int cout,
-                                        bool has_b, int out_f16, const float* __restrict__ zeros) {
+                                        bool has_b, int out_f16, const float* __restrict__ zeros, const float (&unscale)[2]) {
     float bv[NT];
+    unsigned amax = 0;  // largest |output| of this lane (f32 bits), for the next layer's f16x2 scale
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) {
         const int col = n0 + nb * 16 + ncol;
@@ -198,8 +284,10 @@ __device__ inline void sconv16_epilogue(const asr_sparse_conv_args& a, const f32
             if (DUAL) {
                 const bool colb = col >= ca;
                 if (nb == NT - 1 && has_b && colb) v = acc_b[i];
+                if (MODE == ASR_CONV16_F16X2) v = v * unscale[0] * unscale[1];  // powers of two: exact
                 v = (colb && do_norm) ? v / norm : v;
             } else {
+                if (MODE == ASR_CONV16_F16X2) v = v * unscale[0] * unscale[1];
                 v = do_norm ? v / norm : v;
             }
             v += bv[nb];
@@ -210,8 +298,17 @@ __device__ inline void sconv16_epilogue(const asr_sparse_conv_args& a, const f32
                     ((u16*)a.out)[q * a.out_ld + col] = f32_to_f16_bits(v);
                 else
                     a.out[q * a.out_ld + col] = v;
+                amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
             }
         }
+    }
+    if (a.out_absmax) {
+        // One candidate per wave; the value only grows, so a wave whose candidate is not above what it reads (possibly
+        // stale, i.e. smaller) has nothing to add -- after the first waves hardly any atomic reaches the L2.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+        if ((threadIdx.x & 63) == 0 && amax > __hip_atomic_load(a.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.out_absmax, amax);
     }
 }
 
@@ -232,7 +329,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
     constexpr int TM = WAVES * 16;
     constexpr int NTHR = WAVES * 64;
     constexpr int NCOL = NT * 16;
-    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : 1;
+    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : (MODE == ASR_CONV16_F16X2 ? 2 : 1);
     constexpr int SLOTS = KC / 8;                 // 16-byte pieces per panel row
     constexpr int NJ = KC / 32;                   // MFMA k-chunks per panel
     constexpr int PV = PLANES * NCOL * SLOTS;     // 16-byte pieces per panel
@@ -338,6 +435,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
 
     const int npanel = (cin + KC - 1) / KC;
     const i64 plane_stride = (i64)K * ctot_pad * cin_pad;  // elements per weight plane
+    // f16x2: activations * a_scale before the split, sums * 2^-(sa + sw) after (in two factors: the sum can reach 200)
+    float a_scale = 1.f, unscale[2] = {1.f, 1.f};
+    if constexpr (MODE == ASR_CONV16_F16X2) {
+        const int sa = f16x2_scale_exp(*a.inp_absmax);
+        const int un = -(sa + *(const int*)(packed + PLANES * plane_stride));
+        a_scale = f16x2_pow2(sa);
+        unscale[0] = f16x2_pow2(un / 2);
+        unscale[1] = f16x2_pow2(un - un / 2);
+    }
 
 #define ASR_SEQ_ADVANCE(todo, k, p)                          \
     if ((k) >= 0 && ++(p) == npanel) {                       \
@@ -462,6 +568,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
             for (int j = 0; j < NJ; ++j) {
                 if constexpr (MODE == ASR_CONV16_F16) {
                     fa[j][0] = aq[j];
+                } else if constexpr (MODE == ASR_CONV16_F16X2) {
+                    sconv16_split_f16x2(aq[j * 2], aq[j * 2 + 1], a_scale, fa[j][0], fa[j][PLANES > 1 ? 1 : 0]);
                 } else {
                     // exact split of the 8 gathered f32 into three bf16 fragments: a0 = rn(a), a1 = rn(a - a0),
                     // a2 = a - a0 - a1 (exactly representable: 24 = 8 + 8 + 8 mantissa bits).  Round to nearest
@@ -529,7 +637,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
         rows4[i] = s_row[wave * 16 + 4 * g + i];
         norms4[i] = s_norm[wave * 16 + 4 * g + i];
     }
-    sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, rows4, norms4, n0, ncol, ca, cout, has_b, out_f16, zeros);
+    sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, rows4, norms4, n0, ncol, ca, cout, has_b, out_f16, zeros, unscale);
     if (a.out_importance && ychunk == 0 && tid < TM && s_row[tid] >= 0)
         a.out_importance[s_row[tid]] = s_norm[tid];
 }
@@ -558,7 +666,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         const float* __restrict__ zeros) {
     constexpr int TM = WAVES * 16;
     constexpr int NCOL = NT * 16;
-    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : 1;
+    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : (MODE == ASR_CONV16_F16X2 ? 2 : 1);
     constexpr int SLOTS = KC / 8;
     constexpr int NJ = KC / 32;
     constexpr int PV = PLANES * NCOL * SLOTS;  // 16-byte pieces per panel
@@ -623,6 +731,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
 
     const int npanel = (cin + KC - 1) / KC;
     const i64 plane_stride = (i64)K * ctot_pad * cin_pad;
+    // f16x2: activations * a_scale before the split, sums * 2^-(sa + sw) after (in two factors: the sum can reach 200)
+    float a_scale = 1.f, unscale[2] = {1.f, 1.f};
+    if constexpr (MODE == ASR_CONV16_F16X2) {
+        const int sa = f16x2_scale_exp(*a.inp_absmax);
+        const int un = -(sa + *(const int*)(packed + PLANES * plane_stride));
+        a_scale = f16x2_pow2(sa);
+        unscale[0] = f16x2_pow2(un / 2);
+        unscale[1] = f16x2_pow2(un - un / 2);
+    }
 
 #define ASR_SEQ_ADVANCE(todo, k, p)                          \
     if ((k) >= 0 && ++(p) == npanel) {                       \
@@ -749,6 +866,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
             for (int j = 0; j < NJ; ++j) {
                 if constexpr (MODE == ASR_CONV16_F16) {
                     fa[j][0] = aq[j];
+                } else if constexpr (MODE == ASR_CONV16_F16X2) {
+                    sconv16_split_f16x2(aq[j * 2], aq[j * 2 + 1], a_scale, fa[j][0], fa[j][PLANES > 1 ? 1 : 0]);
                 } else {
                     unsigned p0[4], p1v[4], p2v[4];
 #pragma unroll
@@ -819,7 +938,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         const i64 lr = row0 + wave * 16 + 4 * g + i;
         q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
     }
-    sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, q4, norm4, n0, ncol, ca, cout, has_b, out_f16, zeros);
+    sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, q4, norm4, n0, ncol, ca, cout, has_b, out_f16, zeros, unscale);
     if (ROWW && a.out_importance && ncol == 0 && (DUAL ? has_b : ychunk == 0)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -835,21 +954,45 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // f16 tensors whose padded cin is a multiple of 64 use 64-deep panels (bf16x3 panels carry three planes)
 static inline int panel_depth(int mode, int cin) { return mode == ASR_CONV16_F16 && round_up(cin, 32) % 64 == 0 ? 64 : 32; }
 
+static inline bool mode_ok(int mode) { return mode == ASR_CONV16_F16 || mode == ASR_CONV16_BF16X3 || mode == ASR_CONV16_F16X2; }
+
+// f16x2: two planes + a 16-byte trailer: [0] the exponent of the weights' power-of-two scale, [1] their largest magnitude
 size_t asr_conv16_packed_bytes(int mode, int K, int cin, int cout, int cout_b) {
-    const size_t planes = mode == ASR_CONV16_BF16X3 ? 3 : 1;
-    return planes * (size_t)K * round_up(cout + cout_b, 16) * round_up(cin, 32) * sizeof(u16);
+    const size_t planes = mode == ASR_CONV16_BF16X3 ? 3 : (mode == ASR_CONV16_F16X2 ? 2 : 1);
+    return planes * (size_t)K * round_up(cout + cout_b, 16) * round_up(cin, 32) * sizeof(u16) +
+           (mode == ASR_CONV16_F16X2 ? 16 : 0);
+}
+
+// largest |x| of a [rows, c] matrix with row stride ld, as f32 bits, into *out (device)
+int asr_conv16_absmax(asr_hip_context* ctx, const float* x, i64 rows, int c, i64 ld, unsigned* out) {
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(out, 0, sizeof(unsigned), ctx->stream));
+    const i64 total = rows * c;
+    if (total <= 0) return ASR_HIP_OK;
+    k_absmax<<<(unsigned)std::min<i64>((total + 255) / 256, 8192), 256, 0, ctx->stream>>>(x, rows, c, ld, out);
+    ASR_CHECK_LAUNCH(ctx);
+    return ASR_HIP_OK;
 }
 
 int asr_conv16_pack(asr_hip_context* ctx, int mode, const float* wa, const float* wb, int K, int cin, int ca, int cb,
                     void* out) {
-    if (mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3)
-        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv_pack: mode must be ASR_CONV16_F16 or ASR_CONV16_BF16X3");
+    if (!mode_ok(mode))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv_pack: mode must be ASR_CONV16_F16, ASR_CONV16_BF16X3 or ASR_CONV16_F16X2");
     if (!wa || !out || K < 1 || K > 56 || cin < 1 || ca < 1 || cb < 0 || (cb > 0 && !wb))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv_pack: bad argument");
     const int cin_pad = round_up(cin, 32), ctot_pad = round_up(ca + cb, 16);
     const i64 total = (i64)K * ctot_pad * cin_pad;
+    unsigned* w_absmax = nullptr;
+    if (mode == ASR_CONV16_F16X2) {  // one scale for both banks; the trailer's spare bytes hold the maximum
+        w_absmax = (unsigned*)((u16*)out + 2 * total) + 1;
+        ASR_TRY(asr_conv16_absmax(ctx, wa, (i64)K * cin, ca, ca, w_absmax));
+        if (cb > 0) {
+            k_absmax<<<(unsigned)std::min<i64>(((i64)K * cin * cb + 255) / 256, 8192), 256, 0, ctx->stream>>>(
+                    wb, (i64)K * cin, cb, cb, w_absmax);
+            ASR_CHECK_LAUNCH(ctx);
+        }
+    }
     k_pack_filters<<<(unsigned)std::min<i64>((total + 255) / 256, 65535), 256, 0, ctx->stream>>>(
-            wa, wb, K, cin, ca, cb, cin_pad, ctot_pad, mode, panel_depth(mode, cin), (u16*)out);
+            wa, wb, K, cin, ca, cb, cin_pad, ctot_pad, mode, panel_depth(mode, cin), (u16*)out, w_absmax);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }
@@ -870,9 +1013,8 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
                       int out_f16, const asr_conv_plan* plan) {
     asr_sparse_conv_args a = *pa;
     if (a.num_out <= 0) return ASR_HIP_OK;
-    if (mode != ASR_CONV16_F16 && mode != ASR_CONV16_BF16X3)
-        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: unknown mode");
-    if (mode == ASR_CONV16_BF16X3 && out_f16) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: bf16x3 writes f32");
+    if (!mode_ok(mode)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: unknown mode");
+    if (mode != ASR_CONV16_F16 && out_f16) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: bf16x3 and f16x2 write f32");
     if (a.kernel_size < 1 || a.kernel_size > 56) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: kernel_size must be 1..56");
     const bool dual = a.cout_b > 0;
     const bool imp = a.inp_importance || a.neighbors_importance;
@@ -887,6 +1029,12 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: row stride smaller than channel count");
     const float* zeros = nullptr;
     ASR_TRY(asr_ctx_zeros(ctx, &zeros));
+    if (mode == ASR_CONV16_F16X2 && !a.inp_absmax) {  // nobody kept the running maximum of this input: one pass over it
+        if (!ctx->d_absmax) ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_absmax, 256 * sizeof(unsigned)));
+        unsigned* m = ctx->d_absmax + 255;
+        ASR_TRY(asr_conv16_absmax(ctx, a.inp_features, a.num_inp, a.cin, a.inp_ld, m));
+        a.inp_absmax = m;
+    }
     const int cin_pad = round_up(a.cin, 32), ctot_pad = round_up(a.cout + a.cout_b, 16);
     // column tile: the widest of 128 / 64 / 32 / 16 that divides the padded width, narrowed while the launch
     // has too few blocks (as asr_conv_sparse)
@@ -953,6 +1101,8 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
             ASR_L16_NT(64, ASR_CONV16_F16)
         else
             ASR_L16_NT(32, ASR_CONV16_F16)
+    } else if (mode == ASR_CONV16_F16X2) {
+        ASR_L16_NT(32, ASR_CONV16_F16X2)
     } else {
         ASR_L16_NT(32, ASR_CONV16_BF16X3)
     }

@@ -45,8 +45,14 @@ PRECISION_INFO = {
                "bf16 dense MFMA peak (%.0f TFLOP/s) / 6: the kernel evaluates every f32 product as six bf16 MFMA "
                "products (exact three-way split, fp32-class result); f32-input MFMA peak %.1f TFLOP/s for comparison"
                % (MFMA_16BIT_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS)),
+    # the same with half the matrix instructions: per-tensor power-of-two scaling, two-way f16 split, three products
+    "f16x2": ("f32", MFMA_16BIT_PEAK_TFLOPS / 3.0, "k_sconv_plan16<f16x2>",
+              "f16 dense MFMA peak (%.0f TFLOP/s) / 3: the kernel evaluates every f32 product as three f16 MFMA "
+              "products (scaled two-way split, fp32-class result); f32-input MFMA peak %.1f TFLOP/s for comparison"
+              % (MFMA_16BIT_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS)),
     "f16": ("f16", MFMA_16BIT_PEAK_TFLOPS, "k_sconv_plan16<f16>", "f16 MFMA dense peak"),
 }
+SPLIT_PRODUCTS = {"bf16x3": 6, "f16x2": 3}
 
 
 def conv_flops(sizes, shapes):
@@ -417,7 +423,7 @@ def main():
                     help="also run the informational two- / three-context pipelined measurement (slower than the serial "
                          "step since round 2: the network leaves no room for a second stream)")
     ap.add_argument("--backend", default="nccl")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16"], default=os.environ.get("ASR_BENCH_PRECISION", "bf16x3"),
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2", "f16"], default=os.environ.get("ASR_BENCH_PRECISION", "bf16x3"),
                     help="arithmetic of the 53 sparse convs: bf16x3 (default) = f32 in / f32 out, every operand split "
                          "exactly into three bf16 terms, six bf16 MFMAs per product, f32 accumulate (fp32-class "
                          "results, same parity bound as f32); f32 = f32-input MFMA, a bit-exact fmaf chain; "
@@ -538,7 +544,7 @@ def main():
     torch.cuda.synchronize()
     t_knn2 = time.perf_counter() - t_knn2
     exact = None
-    if world == 1 and args.precision == "bf16x3" and not args.no_exact_f32:
+    if world == 1 and args.precision in SPLIT_PRODUCTS and not args.no_exact_f32:
         exact = exact_f32_run(weights, dev, (pts, nrm, radii, bb_min, bb_max), n, max(args.steps, 2), shapes,
                               values_timed)
     c2 = c5 = None
@@ -592,9 +598,10 @@ def main():
                        "untimed_exact_f32_kernel": exact},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note,
-                         "executed_bf16_mfma_tflops": 6 * achieved if args.precision == "bf16x3" else None,
+                         "executed_16bit_mfma_tflops": SPLIT_PRODUCTS[args.precision] * achieved
+                         if args.precision in SPLIT_PRODUCTS else None,
                          "ratio_to_f32_input_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS
-                         if args.precision == "bf16x3" else None,
+                         if args.precision in SPLIT_PRODUCTS else None,
                          "traffic": tr[0] if tr else None,
                          "traffic_note": ("HBM bytes per launch, rocprofv3 PMC passes in profiles/%s" % tr[1]) if tr else None,
                          "kernel": "%s (%d launches/step, %.3f ms avg, %.1f algorithmic "

@@ -309,6 +309,12 @@ typedef struct asr_sparse_conv_args {
     /* 16-bit entry points only: row-group plan of this neighbour list (asr_hip_sparse_conv_plan_create), or NULL
      * to have a temporary one built for the call.  A plan is tied to (neighbour arrays, row_perm, num_out). */
     const struct asr_hip_conv_plan* plan;
+    /* ASR_CONV16_F16X2 only: largest |element| of inp_features as f32 bits (device scalar), or NULL to have it
+     * computed by one pass over the input. */
+    const uint32_t* inp_absmax;
+    /* 16-bit entry points: device scalar that receives max(its value, f32 bits of the largest |element| written to
+     * `out`) -- the inp_absmax of the convolutions that read `out`; the caller zeroes it.  NULL: not kept. */
+    uint32_t* out_absmax;
 } asr_sparse_conv_args;
 int asr_hip_sparse_conv_f32(asr_hip_context* ctx, const asr_sparse_conv_args* args);
 /* Launch statistics of the MFMA sparse conv since the last reset: text "NT,KC,IMP,WAVES,DUAL:count;..."
@@ -323,19 +329,29 @@ int asr_hip_sparse_conv_variant_counts(asr_hip_context* ctx, char* buf, size_t c
  * ASR_CONV16_BF16X3: f32 activations and weights; every operand is split exactly into three bf16 terms and
  *   the product is evaluated with six bf16 MFMAs, f32 accumulate -- fp32-class results (error of the dropped
  *   terms < 2^-23 per product) at 2.7x the f32 matrix peak.  args as for asr_hip_sparse_conv_f32.
- * Both take the filters re-packed by asr_hip_sparse_conv_pack (16-bit, [plane][K][cin panel][cout padded to
+ * ASR_CONV16_F16X2: f32 activations and weights, fp32-class results from HALF the MFMAs of bf16x3: each tensor is
+ *   scaled by a power of two (its largest magnitude to [2^14, 2^15): exact, no f16 overflow or underflow worth
+ *   speaking of) and split into two f16 terms, a*b = a0*b0 + a1*b0 + a0*b1 (three f16 MFMAs, f32 accumulate).
+ *   Error per product < 2^-21 for elements within 2^-17 of their tensor's maximum, < 2^-38 of the product of the
+ *   maxima otherwise.  The activations' scale comes from args->inp_absmax, which the producing convolution keeps
+ *   through args->out_absmax (asr_hip_absmax_f32 for other producers).  args as for asr_hip_sparse_conv_f32.
+ * All take the filters re-packed by asr_hip_sparse_conv_pack (16-bit, [plane][K][cin panel][cout padded to
  * 16][panel depth] in the kernels' LDS order; bank b appended as columns); args->filters / filters_b are
  * ignored, cout_b > 0 selects the two-bank form.  cin and the row strides must be multiples of 8 (f16) / 4 (f32) elements.
  * A row may name every kernel slot at most once (true for all lists of the reference's grids, cpp/lib/grid.cpp:99-170,
  * 229-240); a list that does not is refused with ASR_HIP_EINVAL when its plan is built. */
 #define ASR_CONV16_F16 1
 #define ASR_CONV16_BF16X3 2
+#define ASR_CONV16_F16X2 3
 size_t asr_hip_sparse_conv_packed_bytes(int mode, int kernel_size, int cin, int cout, int cout_b);
 int asr_hip_sparse_conv_pack(asr_hip_context* ctx, int mode, const float* filters_dev, const float* filters_b_dev,
                              int kernel_size, int cin, int cout, int cout_b, void* packed_out_dev);
 int asr_hip_sparse_conv_f16(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed_dev,
                             int out_is_f16);
 int asr_hip_sparse_conv_bf16x3(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed_dev);
+int asr_hip_sparse_conv_f16x2(asr_hip_context* ctx, const asr_sparse_conv_args* args, const void* packed_dev);
+/* f32 bits of the largest |element| of a [rows, cols] matrix with row stride ld (floats) into *out_dev */
+int asr_hip_absmax_f32(asr_hip_context* ctx, const float* x_dev, int64_t rows, int cols, int64_t ld, uint32_t* out_dev);
 /* Row-group plan: the neighbour list re-laid in the order the 16-bit kernels stream it -- per 16 consecutive
  * rows (row_perm order) the set of kernel slots in use and, slot by slot, the 16 neighbour indices.  Built once
  * per list and reused by every convolution over it (the U-Net runs ~10 per grid level); the kernels then need no
@@ -404,7 +420,9 @@ typedef struct asr_implicit_params {
     int scale_sdf;            /* 1: values[:,0] *= voxel_size (asr.cpp:334-336)             */
     int precision;            /* arithmetic of the 53 sparse convs: 0 = exact f32 MFMA (default),
                                  ASR_CONV16_F16 = f16 activations + weights (config C5),
-                                 ASR_CONV16_BF16X3 = fp32-class result on the bf16 matrix cores  */
+                                 ASR_CONV16_BF16X3 = fp32-class result on the bf16 matrix cores (six MFMAs per
+                                 product), ASR_CONV16_F16X2 = fp32-class result on the f16 matrix cores
+                                 (three MFMAs per product, per-tensor power-of-two scaling)             */
 } asr_implicit_params;
 
 /* sizes of the structures built by the last asr_hip_implicit_* call */

@@ -78,7 +78,7 @@ def plan_option(request, gpu):
 
 
 @pytest.mark.parametrize("plan_option", [1, 0], ids=["plan", "table"], indirect=True)
-@pytest.mark.parametrize("mode", ["bf16x3", "f16"])
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2", "f16"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%s%d-%dx%d+%d-nt%dw%d" % (s[0], s[1], s[3], s[4], s[5], s[6], s[7]))
 def test_sparse_conv16_vs_oracle(geo, gpu, mode, shape, plan_option):
     from asr_hip import ops
@@ -86,7 +86,7 @@ def test_sparse_conv16_vs_oracle(geo, gpu, mode, shape, plan_option):
     # the plan-driven kernel takes cin that fills whole panels; everything else goes to the table-driven one
     kc = 64 if mode == "f16" and ((cin + 31) // 32 * 32) % 64 == 0 else 32
     expect_plan = int(plan_option and cin % kc == 0)
-    if mode == "bf16x3" and cin % 4:
+    if mode != "f16" and cin % 4:
         pytest.skip("f32 rows need cin % 4 == 0")
     idx, kidx, rs, num_inp = _csr(geo, kind, level)
     v = len(rs) - 1
@@ -127,7 +127,7 @@ def test_sparse_conv16_vs_oracle(geo, gpu, mode, shape, plan_option):
     assert out.dtype == torch.float32
     _close(out.cpu().numpy(), ref)
     key = list(ctx.sconv_variant_counts())
-    assert len(key) == 1 and key[0][5] == (1 if f16 else 2) and (nt == 0 or key[0][0] == nt)
+    assert len(key) == 1 and key[0][5] == {"f16": 1, "bf16x3": 2, "f16x2": 3}[mode] and (nt == 0 or key[0][0] == nt)
     assert key[0][6] == expect_plan, key
     if not cb:
         # importance weighted + normalised single bank (conv1b alone), residual after the activation
@@ -323,6 +323,62 @@ def test_plan_kernel_equals_table_kernel_on_random_lists(gpu):
             assert torch.equal(outs[0], outs[1]), case
         else:
             assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max())), case
+
+
+def _rel(a, b, tol=2e-6):
+    """|a - b| <= tol * max|b|: tensors whose magnitude is far from 1 (1e-5 absolute would be vacuous or hopeless)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err, scale = np.abs(a - b).max(), np.abs(b).max()
+    assert err <= tol * scale, "max err %.3e of %.3e (%.2e)" % (err, scale, err / scale)
+
+
+@pytest.mark.parametrize("fscale,wscale", [(1.0, 1.0), (3e7, 1e-6), (2e-9, 5e4), (1e-20, 1.0), (1.0, 1e25), (1e-20, 1e25)])
+def test_f16x2_range_and_running_maximum(geo, gpu, fscale, wscale):
+    """f16x2 scales each tensor by a power of two before the f16 split: activations and weights far outside the f16
+    range (65504 / 6e-8) give the same fp32-class result; a wide spread inside one tensor (1e-4 .. 1e4 per column)
+    too.  The epilogue keeps the running maximum of what it writes (out_absmax), the next layer's inp_absmax: the
+    same bits as a pass over the output, and a chained second layer agrees with the oracle."""
+    from asr_hip import ops
+    idx, kidx, rs, num_inp = _csr(geo, "nb", 1)
+    v = len(rs) - 1
+    cin, c1, c2 = 64, 64, 32
+    rng = np.random.default_rng(77)
+    spread = np.exp(rng.uniform(np.log(1e-4), np.log(1e4), size=cin)).astype(np.float32)
+    f = (rng.standard_normal((num_inp, cin)) * spread * fscale).astype(np.float32)
+    W1 = (rng.standard_normal((55, cin, c1)) * np.sqrt(2.0 / (8 * cin)) * wscale).astype(np.float32)
+    W2 = (rng.standard_normal((55, c1, c2)) * np.sqrt(2.0 / (8 * c1))).astype(np.float32)
+    b1 = (rng.standard_normal(c1) * 0.1 * fscale * wscale).astype(np.float32)
+    p1 = ops.pack_filters(_t(W1, gpu), "f16x2")
+    p2 = ops.pack_filters(_t(W2, gpu), "f16x2")
+    with O.precise():
+        r1 = np.maximum(O.sparse_conv(W1, f, idx, kidx, None, rs, False) + b1, 0)
+        r2 = O.sparse_conv(W2, r1, idx, kidx, None, rs, False)
+    g = [_t(a, gpu) for a in (idx, kidx, rs)]
+    amax_in = ops.absmax(_t(f, gpu))
+    assert int(amax_in.item()) == int(np.abs(f).max().view(np.int32))
+    amax1 = torch.zeros(1, dtype=torch.int32, device=gpu)
+    o1 = ops.sparse_conv16("f16x2", p1, 55, cin, c1, _t(f, gpu), *g, bias=_t(b1, gpu), relu=True, inp_absmax=amax_in,
+                           out_absmax=amax1)
+    _rel(o1.cpu().numpy(), r1)
+    assert int(amax1.item()) == int(ops.absmax(o1).item()) == int(o1.abs().max().cpu().numpy().view(np.int32))
+    o2 = ops.sparse_conv16("f16x2", p2, 55, c1, c2, o1, *g, inp_absmax=amax1)
+    _rel(o2.cpu().numpy(), r2)
+    # without inp_absmax the entry point makes the pass itself: same bits
+    o2b = ops.sparse_conv16("f16x2", p2, 55, c1, c2, o1, *g)
+    assert torch.equal(o2, o2b)
+
+
+def test_f16x2_zero_input(geo, gpu):
+    from asr_hip import ops
+    idx, kidx, rs, num_inp = _csr(geo, "nb", 2)
+    W = np.random.default_rng(1).standard_normal((55, 32, 32)).astype(np.float32)
+    b = np.arange(32, dtype=np.float32)
+    out = ops.sparse_conv16("f16x2", ops.pack_filters(_t(W, gpu), "f16x2"), 55, 32, 32,
+                            torch.zeros(num_inp, 32, device=gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu), bias=_t(b, gpu))
+    assert torch.equal(out.cpu(), torch.from_numpy(b).expand(len(rs) - 1, 32))
+    zero_w = ops.sparse_conv16("f16x2", ops.pack_filters(torch.zeros(55, 32, 32, device=gpu), "f16x2"), 55, 32, 32,
+                               torch.ones(num_inp, 32, device=gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu))
+    assert float(zero_w.abs().max()) == 0.0
 
 
 def test_duplicate_slot_in_a_row_is_refused(gpu):

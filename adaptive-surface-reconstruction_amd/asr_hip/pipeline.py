@@ -53,8 +53,9 @@ class ImplicitPipeline:
     def __init__(self, weights, device="cuda:0", point_radius_scale=1.0, octree_max_depth=21,
                  scale_sdf=True, precision="f32"):
         """precision: arithmetic of the 53 sparse convs -- "f32" (exact f32 MFMA, the reference's type),
-        "f16" (f16 activations and weights, f32 accumulate: BASELINE config C5) or "bf16x3" (exact three-way
-        bf16 split on the bf16 matrix cores: fp32-class results)"""
+        "f16" (f16 activations and weights, f32 accumulate: BASELINE config C5), "bf16x3" (exact three-way
+        bf16 split on the bf16 matrix cores, six MFMAs per product: fp32-class results) or "f16x2" (per-tensor
+        power-of-two scaling + two-way f16 split, three MFMAs per product: fp32-class results, what bench.py times)"""
         if precision not in _lib.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self.precision = precision

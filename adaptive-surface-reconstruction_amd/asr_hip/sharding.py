@@ -369,6 +369,8 @@ class ShardedNetwork:
         g, w, be = self.g, self.w, self.be
         V0 = self.v[0]
         own0 = self.rows[0]
+        if hasattr(be, "begin_forward"):
+            be.begin_forward()
         if feats1 is None:
             # ---- aggregate (net_definitions_torch.py:640-653): search + continuous conv for the owned voxels
             feats1_own, _ = be.aggregate(points, normals, radii, frame_or_bb, g["voxel_centers0"][own0],
@@ -451,15 +453,19 @@ class ShardedNetwork:
 
 # ---- GPU backend: the C ABI through asr_hip.ops --------------------------------------------------------
 class HipBackend:
-    """precision "f32": the exact f32 MFMA kernel; "bf16x3": the plan-driven 16-bit kernel (fp32-class).  Either way a
-    row is computed by the same kernel arithmetic as on one GPU, so sharded results equal the unsharded pipeline of the
-    same precision bit for bit."""
+    """precision "f32": the exact f32 MFMA kernel; "bf16x3" / "f16x2": the plan-driven 16-bit kernel (fp32-class).
+    Either way a row is computed by the same kernel arithmetic as on one GPU, so sharded results equal the unsharded
+    pipeline of the same precision bit for bit.  f16x2 scales every activation tensor by a power of two taken from its
+    largest magnitude over ALL rows: each rank's convolution keeps the maximum of the rows it writes (out_absmax) and
+    one MAX all-reduce of that scalar per convolution makes it the tensor's (group: the ranks that share the cloud)."""
 
-    def __init__(self, device, precision="f32"):
-        if precision not in ("f32", "bf16x3"):
-            raise ValueError("HipBackend: precision must be 'f32' or 'bf16x3'")
+    def __init__(self, device, precision="f32", group=None):
+        if precision not in ("f32", "bf16x3", "f16x2"):
+            raise ValueError("HipBackend: precision must be 'f32', 'bf16x3' or 'f16x2'")
         self.device = torch.device(device)
         self.precision = precision
+        self.group = group
+        self._amax = {}     # f16x2: storage of an activation buffer -> int32 scalar (f32 bits of its largest magnitude)
         self.supports_out = True  # sparse_conv(..., out=<column slice of a wider buffer>)
         self._packed = {}   # weight tensors (by identity) -> packed 16-bit copy; kept across forwards
         self._plans = {}    # (row splits, row list) -> (int32 row list, ConvPlan); one geometry
@@ -481,8 +487,43 @@ class HipBackend:
         key = (id(kernel), id(kernel_b))
         if key not in self._packed:
             self._keep.append((kernel, kernel_b))  # identities stay unique while cached
-            self._packed[key] = ops.pack_filters(kernel, "bf16x3", kernel_b)
+            self._packed[key] = ops.pack_filters(kernel, self.precision, kernel_b)
         return self._packed[key]
+
+    # ---- f16x2: running maxima of the activation buffers of one forward
+    def begin_forward(self):
+        self._amax.clear()
+
+    def _max_over_ranks(self, m):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if dist.get_backend(self.group) == "gloo" and m.is_cuda:
+                h = m.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                m.copy_(h)
+            else:
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        return m
+
+    def _amax_in(self, x):
+        """scalar of an input buffer: kept by its producers, or (the aggregation's output: zero outside the rows this
+        rank computed) one pass + the maximum over the ranks"""
+        if self.precision != "f16x2":
+            return None
+        key = x.untyped_storage().data_ptr()
+        if key not in self._amax:
+            from . import ops
+            self._amax[key] = self._max_over_ranks(ops.absmax(x))
+        return self._amax[key]
+
+    def _amax_out(self, out, fresh):
+        """scalar the convolution that writes `out` updates; fresh: `out` is a new buffer (an address can be re-used
+        within a forward), else a column slice of a concat buffer that another producer may have written already"""
+        if self.precision != "f16x2":
+            return None
+        key = out.untyped_storage().data_ptr()
+        if fresh or key not in self._amax:
+            self._amax[key] = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._amax[key]
 
     def _plan(self, K, csr, rows):
         from . import ops
@@ -496,14 +537,19 @@ class HipBackend:
     def sparse_conv(self, kernel, bias, x, csr, rows, v_out, imp=None, normalize=False, residual=None, out=None):
         from . import ops
         idx, kidx, rs = csr
+        fresh = out is None
         if out is None:  # only the owned rows are written; the others are never read before an exchange fills them
             out = torch.empty((v_out, kernel.shape[2]), dtype=torch.float32, device=self.device)
-        if self.precision == "bf16x3" and x.shape[1] % 4 == 0:
+        if self.precision != "f32" and x.shape[1] % 4 == 0:
             perm, plan = self._plan(kernel.shape[0], csr, rows)
-            return ops.sparse_conv16("bf16x3", self._pack(kernel), kernel.shape[0], kernel.shape[1], kernel.shape[2], x,
-                                     idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias, relu=True,
-                                     residual=residual, out=out, return_importance=imp is not None, row_perm=perm,
-                                     num_rows=rows.numel(), plan=plan)
+            m_in, m_out = self._amax_in(x), self._amax_out(out, fresh)
+            r = ops.sparse_conv16(self.precision, self._pack(kernel), kernel.shape[0], kernel.shape[1], kernel.shape[2], x,
+                                  idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias, relu=True,
+                                  residual=residual, out=out, return_importance=imp is not None, row_perm=perm,
+                                  num_rows=rows.numel(), plan=plan, inp_absmax=m_in, out_absmax=m_out)
+            if m_out is not None:
+                self._max_over_ranks(m_out)
+            return r
         return ops.sparse_conv(kernel, x, idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias,
                                relu=True, residual=residual, out=out, return_importance=imp is not None,
                                row_perm=self._rows32(rows), num_rows=rows.numel())
@@ -519,15 +565,19 @@ class HipBackend:
         from . import ops
         idx, kidx, rs = csr
         ca, cb = ka.shape[2], kb.shape[2]
+        fresh = out is None
         if out is None:
             out = torch.empty((v_out, ca + cb), dtype=torch.float32, device=self.device)
         fused = ca % 16 == 8 and cb == 8 and x.shape[1] % 4 == 0
-        if fused and self.precision == "bf16x3":
+        if fused and self.precision != "f32":
             perm, plan = self._plan(ka.shape[0], csr, rows)
-            _, oimp = ops.sparse_conv16("bf16x3", self._pack(ka, kb), ka.shape[0], ka.shape[1], ca, x, idx, kidx, rs,
+            m_in, m_out = self._amax_in(x), self._amax_out(out, fresh)
+            _, oimp = ops.sparse_conv16(self.precision, self._pack(ka, kb), ka.shape[0], ka.shape[1], ca, x, idx, kidx, rs,
                                         inp_importance=imp, normalize=True, bias=ba, relu=True, out=out,
                                         return_importance=True, row_perm=perm, num_rows=rows.numel(), cout_b=cb,
-                                        bias_b=bb, plan=plan)
+                                        bias_b=bb, plan=plan, inp_absmax=m_in, out_absmax=m_out)
+            if m_out is not None:
+                self._max_over_ranks(m_out)
             return out, oimp
         if fused:
             _, oimp = ops.sparse_conv(ka, x, idx, kidx, rs, inp_importance=imp, normalize=True, bias=ba, relu=True,
@@ -582,7 +632,7 @@ class ShardedImplicitPipeline:
         from .pipeline import ImplicitPipeline
         self.pipe = ImplicitPipeline(weights, device=device, point_radius_scale=point_radius_scale,
                                      octree_max_depth=octree_max_depth, scale_sdf=scale_sdf)
-        self.backend = HipBackend(self.pipe.device, precision)
+        self.backend = HipBackend(self.pipe.device, precision, group)
         # every rank runs the whole-cloud aggregation of the monolithic driver (search overlapped with the grid build,
         # Morton-ordered continuous conv): replicated work, but cheaper than a generic search of the owned rows plus
         # the importance prefix; whole_cloud_aggregation = False restores the owned-rows form

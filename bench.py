@@ -381,7 +381,7 @@ def run_one_scan(args, world, rank, dev, weights, n, barrier, synth, fused=0):
         pts, nrm = synth.scan_cloud(n, seed=rank_seed(0), device=dev, density_variance=args.density_variance)
     radii = synth.knn_radii_gpu(pts, 24)
     bb_min, bb_max = synth.bounding_box(pts, 0.1)
-    sharded = ShardedImplicitPipeline(weights, dev, precision="bf16x3" if args.precision == "bf16x3" else "f32")
+    sharded = ShardedImplicitPipeline(weights, dev, precision=args.precision if args.precision in SPLIT_PRODUCTS else "f32")
     for _ in range(args.warmup):
         sharded.forward(pts, nrm, radii, bb_min, bb_max)
     barrier()
@@ -423,11 +423,12 @@ def main():
                     help="also run the informational two- / three-context pipelined measurement (slower than the serial "
                          "step since round 2: the network leaves no room for a second stream)")
     ap.add_argument("--backend", default="nccl")
-    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2", "f16"], default=os.environ.get("ASR_BENCH_PRECISION", "bf16x3"),
-                    help="arithmetic of the 53 sparse convs: bf16x3 (default) = f32 in / f32 out, every operand split "
-                         "exactly into three bf16 terms, six bf16 MFMAs per product, f32 accumulate (fp32-class "
-                         "results, same parity bound as f32); f32 = f32-input MFMA, a bit-exact fmaf chain; "
-                         "f16 = f16 activations and weights (config C5)")
+    ap.add_argument("--precision", choices=["f32", "bf16x3", "f16x2", "f16"], default=os.environ.get("ASR_BENCH_PRECISION", "f16x2"),
+                    help="arithmetic of the 53 sparse convs: f16x2 (default) = f32 in / f32 out, every tensor scaled by a "
+                         "power of two and split into two f16 terms, three f16 MFMAs per product, f32 accumulate "
+                         "(fp32-class results, same parity bound as f32); bf16x3 = the same with an exact three-way "
+                         "bf16 split and six MFMAs; f32 = f32-input MFMA, a bit-exact fmaf chain; f16 = f16 "
+                         "activations and weights (config C5)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the informational runs of BASELINE configs C2 (1 M single-scale continuous conv) and C5 "
                          "(mixed density, f16 features)")

@@ -35,9 +35,9 @@ def test_struct_layouts_match_header_sizes():
     assert ctypes.sizeof(_lib.Weight) == 8 + 8 + 8 + 5 * 8
     assert ctypes.sizeof(_lib.ImplicitSizes) == 8 * (2 + 5 + 5 + 1)
     assert ctypes.sizeof(_lib.ImplicitParams) == 4 * (1 + 1 + 3 + 3 + 1 + 1)
-    assert ctypes.sizeof(_lib.SparseConvArgs) == 208
+    assert ctypes.sizeof(_lib.SparseConvArgs) == 224
     lib = _lib.load()
-    assert lib.asr_hip_struct_size(b"asr_sparse_conv_args") == 208
+    assert lib.asr_hip_struct_size(b"asr_sparse_conv_args") == 224
     assert lib.asr_hip_struct_size(b"nope") == 0
 
 

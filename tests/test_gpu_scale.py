@@ -105,13 +105,15 @@ def test_one_million_points_full_width_vs_oracle(gpu):
     from sconv_instances import BENCH_INSTANCES
     wide = {i for i in BENCH_INSTANCES if i[3] == 8}
     assert wide <= seen, (wide - seen, seen)
-    # the same bound for the bf16x3 arithmetic (six bf16 MFMAs per product, fp32-class result)
-    pipe3 = ImplicitPipeline(weights, device=gpu, precision="bf16x3")
-    values = pipe3.forward(pts, nrm, radii, bb[0], bb[1])
-    for k, got in (("code", pipe3.get("code")), ("values", values)):
-        err = float(np.abs(got.cpu().numpy().astype(np.float64) - ref[k]).max())
-        print("bf16x3 %s: GPU vs exact %.3e (bound %.3e)" % (k, err, tol[k]))
-        assert err <= tol[k], (k, err, tol[k])
+    # the same bound for the split arithmetics (six bf16 / three f16 MFMAs per product, fp32-class result)
+    for precision in ("bf16x3", "f16x2"):
+        pipe3 = ImplicitPipeline(weights, device=gpu, precision=precision)
+        values = pipe3.forward(pts, nrm, radii, bb[0], bb[1])
+        for k, got in (("code", pipe3.get("code")), ("values", values)):
+            err = float(np.abs(got.cpu().numpy().astype(np.float64) - ref[k]).max())
+            print("%s %s: GPU vs exact %.3e (bound %.3e)" % (precision, k, err, tol[k]))
+            assert err <= tol[k], (k, err, tol[k])
+        del pipe3
 
 
 def _close_or_cpu_class(got, exact, ref32, what):
@@ -131,18 +133,19 @@ def _close_or_cpu_class(got, exact, ref32, what):
 def test_ten_million_points_single_layers_vs_oracle(gpu):
     """C3 size: full-width layers of every grid level through the launcher's OWN tile choice at 10 M points, each
     compared with the oracle on the same CSR -- once on the exact f32 kernel (k_sconv_mfma) and once on the kernel
-    the default bench TIMES (k_sconv_plan16<bf16x3> with the row-group plan of the list).  The instances launched
-    must be exactly the ones named in the committed trace of the bench (tests/sconv_instances.py)."""
+    the default bench TIMES (k_sconv_plan16<f16x2> with the row-group plan of the list; and its six-product sibling
+    bf16x3).  The instances launched must be exactly the ones named in the committed trace of the bench
+    (tests/sconv_instances.py)."""
     from asr_hip import ops
     from asr_hip.pipeline import ImplicitPipeline
     from oracle import oracle as O
-    from sconv_instances import BENCH_INSTANCES, BENCH_INSTANCES16
+    from sconv_instances import BENCH_INSTANCES, bench_instances16
     pts, nrm, radii, bb = _prep(10_000_000, 1000, gpu)
     pipe = ImplicitPipeline(synth.make_weights(4, seed=2), device=gpu)
     pipe.build(pts, radii, bb[0], bb[1])
     ctx = ops.context(gpu)
     rng = np.random.default_rng(9)
-    seen, seen16 = set(), set()
+    seen, seen16 = set(), {"f16x2": set(), "bf16x3": set()}
     # (level, cin, cout_a, cout_b): encblock0.conv2, encblock0.conv1a+1b, decblock0.conv2, encblock1.conv2,
     # encblock2.conv1a+1b, decblock3.conv1, encblock3.conv1a+1b, encblock4.conv2, encblock4.conv1a+1b
     for level, cin, ca, cb in ((0, 64, 64, 0), (0, 32, 56, 8), (0, 32, 32, 0), (1, 128, 128, 0), (2, 256, 248, 8),
@@ -179,46 +182,49 @@ def test_ten_million_points_single_layers_vs_oracle(gpu):
         inst = set(ctx.sconv_variant_counts())
         assert len(inst) == 1 and inst <= BENCH_INSTANCES, inst
         seen |= inst
-        # the same layer on the timed kernel: bf16x3 arithmetic, plan-driven, the launcher's own tiles
-        ctx.sconv_variant_counts(reset=True)
-        packed = ops.pack_filters(d(W), "bf16x3", d(Wb) if cb else None)
-        if cb:
-            out16 = ops.sparse_conv16("bf16x3", packed, 55, cin, ca, d(f), idx, kidx, rs, inp_importance=d(imp),
-                                      normalize=True, bias=d(b), relu=True, row_perm=perm, cout_b=cb, bias_b=d(bb_),
-                                      plan=plan).cpu().numpy()
-            _close_or_cpu_class(out16[:, :ca], exact_a, ref_a, "level %d %d->%d+%d bank a" % (level, cin, ca, cb))
-            _close_or_cpu_class(out16[:, ca:], exact_b, ref_b, "level %d %d->%d+%d bank b" % (level, cin, ca, cb))
-        else:
-            out16 = ops.sparse_conv16("bf16x3", packed, 55, cin, ca, d(f), idx, kidx, rs, bias=d(b), relu=True,
-                                      row_perm=perm, plan=plan).cpu().numpy()
-            _close_or_cpu_class(out16, exact_a, ref_a, "level %d %d->%d" % (level, cin, ca))
-        inst16 = set(ctx.sconv_variant_counts())
-        assert len(inst16) == 1 and inst16 <= BENCH_INSTANCES16 and all(k[6] == 1 for k in inst16), inst16
-        seen16 |= inst16
+        # the same layer on the timed kernel: split arithmetic, plan-driven, the launcher's own tiles
+        for mode in ("f16x2", "bf16x3"):
+            ctx.sconv_variant_counts(reset=True)
+            packed = ops.pack_filters(d(W), mode, d(Wb) if cb else None)
+            what = "%s level %d %d->%d+%d" % (mode, level, cin, ca, cb)
+            if cb:
+                out16 = ops.sparse_conv16(mode, packed, 55, cin, ca, d(f), idx, kidx, rs, inp_importance=d(imp),
+                                          normalize=True, bias=d(b), relu=True, row_perm=perm, cout_b=cb, bias_b=d(bb_),
+                                          plan=plan).cpu().numpy()
+                _close_or_cpu_class(out16[:, :ca], exact_a, ref_a, what + " bank a")
+                _close_or_cpu_class(out16[:, ca:], exact_b, ref_b, what + " bank b")
+            else:
+                out16 = ops.sparse_conv16(mode, packed, 55, cin, ca, d(f), idx, kidx, rs, bias=d(b), relu=True,
+                                          row_perm=perm, plan=plan).cpu().numpy()
+                _close_or_cpu_class(out16, exact_a, ref_a, what)
+            inst16 = set(ctx.sconv_variant_counts())
+            assert len(inst16) == 1 and inst16 <= bench_instances16(mode), inst16
+            seen16[mode] |= inst16
         del plan
     assert len(seen) >= 6, seen
-    assert seen16 == BENCH_INSTANCES16, (BENCH_INSTANCES16 - seen16, seen16 - BENCH_INSTANCES16)
+    for mode, got in seen16.items():
+        assert got == bench_instances16(mode), (mode, bench_instances16(mode) - got, got - bench_instances16(mode))
 
 
-def test_ten_million_points_bf16x3_whole_path_equals_the_exact_f32_kernel(gpu):
+def test_ten_million_points_split_arithmetic_whole_path_equals_the_exact_f32_kernel(gpu):
     """C3 size, full-width network (the widths of the bench), variance-preserving weights: the implicit values of
-    the arithmetic the bench times (bf16x3) against the bit-exact f32-input MFMA kernel on the same cloud, bound
-    1e-5 of the range (north_star) -- measured 3e-6."""
+    the arithmetic the bench times (f16x2; and bf16x3) against the bit-exact f32-input MFMA kernel on the same cloud,
+    bound 1e-5 of the range (north_star) -- measured 3e-6 for bf16x3."""
     from asr_hip.pipeline import ImplicitPipeline
     pts, nrm, radii, bb = _prep(10_000_000, 1000, gpu)
     weights = synth.make_weights(1, seed=2)
     out = {}
-    for precision in ("f32", "bf16x3"):
+    for precision in ("f32", "bf16x3", "f16x2"):
         pipe = ImplicitPipeline(weights, device=gpu, precision=precision)
         pipe.ctx.sconv_variant_counts(reset=True)
         out[precision] = pipe.forward(pts, nrm, radii, bb[0], bb[1]).clone()
         out["code_" + precision] = pipe.get("code").clone()
         counts = pipe.ctx.sconv_variant_counts()
-        if precision == "bf16x3":
-            from sconv_instances import BENCH_INSTANCES16
-            assert sum(counts.values()) == 44 and set(counts) == BENCH_INSTANCES16, counts
+        if precision != "f32":
+            from sconv_instances import bench_instances16
+            assert sum(counts.values()) == 44 and set(counts) == bench_instances16(precision), counts
         del pipe
-    for a, b in (("f32", "bf16x3"), ("code_f32", "code_bf16x3")):
+    for a, b in (("f32", "bf16x3"), ("code_f32", "code_bf16x3"), ("f32", "f16x2"), ("code_f32", "code_f16x2")):
         scale = max(1.0, float(out[a].abs().max()))
         err = float((out[a].double() - out[b].double()).abs().max())
         print("%s vs %s: max deviation %.3e at a range of %.3g (%.2e of the range)" % (b, a, err, scale, err / scale))

@@ -56,10 +56,12 @@ def _worker(rank, world, port, n_points, channel_div, precision, out, fused=0, s
 
 
 @pytest.mark.parametrize("world,n_points,channel_div,precision",
-                         [(2, 30000, 2, "f32"), (3, 8000, 1, "f32"), (2, 30000, 1, "bf16x3"), (3, 8000, 2, "bf16x3")])
+                         [(2, 30000, 2, "f32"), (3, 8000, 1, "f32"), (2, 30000, 1, "bf16x3"), (3, 8000, 2, "bf16x3"),
+                          (2, 30000, 1, "f16x2"), (3, 8000, 2, "f16x2")])
 def test_sharded_values_equal_single_process(gpu, world, n_points, channel_div, precision):
-    """precision: the arithmetic of the 53 sparse convs on both sides (exact f32 MFMA / plan-driven bf16x3 kernel with a
-    plan per rank's row list): per row the same kernel arithmetic, so the stitched values are bit-identical either way"""
+    """precision: the arithmetic of the 53 sparse convs on both sides (exact f32 MFMA / plan-driven bf16x3 or f16x2 kernel
+    with a plan per rank's row list): per row the same kernel arithmetic, so the stitched values are bit-identical either
+    way (f16x2: the per-tensor scale comes from a MAX all-reduce of the ranks' running maxima = the monolithic one)"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
@@ -80,12 +82,12 @@ def test_sharded_values_equal_single_process(gpu, world, n_points, channel_div, 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_fused_multi_scan_cloud_equals_single_process(gpu, world):
     """BASELINE config C4 in small: eight disjoint scans fused into one cloud, cut into Morton ranges over `world`
-    processes (the cuts fall between and inside scans), bf16x3 arithmetic; the stitched values equal the monolithic
+    processes (the cuts fall between and inside scans), f16x2 arithmetic; the stitched values equal the monolithic
     driver's bit for bit"""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 64000, 2, "bf16x3", out, 8)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 64000, 2, "f16x2", out, 8)) for r in range(world)]
     for p in procs:
         p.start()
     infos = sorted([out.get(timeout=900) for _ in range(world)], key=lambda d: d["rank"])
@@ -99,7 +101,7 @@ def test_sharded_fused_multi_scan_cloud_equals_single_process(gpu, world):
     assert max(owned) < 1.5 * min(owned)  # equal pair counts per rank give similar row counts
 
 
-@pytest.mark.parametrize("world,fused,precision", [(2, 0, "bf16x3"), (3, 8, "bf16x3"), (3, 0, "f32")])
+@pytest.mark.parametrize("world,fused,precision", [(2, 0, "bf16x3"), (3, 8, "f16x2"), (3, 0, "f32")])
 def test_sharded_geometry_equals_single_process(gpu, world, fused, precision):
     """The geometry itself sharded (asr_hip.sharding.sharded_geometry): octree and voxel keys on every rank, 55-slot
     neighbour lists (asr_hip_grid_neighbors_rows_*), tiling orders, aggregation search and continuous conv only for the

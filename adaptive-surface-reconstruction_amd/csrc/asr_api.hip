@@ -7,6 +7,8 @@
 #include <cstring>
 
 #include <algorithm>
+#include <functional>
+#include <future>
 #include <mutex>
 #include <thread>
 
@@ -48,6 +50,7 @@ const OptEntry k_options[] = {
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
+        {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
 };
 
 // asr::GetPrintCallbackFunction (cpp/lib/asr.cpp:34-37): one callback per verbosity level, process wide
@@ -922,6 +925,48 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         // PRESORT_LEVEL): enqueued on the auxiliary stream now, it runs beside the octree construction.
         if (ctx->opt.early_sort) ASR_TRY(asr_geom_presort(sc, sc->persist, &ctx->frame, points, radii, n));
     }
+    // The search thread starts here: first the cell table of the sorted points (host round trips of its own, beside
+    // the octree construction on this thread), then it waits for the level-0 voxels.
+    std::promise<bool> level0_ready;
+    std::future<bool> level0_future = level0_ready.get_future();
+    struct Release {  // an early return of this function must not leave the thread waiting
+        std::promise<bool>& p;
+        bool done = false;
+        void set(bool v) {
+            if (!done) p.set_value(v);
+            done = true;
+        }
+        ~Release() { set(false); }
+    };
+    i64 agg_pairs = 0;
+    int search_rc = ASR_HIP_OK;
+    std::function<int()> search;  // defined below, once the names it uses exist
+    std::thread worker;
+    struct Joiner {  // the code below returns early on errors: never leave the thread running
+        std::thread& t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{worker};
+    Release release{level0_ready};  // (destroyed before the joiner: the thread is released, then joined)
+    if (overlap) {
+        worker = std::thread([&] {
+            if (hipSetDevice(ctx->device) != hipSuccess) {
+                sc->err = "hipSetDevice failed in the search thread";
+                search_rc = ASR_HIP_EHIP;
+                (void)level0_future.get();
+                return;
+            }
+            int rc = ASR_HIP_OK;
+            if (ctx->opt.early_sort && ctx->opt.early_cells && sc->pindex.valid) rc = asr_geom_precells(sc, sc->persist);
+            const bool go = level0_future.get();
+            if (rc != ASR_HIP_OK || !go) {
+                search_rc = rc;
+                return;
+            }
+            search_rc = search();
+        });
+    }
     ctx->pindex.valid = false;
     ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale, prm->octree_max_depth));
     ctx->sizes.num_nodes = ctx->num_nodes;
@@ -942,18 +987,11 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     }
 
     if (want_search) asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264 (here: concurrent with the grids)
-    if (overlap) {
-        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));  // the level-0 voxel centres / sizes are ready
-        ASR_HIP_CHECK(ctx, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
-    }
+    if (overlap) ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));  // the level-0 voxel centres / sizes are ready
     ctx->search_overlapped = overlap;
-    i64 agg_pairs = 0;
-    auto search = [&]() -> int {
+    search = [&]() -> int {
         if (sc != ctx) {
-            if (hipSetDevice(ctx->device) != hipSuccess) {
-                sc->err = "hipSetDevice failed in the search thread";
-                return ASR_HIP_EHIP;
-            }
+            ASR_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
         } else {
             ctx->scratch.reset();
         }
@@ -977,15 +1015,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         }
         return ASR_HIP_OK;
     };
-    int search_rc = ASR_HIP_OK;
-    std::thread worker;
-    if (overlap) worker = std::thread([&] { search_rc = search(); });
-    struct Joiner {  // the grid code below returns early on errors: never leave the thread running
-        std::thread& t;
-        ~Joiner() {
-            if (t.joinable()) t.join();
-        }
-    } joiner{worker};
+    release.set(true);  // the search thread goes on
 
     // grids (cpp/lib/grid.cpp:245-314); the MFMA tiling orders of all 13 CSRs are computed in one batch at the end
     std::vector<asr_row_group_job> rg_jobs;

@@ -109,6 +109,7 @@ struct AsrOptions {
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
     i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
+    i64 early_cells = 1;            // ... and its cell table, on the search thread
     i64 early_sort = 1;           // overlapped search: its point sort starts on the auxiliary stream beside the octree build
 };
 
@@ -149,6 +150,12 @@ struct AsrPointIndex {
     int32_t* rank = nullptr;     // Morton position per original index
     float* srad = nullptr;       // radii in Morton order
     u64* codes = nullptr;        // sorted level-21 codes
+    // cell table of the levels [tab_lmin, tab_lmax] built ahead of the query (asr_geom_precells), or tab_keys == nullptr
+    u64* tab_keys = nullptr;
+    u64 tab_mask = 0;
+    int32_t* tab_start = nullptr;
+    int32_t* tab_end = nullptr;
+    int tab_lmin = 0, tab_lmax = -1, tab_lhash = 0, tab_grow = 0;
 };
 
 struct asr_hip_context {
@@ -307,6 +314,8 @@ int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, con
 int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                           const float* radii, i64 n, float radius_scale, int max_depth, int grow_steps = 0,
                           const u64* extra_keys = nullptr, i64 num_extra = 0, bool balance = true);
+// cell table of ctx->pindex (after asr_geom_presort) for every level a leaf can have; blocks on ctx->stream
+int asr_geom_precells(asr_hip_context* ctx, Arena& keep);
 // Morton order of the points (+ radii) into ctx->pindex, arrays in `keep`
 int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* frame, const float* pts,
                      const float* radii, i64 n);

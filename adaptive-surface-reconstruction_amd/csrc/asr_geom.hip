@@ -214,6 +214,21 @@ __device__ inline void insert_with_ancestors(const HashTab& t, u64 a, int* cnt, 
     }
 }
 
+// cnt[13] = number of significant bits of the longest key in the node list (cnt[0] entries; the list is radix-sorted on
+// those bits only).  A pass of its own over the list: the same test inside the insertion kernels, next to their atomics
+// on cnt[0], made them 2.6x slower.
+__global__ void k_list_key_bits(const u64* list, int list_cap, int* cnt) {
+    const int n = min(cnt[0], list_cap);
+    int bits = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u64 k = list[i];
+        bits = max(bits, k ? 64 - __clzll((long long)k) : 0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits = max(bits, __shfl_xor(bits, o, 64));
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(&cnt[13], bits);
+}
+
 __global__ void k_octree_insert_points(asr_octree_frame f, const float* pts, const float* radii,
                                        i64 n, float radius_scale, int max_depth, HashTab t,
                                        int* cnt, u64* list, int list_cap) {
@@ -1943,6 +1958,8 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
                                                                                    list, lcap);
             ASR_CHECK_LAUNCH(ctx);
         }
+        k_list_key_bits<<<256, BLK, 0, ctx->stream>>>(list, lcap, ctx->d_flags);  // (balancing adds no longer keys)
+        ASR_CHECK_LAUNCH(ctx);
         ASR_TRY(read_flags(ctx, host));
         if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree: points / radii contain non-finite values");
         bool overflow = host[1] != 0 || (u64)host[0] * 2 > cap;
@@ -1977,7 +1994,8 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
         uint8_t* lflag = arena_alloc<uint8_t>(ctx->scratch, num_nodes);
         i64* d_num = arena_alloc<i64>(ctx->scratch, 1);
         if (!ctx->nodes || !leaves_tmp || !lflag || !d_num) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(sort_keys(ctx, ctx->scratch, list, ctx->nodes, num_nodes));
+        // (every node key is a prefix of an inserted key or a sibling / face neighbour of one: never longer)
+        ASR_TRY(sort_keys(ctx, ctx->scratch, list, ctx->nodes, num_nodes, host[13] > 0 && host[13] <= 64 ? host[13] : 64));
         k_leaf_flags<<<grid_for(num_nodes, BLK), BLK, 0, ctx->stream>>>(t, ctx->nodes, num_nodes, lflag);
         ASR_CHECK_LAUNCH(ctx);
         {
@@ -2392,7 +2410,8 @@ static int sort_points(asr_hip_context* ctx, const asr_octree_frame* frame, cons
     }
     return ASR_HIP_OK;
 }
-static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, RadiusState& st, bool hash_all);
+static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, RadiusState& st, bool hash_all,
+                            Arena* where = nullptr);
 static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                              i64 n, int lmin, int lmax, RadiusState& st, Arena* keep = nullptr,
                              bool want_rank = false, bool hash_all = true, const float* radii = nullptr) {
@@ -2400,7 +2419,8 @@ static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame
     ASR_TRY(sort_points(ctx, frame, pts, n, lmax, st, keep, want_rank, radii));
     return build_cell_table(ctx, n, lmin, lmax, st, hash_all);
 }
-static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, RadiusState& st, bool hash_all) {
+static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, RadiusState& st, bool hash_all, Arena* where) {
+    Arena& arena = where ? *where : ctx->scratch;
     int host[16];
     const u64* codes = st.codes;
     HashTab dummy{nullptr, nullptr, 0};
@@ -2430,9 +2450,9 @@ static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, Rad
     // cell_grow: enlarged after an overflow (keys whose low bits are concentrated on few values -- points on a
     // lattice -- crowd a few positions of the buckets, see TabProbe)
     u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * cells)) << st.cell_grow;
-    ASR_TRY(make_table(ctx, ctx->scratch, cap, false, st.tab));
-    st.start = arena_alloc<int32_t>(ctx->scratch, cap);
-    st.end = arena_alloc<int32_t>(ctx->scratch, cap);
+    ASR_TRY(make_table(ctx, arena, cap, false, st.tab));
+    st.start = arena_alloc<int32_t>(arena, cap);
+    st.end = arena_alloc<int32_t>(arena, cap);
     if (!st.start || !st.end) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     if (n > 0) {
         k_cell_bounds<false><<<grid_for(n + 1, BLK), BLK, 0, ctx->stream>>>(
@@ -2461,6 +2481,33 @@ int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* 
     pi.srad = st.srad;
     pi.codes = st.codes_w;
     pi.valid = true;
+    return ASR_HIP_OK;
+}
+
+// The aggregation search's cell table needs nothing from the octree either, only the range of levels its leaves can
+// have: [1, PRESORT_LEVEL] covers every octree whose leaves are not finer than the sort (a root-only octree or a deeper
+// one makes asr_geom_radius_count build its own table).  Host round trips: call it from the search's own thread.
+int asr_geom_precells(asr_hip_context* ctx, Arena& keep) {
+    AsrPointIndex& pi = ctx->pindex;
+    pi.tab_keys = nullptr;
+    if (!pi.valid || pi.n <= 0) return ASR_HIP_OK;
+    RadiusState st;
+    st.codes = st.codes_w = pi.codes;
+    st.n = pi.n;
+    st.cell_grow = rstate(ctx).cell_grow;
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(build_cell_table(ctx, pi.n, 1, pi.lsort, st, false, &keep));
+    int host[16];
+    ASR_TRY(read_flags(ctx, host));
+    if (host[1]) return ASR_HIP_OK;  // overflow: the query builds (and grows) its own table
+    pi.tab_grow = st.cell_grow;
+    pi.tab_keys = st.tab.keys;
+    pi.tab_mask = st.tab.mask;
+    pi.tab_start = st.start;
+    pi.tab_end = st.end;
+    pi.tab_lmin = 1;
+    pi.tab_lmax = pi.lsort;
+    pi.tab_lhash = st.lhash;
     return ASR_HIP_OK;
 }
 
@@ -2533,7 +2580,14 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         st.ids_u = nullptr;
         st.ids_w = pre->ids;
         ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
-        ASR_TRY(build_cell_table(ctx, n, lmin, std::max(lmax, ltab), st, false));
+        if (pre->tab_keys && pre->tab_grow == st.cell_grow && pre->tab_lmin <= lmin && pre->tab_lmax >= std::max(lmax, ltab)) {
+            st.tab = HashTab{pre->tab_keys, nullptr, pre->tab_mask};  // built beside the octree (asr_geom_precells)
+            st.start = pre->tab_start;
+            st.end = pre->tab_end;
+            st.lhash = pre->tab_lhash;
+        } else {
+            ASR_TRY(build_cell_table(ctx, n, lmin, std::max(lmax, ltab), st, false));
+        }
     } else {
         ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, std::max(lmax, ltab), st, keep, true, false, radii));
     }

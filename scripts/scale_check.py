@@ -1,5 +1,5 @@
-"""Large-cloud check: the bf16x3 path (plan-driven kernel, falling back to the table-driven one where a feature
-matrix exceeds the 4 GB buffer-addressing range) against the exact f32 kernel on the same cloud.
+"""Large-cloud check: the split-arithmetic paths (f16x2, bf16x3; (plan-driven kernel, falling back to the table-driven one where a feature
+matrix exceeds the 4 GB buffer-addressing range)) against the exact f32 kernel on the same cloud.
 usage: python scripts/scale_check.py [points]"""
 import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ print("knn %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
 bb = synth.bounding_box(pts, 0.1)
 w = synth.make_weights(1, seed=0)
 out = {}
-for prec in ("f32", "bf16x3"):
+for prec in ("f32", "bf16x3", "f16x2"):
     pipe = ImplicitPipeline(w, device=dev, precision=prec)
     pipe.ctx.sconv_variant_counts(reset=True)
     for i in range(2):
@@ -33,9 +33,11 @@ for prec in ("f32", "bf16x3"):
               sum(c for k, c in counts.items() if len(k) == 7 and k[6] == 0) // 2, flush=True)
     del pipe
     torch.cuda.empty_cache()
-a, b = out["f32"], out["bf16x3"]
-assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+a = out["f32"]
 scale = float(a.abs().max())
-err = float((a - b).abs().max())
-print("range %.3g, max |bf16x3 - f32| %.3e (%.2e of the range)" % (scale, err, err / scale))
+for prec in ("bf16x3", "f16x2"):
+    b = out[prec]
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    err = float((a - b).abs().max())
+    print("range %.3g, max |%s - f32| %.3e (%.2e of the range)" % (scale, prec, err, err / scale))
 assert err <= 3e-5 * max(scale, 1.0), err

@@ -168,9 +168,9 @@ def test_bf16x3_split_is_exact(gpu):
     assert np.array_equal(out.cpu().numpy().view(np.uint32), f.view(np.uint32))
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-5), ("f16", 5e-3)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-5), ("f16x2", 1e-5), ("f16", 5e-3)])
 def test_whole_path_precisions(gpu, precision, tol):
-    """asr_implicit_params.precision.  bf16x3: implicit values within 1e-5 of the range, like f32.
+    """asr_implicit_params.precision.  bf16x3 / f16x2: implicit values within 1e-5 of the range, like f32.
     f16 (config C5): f16 activations through 53 layers; bound 5e-3 of the range against the exact oracle
     (every layer rounds its output to 11 bits: 4.9e-4 per rounding; measured 1.9e-3), on the mixed-density
     cloud of that config."""
@@ -186,7 +186,7 @@ def test_whole_path_precisions(gpu, precision, tol):
     pipe.ctx.sconv_variant_counts(reset=True)
     values = pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
     counts = pipe.ctx.sconv_variant_counts()
-    assert sum(counts.values()) == 44 and all(len(k) == 7 and k[5] == (2 if precision == "bf16x3" else 1) and k[6] == 1 for k in counts)
+    assert sum(counts.values()) == 44 and all(len(k) == 7 and k[5] == {"f16": 1, "bf16x3": 2, "f16x2": 3}[precision] and k[6] == 1 for k in counts)
     assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), ref["voxel_keys0"])
     for name, got in (("code", pipe.get("code")), ("values", values)):
         scale = max(1.0, float(np.abs(ref[name]).max()))
@@ -198,7 +198,8 @@ def test_whole_path_precisions(gpu, precision, tol):
     assert torch.equal(values, v2)
 
 
-def test_conv_plan_reuse_and_row_lists(geo, gpu):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_conv_plan_reuse_and_row_lists(geo, gpu, mode):
     """One ConvPlan serves every convolution over its list (plain, two-bank, importance-weighted); a plan built
     for a row list (row_perm + num_rows) writes exactly those rows; per-pair importance ignores the plan."""
     from asr_hip import ops
@@ -217,25 +218,25 @@ def test_conv_plan_reuse_and_row_lists(geo, gpu):
     assert 0 < plan.nbytes() < 64 * idx.size + (1 << 21)  # about the size of the list, never 16x it
     ctx = ops.context(gpu)
     ctx.sconv_variant_counts(reset=True)
-    pa = ops.pack_filters(_t(Wa, gpu), "bf16x3")
-    pab = ops.pack_filters(_t(Wa, gpu), "bf16x3", _t(Wb, gpu))
+    pa = ops.pack_filters(_t(Wa, gpu), mode)
+    pab = ops.pack_filters(_t(Wa, gpu), mode, _t(Wb, gpu))
     with O.precise():
         ref_a = O.sparse_conv(Wa, f, idx, kidx, None, rs, False)
         ref_b = O.sparse_conv(Wb, f, idx, kidx, nimp, rs, True)
         ref_i = O.sparse_conv(Wa, f, idx, kidx, nimp, rs, True)
-    a = ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan)
+    a = ops.sparse_conv16(mode, pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan)
     _close(a.cpu().numpy(), ref_a)
-    ab, oi = ops.sparse_conv16("bf16x3", pab, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
+    ab, oi = ops.sparse_conv16(mode, pab, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
                                inp_importance=_t(imp, gpu), normalize=True, cout_b=cb, return_importance=True)
     _close(ab.cpu().numpy(), np.concatenate([ref_a, ref_b], 1))
     _close(oi.cpu().numpy(), O.reduce_subarrays_sum(nimp, rs))
-    ai = ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
+    ai = ops.sparse_conv16(mode, pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
                            inp_importance=_t(imp, gpu), normalize=True)
     _close(ai.cpu().numpy(), ref_i)
     assert all(k[6] == 1 for k in ctx.sconv_variant_counts())
     # per-pair importance: table-driven kernel, same numbers
     ctx.sconv_variant_counts(reset=True)
-    an = ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
+    an = ops.sparse_conv16(mode, pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
                            neighbors_importance=_t(nimp, gpu), normalize=True)
     _close(an.cpu().numpy(), ref_i)
     assert all(k[6] == 0 for k in ctx.sconv_variant_counts())
@@ -244,7 +245,7 @@ def test_conv_plan_reuse_and_row_lists(geo, gpu):
     n_rows = 1000
     lplan = ops.ConvPlan(K, d_idx, d_k, d_rs, row_perm=order, num_rows=n_rows)
     out = torch.full((v, ca), 7.0, dtype=torch.float32, device=gpu)
-    ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=order, num_rows=n_rows,
+    ops.sparse_conv16(mode, pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=order, num_rows=n_rows,
                       plan=lplan, out=out)
     rows = order[:n_rows].long().cpu().numpy()
     got = out.cpu().numpy()
@@ -253,10 +254,11 @@ def test_conv_plan_reuse_and_row_lists(geo, gpu):
     assert np.all(got[rest] == 7.0)
     # a plan of another list is refused
     with pytest.raises(Exception):
-        ops.sparse_conv16("bf16x3", pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=lplan)
+        ops.sparse_conv16(mode, pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=lplan)
 
 
-def test_feature_matrix_beyond_4gb(gpu):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_feature_matrix_beyond_4gb(gpu, mode):
     """Feature matrices of 4 GB and more are out of reach of buffer addressing: the launcher hands them to the
     table-driven kernel, which switches to 64-bit pointers.  9 M rows x 128 f32 (4.6 GB), neighbours spread over the
     whole matrix, against a float64 gather-and-contract on the GPU."""
@@ -273,7 +275,7 @@ def test_feature_matrix_beyond_4gb(gpu):
     ref = torch.einsum("pc,pco->po", f[idx].double(), W.double()[slots]).reshape(v, per_row, cout).sum(1)
     ctx = ops.context(gpu)
     ctx.sconv_variant_counts(reset=True)
-    out = ops.sparse_conv16("bf16x3", ops.pack_filters(W, "bf16x3"), K, cin, cout, f, idx.to(torch.int32),
+    out = ops.sparse_conv16(mode, ops.pack_filters(W, mode), K, cin, cout, f, idx.to(torch.int32),
                             slots.to(torch.uint8), rs)
     counts = ctx.sconv_variant_counts()
     assert len(counts) == 1 and list(counts)[0][6] == 0, counts  # table-driven kernel
@@ -281,7 +283,8 @@ def test_feature_matrix_beyond_4gb(gpu):
     assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
 
 
-def test_plan_kernel_equals_table_kernel_on_random_lists(gpu):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_plan_kernel_equals_table_kernel_on_random_lists(gpu, mode):
     """Random neighbour lists (empty rows, rows with every slot, shuffled entry order inside a row, row lists, padded
     strides): the plan-driven kernel and the table-driven one run the same products in the same slot order, so plain
     convolutions agree bit for bit; with importance the row sums are formed in a different order (1e-6)."""
@@ -308,13 +311,13 @@ def test_plan_kernel_equals_table_kernel_on_random_lists(gpu):
         perm = torch.randperm(v, generator=g).to(torch.int32).to(gpu) if case % 3 else None
         n_rows = max(1, v // 2) if (use_rows and perm is not None) else None
         kw = dict(inp_importance=imp, normalize=imp is not None, relu=True, row_perm=perm, num_rows=n_rows)
-        pk = ops.pack_filters(W, "bf16x3")
+        pk = ops.pack_filters(W, mode)
         outs = []
         for plan_on in (1, 0):
             ctx.set_option("sconv_plan", plan_on)
             ctx.sconv_variant_counts(reset=True)
             out = torch.full((v, cout), -3.0, device=gpu)
-            ops.sparse_conv16("bf16x3", pk, K, cin, cout, f, idx.to(torch.int32).to(gpu), slots.to(torch.uint8).to(gpu),
+            ops.sparse_conv16(mode, pk, K, cin, cout, f, idx.to(torch.int32).to(gpu), slots.to(torch.uint8).to(gpu),
                               rs.to(gpu), out=out, **kw)
             assert list(ctx.sconv_variant_counts())[0][6] == plan_on
             outs.append(out)

@@ -1094,6 +1094,31 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
                                     s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
 }
 
+// Cell ranges of the heavy rows, looked up ONCE per row (one wave each) and kept for the RADIUS_SPLIT x 4 waves of the
+// counting pass and of the filling pass, which used to repeat the 27 / 64 table look-ups each (2 x 2 x 10^8 probes at
+// 10 M points, three times the light rows' own)
+constexpr int HC_LD = 65;  // ints per row in hc_pref (prefix, NCELL + 1 used) and hc_beg (NCELL used)
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void k_radius_heavy_cells(asr_octree_frame f, const float* centers, const float* sizes,
+                                                            const int32_t* heavy, int nh, CellIndex ci, AlignedQ aq,
+                                                            int* hc_pref, int* hc_beg) {
+    constexpr int NCELL = ALIGNED ? 64 : 27;
+    __shared__ int s_pref[4][NCELL + 1];
+    __shared__ int s_beg[4][NCELL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= nh) return;
+    const i64 q = heavy[j];
+    if (ALIGNED)
+        aligned_cells(ci, aq, aq.keys[q], lane, s_pref[wave], s_beg[wave]);
+    else
+        radius_cells(f, ci, centers[3 * q], centers[3 * q + 1], centers[3 * q + 2], sizes[q], lane, s_pref[wave], s_beg[wave]);
+    __builtin_amdgcn_wave_barrier();
+    if (lane <= NCELL) hc_pref[(i64)j * HC_LD + lane] = s_pref[wave][lane];
+    if (NCELL == 64 && lane == 0) hc_pref[(i64)j * HC_LD + 64] = s_pref[wave][64];
+    if (lane < NCELL) hc_beg[(i64)j * HC_LD + lane] = s_beg[wave][lane];
+}
+
 // Heavy rows: RADIUS_SPLIT blocks per row, each block walks 1/RADIUS_SPLIT of the candidates.
 // FILL = false: accumulates the hit count into counts[q]; FILL = true: writes the (distance, index)
 // keys at hoff[j] + cursor (any order: the rows are sorted by a segmented sort afterwards).
@@ -1101,22 +1126,26 @@ template <bool FILL, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const float4* sorted, const float* centers,
                                                       const float* sizes, const int32_t* heavy, CellIndex ci, AlignedQ aq,
                                                       i64* counts, const i64* hoff, int* cursor, u64* keys_out,
-                                                      int32_t* row_out) {
+                                                      int32_t* row_out, const int* hc_pref, const int* hc_beg) {
     constexpr int NCELL = ALIGNED ? 64 : 27;
     __shared__ int s_pref[4][NCELL + 1];
     __shared__ int s_beg[4][NCELL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x;
-    const i64 q = heavy[j];
-    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
-    const float r = sizes[q];
-    const float r2 = r * r;
-    const int total = ALIGNED ? aligned_cells(ci, aq, aq.keys[q], lane, s_pref[wave], s_beg[wave])
-                              : radius_cells(f, ci, cx, cy, cz, r, lane, s_pref[wave], s_beg[wave]);
+    const int total = hc_pref[(i64)j * HC_LD + NCELL];  // (k_radius_heavy_cells)
     int per = (total + RADIUS_SPLIT - 1) / RADIUS_SPLIT;
     per = (per + 255) & ~255;  // whole 4-wave rounds
     const int lo = blockIdx.y * per;
     const int hi = min(total, lo + per);
+    if (lo >= total && !(ALIGNED && blockIdx.y == 0)) return;  // (block 0 also walks the pairs of the rounding margin)
+    const i64 q = heavy[j];
+    const float cx = centers[3 * q], cy = centers[3 * q + 1], cz = centers[3 * q + 2];
+    const float r = sizes[q];
+    const float r2 = r * r;
+    if (lane <= NCELL) s_pref[wave][lane] = hc_pref[(i64)j * HC_LD + lane];
+    if (NCELL == 64 && lane == 0) s_pref[wave][64] = total;
+    if (lane < NCELL) s_beg[wave][lane] = hc_beg[(i64)j * HC_LD + lane];
+    __builtin_amdgcn_wave_barrier();
     unsigned long long found = 0;
     auto consume = [&](bool hit, float d, int id) {
         const unsigned long long m = __ballot(hit);
@@ -2352,6 +2381,8 @@ struct RadiusState {
     int32_t* heavy = nullptr;  // rows with more than RADIUS_LIGHT hits or RADIUS_GIANT candidates
     uint8_t* is_heavy = nullptr;
     i64 num_heavy = 0;
+    int* hc_pref = nullptr;    // cell ranges of the heavy rows (k_radius_heavy_cells)
+    int* hc_beg = nullptr;
     const u64* dual_leaves = nullptr;  // leaf array of the pending dual-cell count / fill pair
     i64 dual_nl = 0;
     float* srad = nullptr;     // radii in Morton order (when the count call was given them)
@@ -2625,12 +2656,23 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
     ctx->search_extras = host[15];
     st.num_heavy = host[10];
     if (st.num_heavy > 0) {
-        if (st.aligned)
+        st.hc_pref = arena_alloc<int>(ctx->scratch, (size_t)st.num_heavy * HC_LD);
+        st.hc_beg = arena_alloc<int>(ctx->scratch, (size_t)st.num_heavy * HC_LD);
+        if (!st.hc_pref || !st.hc_beg) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        const unsigned cgrid = grid_for(st.num_heavy, 4);
+        if (st.aligned) {
+            k_radius_heavy_cells<true><<<cgrid, BLK, 0, ctx->stream>>>(*frame, centers, sizes, st.heavy, (int)st.num_heavy,
+                                                                       st.index(), st.aq, st.hc_pref, st.hc_beg);
             k_radius_heavy<false, true><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                    *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr);
-        else
+                    *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr,
+                    st.hc_pref, st.hc_beg);
+        } else {
+            k_radius_heavy_cells<false><<<cgrid, BLK, 0, ctx->stream>>>(*frame, centers, sizes, st.heavy, (int)st.num_heavy,
+                                                                        st.index(), st.aq, st.hc_pref, st.hc_beg);
             k_radius_heavy<false, false><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                    *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr);
+                    *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr,
+                    st.hc_pref, st.hc_beg);
+        }
         ASR_CHECK_LAUNCH(ctx);
     }
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
@@ -2792,10 +2834,12 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         ASR_HIP_CHECK(ctx, hipMemsetAsync(cursor, 0, (size_t)nh * sizeof(int), ctx->stream));
         if (st.aligned)
             k_radius_heavy<true, true><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                    st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row);
+                    st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row,
+                    st.hc_pref, st.hc_beg);
         else
             k_radius_heavy<true, false><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
-                    st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row);
+                    st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row,
+                    st.hc_pref, st.hc_beg);
         ASR_CHECK_LAUNCH(ctx);
         // order by (row, squared distance, index) with two stable radix sorts: by the 64-bit key, then
         // by the row (a segmented sort spends 1.6 ms on the few 10^4-entry rows)

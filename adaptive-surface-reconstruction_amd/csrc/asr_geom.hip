@@ -1736,7 +1736,8 @@ __device__ inline int rg_job_of(const RowGroupBatch& b, i64 e) {
     while (j + 1 < b.n && e >= b.base[j + 1]) ++j;
     return j;
 }
-__global__ void k_rg_keys(RowGroupBatch b, i64 seg, u64* keys, u64* masks, int32_t* ids) {
+// key = (job, segment, slot mask without slot 0) in 4 + 6 + mask_bits bits
+__global__ void k_rg_keys(RowGroupBatch b, i64 seg, u64* keys, u64* masks, int32_t* ids, int mask_bits) {
     const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (e >= b.base[b.n]) return;
     const int j = rg_job_of(b, e);
@@ -1746,9 +1747,9 @@ __global__ void k_rg_keys(RowGroupBatch b, i64 seg, u64* keys, u64* masks, int32
         const i64* rs = b.rs[j];
         const uint8_t* kidx = b.kidx[j];
         for (i64 p = rs[r]; p < rs[r + 1]; ++p) m |= u64(1) << (kidx[p] & 63);
-        key = ((u64)j << 60) | ((u64)(r / seg) << 54) | ((m >> 1) & ((u64(1) << 54) - 1));
+        key = ((u64)j << (6 + mask_bits)) | ((u64)(r / seg) << mask_bits) | ((m >> 1) & ((u64(1) << mask_bits) - 1));
     } else {
-        key = ((u64)j << 60) | (u64(63) << 54) | ((u64(1) << 54) - 1);  // padding: last inside the job
+        key = ((u64)j << (6 + mask_bits)) | (u64(63) << mask_bits) | ((u64(1) << mask_bits) - 1);  // padding: last inside the job
     }
     keys[e] = key;
     masks[e] = m;
@@ -2214,6 +2215,7 @@ int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs
 
 // all CSRs of one hierarchy in one pass (see k_rg_keys); falls back to the per-CSR routine for shapes the
 // packed key cannot hold
+static int rg_batch_run(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg, int mask_bits);
 int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg) {
     if (seg < 128) seg = 128;
     bool fits = n <= RG_MAX_JOBS && seg % 128 == 0;
@@ -2223,6 +2225,15 @@ int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* job
             ASR_TRY(asr_geom_row_groups(ctx, jobs[j].kidx, jobs[j].rs, jobs[j].v, seg, jobs[j].perm_out, jobs[j].kbits));
         return ASR_HIP_OK;
     }
+    // The radix sort of the keys is what this routine costs.  Lists with few slots (the 9-slot up / down lists: more than
+    // half of all rows of a hierarchy) go through it with 19-bit keys, three digit passes instead of eight.
+    std::vector<asr_row_group_job> small_jobs, wide_jobs;
+    for (int j = 0; j < n; ++j) (jobs[j].kbits <= 10 ? small_jobs : wide_jobs).push_back(jobs[j]);
+    if (!small_jobs.empty()) ASR_TRY(rg_batch_run(ctx, small_jobs.data(), (int)small_jobs.size(), seg, 9));
+    if (!wide_jobs.empty()) ASR_TRY(rg_batch_run(ctx, wide_jobs.data(), (int)wide_jobs.size(), seg, 54));
+    return ASR_HIP_OK;
+}
+static int rg_batch_run(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg, int mask_bits) {
     RowGroupBatch b;
     b.n = 0;
     i64 total = 0;
@@ -2251,9 +2262,9 @@ int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* job
     int32_t* cid_s = arena_alloc<int32_t>(ctx->scratch, nc);
     if (!keys || !keys_s || !masks || !ids || !ids_s || !ckey || !ckey_s || !cid || !cid_s)
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    k_rg_keys<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, seg, keys, masks, ids);
+    k_rg_keys<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, seg, keys, masks, ids, mask_bits);
     ASR_CHECK_LAUNCH(ctx);
-    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, keys, keys_s, ids, ids_s, total, 64)));
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, keys, keys_s, ids, ids_s, total, 4 + 6 + mask_bits)));
     const int lpt = ctx->opt.row_lpt != 0;
     if (lpt) {
         k_rg_chunk_keys<<<grid_for(nc * 64, BLK), BLK, 0, ctx->stream>>>(b, seg, ids_s, masks, ckey, cid);

@@ -478,9 +478,10 @@ class HipBackend:
         from . import ops
         self._plans.clear()
         self._rows32_cache.clear()
-        ctx = ops.context(self.device)
-        ctx.set_option("plan_arena", 1)
-        ctx.call("asr_hip_context_plan_arena_reset")
+        # Recycles every arena plan of this device's context (the library refuses such a plan afterwards: a second
+        # backend on the same device that still holds plans gets an error, not recycled memory).  The option that
+        # sends new plans to the arena is set only around this backend's own plan construction (_plan).
+        ops.context(self.device).call("asr_hip_context_plan_arena_reset")
 
     def _pack(self, kernel, kernel_b=None):
         from . import ops
@@ -531,7 +532,13 @@ class HipBackend:
         key = (rs.data_ptr(), rows.data_ptr(), int(rows.numel()))
         if key not in self._plans:
             perm = rows.to(torch.int32).contiguous()
-            self._plans[key] = (perm, ops.ConvPlan(K, idx, kidx, rs, row_perm=perm, num_rows=rows.numel()), rows)
+            ctx = ops.context(self.device)
+            ctx.set_option("plan_arena", 1)  # this plan only: other users of the context keep plans of their own
+            try:
+                plan = ops.ConvPlan(K, idx, kidx, rs, row_perm=perm, num_rows=rows.numel())
+            finally:
+                ctx.set_option("plan_arena", 0)
+            self._plans[key] = (perm, plan, rows)
         return self._plans[key][:2]
 
     def sparse_conv(self, kernel, bias, x, csr, rows, v_out, imp=None, normalize=False, residual=None, out=None):

@@ -497,6 +497,10 @@ static int check_conv16_args(asr_hip_context* ctx, const asr_sparse_conv_args* a
 struct asr_hip_conv_plan {
     Arena mem;  // empty when the plan lives in the context's plan arena
     asr_conv_plan p;
+    // plans from the context arena die with asr_hip_context_plan_arena_reset: they remember the arena generation they
+    // were taken from and the 16-bit entry points refuse them afterwards (instead of convolving with recycled memory)
+    const asr_hip_context* arena_ctx = nullptr;
+    uint64_t arena_epoch = 0;
 };
 int asr_hip_sparse_conv_plan_create(asr_hip_context* ctx, const int32_t* nidx, const uint8_t* kidx, const int64_t* rs,
                                     const int32_t* row_perm, int64_t num_out, int kernel_size,
@@ -510,6 +514,10 @@ int asr_hip_sparse_conv_plan_create(asr_hip_context* ctx, const int32_t* nidx, c
     pl->mem.min_slab = size_t(1) << 20;
     ctx->scratch.reset();
     Arena& where = ctx->opt.plan_arena ? ctx->plan_arena : pl->mem;
+    if (ctx->opt.plan_arena) {
+        pl->arena_ctx = ctx;
+        pl->arena_epoch = ctx->plan_arena_epoch;
+    }
     const int rc = asr_geom_conv_plan_build(ctx, where, nidx, kidx, rs, row_perm, num_out, kernel_size, &pl->p);
     if (rc != ASR_HIP_OK) {
         pl->mem.release();
@@ -528,12 +536,17 @@ size_t asr_hip_sparse_conv_plan_bytes(const asr_hip_conv_plan* plan) { return pl
 int asr_hip_context_plan_arena_reset(asr_hip_context* ctx) {
     CTX_GUARD(ctx);
     ctx->plan_arena.reset();
+    ++ctx->plan_arena_epoch;
     return ASR_HIP_OK;
 }
 
 // 16-bit entry points: the caller's plan, or a temporary one in the scratch arena
 static int conv16_entry(asr_hip_context* ctx, const asr_sparse_conv_args* a, const void* packed, int mode, int out_f16) {
     ASR_TRY(check_conv16_args(ctx, a, packed));
+    if (a->plan && a->plan->arena_ctx && (a->plan->arena_ctx != ctx || a->plan->arena_epoch != ctx->plan_arena_epoch))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL,
+                 "sparse_conv16: stale plan -- it was taken from a context plan arena that has been reset since "
+                 "(asr_hip_context_plan_arena_reset) or belongs to another context");
     if (a->plan) return asr_conv_sparse16(ctx, a, packed, mode, out_f16, &a->plan->p);
     asr_conv_plan tmp;
     const bool want = ctx->opt.sconv_plan && !a->neighbors_importance && a->num_out > 0 && a->algo != 1;

@@ -169,6 +169,7 @@ struct asr_hip_context {
     Arena persist;  // results that outlive a call (octree, grids, values)
     Arena scratch;  // temporaries
     Arena plan_arena;  // row-group plans created with option "plan_arena" (asr_hip_context_plan_arena_reset)
+    uint64_t plan_arena_epoch = 0;  // generation of plan_arena: plans of an earlier generation are refused
     // last octree
     u64* nodes = nullptr;
     u64* leaves = nullptr;

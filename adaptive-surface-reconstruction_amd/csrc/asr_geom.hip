@@ -2068,6 +2068,20 @@ static int build_key_map(asr_hip_context* ctx, const u64* keys, i64 v, HashTab& 
     return ASR_HIP_OK;
 }
 
+// The same for the stand-alone operators: the overflow flag is read back (one synchronisation) and a map that lost keys
+// -- lattice-like key sets fill "their" positions of the 64-slot buckets early -- is rebuilt four times the size, so that
+// every entry point either sees all keys or fails; none drops neighbours silently.
+static int build_key_map_complete(asr_hip_context* ctx, const u64* keys, i64 v, HashTab& t) {
+    for (int grow = 0;; grow += 2) {
+        ASR_TRY(build_key_map(ctx, keys, v, t, grow));
+        int host[16];
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(host, ctx->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!host[1]) return ASR_HIP_OK;
+        if (grow >= 6) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "voxel key map overflow");
+    }
+}
+
 int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* rs, i64* num_pairs) {
     if (v <= 0) {
         *num_pairs = 0;
@@ -2075,7 +2089,7 @@ int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* 
         return ASR_HIP_OK;
     }
     HashTab t;
-    ASR_TRY(build_key_map(ctx, keys, v, t));
+    ASR_TRY(build_key_map_complete(ctx, keys, v, t));
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     k_neighbors_count<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, t, counts, nullptr, nullptr, nullptr);
@@ -2088,7 +2102,7 @@ int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const 
                             int32_t* idx, uint8_t* kidx) {
     if (v <= 0) return ASR_HIP_OK;
     HashTab t;
-    ASR_TRY(build_key_map(ctx, keys, v, t));
+    ASR_TRY(build_key_map_complete(ctx, keys, v, t));
     k_neighbors_fill<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, rs, nullptr, nullptr, nullptr, idx, kidx);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
@@ -2101,7 +2115,7 @@ int asr_geom_neighbors_rows_count(asr_hip_context* ctx, const u64* keys, i64 v, 
         return ASR_HIP_OK;
     }
     HashTab t;
-    ASR_TRY(build_key_map(ctx, keys, v, t));
+    ASR_TRY(build_key_map_complete(ctx, keys, v, t));
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, (v + 1) * sizeof(i64), ctx->stream));
@@ -2110,17 +2124,14 @@ int asr_geom_neighbors_rows_count(asr_hip_context* ctx, const u64* keys, i64 v, 
         ASR_CHECK_LAUNCH(ctx);
     }
     ASR_TRY(scan_counts(ctx, ctx->scratch, counts, rs, v + 1));
-    int host[16];
-    ASR_HIP_CHECK(ctx, hipMemcpyAsync(host, ctx->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     ASR_TRY(read_i64(ctx, rs + v, num_pairs));
-    if (host[1]) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "voxel key map overflow");
     return ASR_HIP_OK;
 }
 int asr_geom_neighbors_rows_fill(asr_hip_context* ctx, const u64* keys, i64 v, const int32_t* rows, i64 nrows,
                                  const i64* rs, int32_t* idx, uint8_t* kidx) {
     if (v <= 0 || nrows <= 0) return ASR_HIP_OK;
     HashTab t;
-    ASR_TRY(build_key_map(ctx, keys, v, t));
+    ASR_TRY(build_key_map_complete(ctx, keys, v, t));
     k_neighbors_fill_rows<<<grid_for(nrows, BLK), BLK, 0, ctx->stream>>>(keys, t, rows, nrows, rs, idx, kidx);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;

@@ -47,6 +47,16 @@ def assert_close_scaled(a, b, tol=1e-5):
     assert np.all(err <= tol * scale), "max err %.3e (ref max %.3e)" % (err.max() if err.size else 0.0, scale)
 
 
+def pass_fraction(a, b, atol=1e-5, rtol=1e-5):
+    """share of the elements that meet the north_star tolerance |a - b| <= 1e-5 + 1e-5 |b| one by one; printed by
+    the whole-path tests whose assertion is range-scaled (assert_close_scaled), so that the claim is visible"""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if not b.size:
+        return 1.0
+    return float(np.mean(np.abs(a - b) <= atol + rtol * np.abs(b)))
+
+
 def oracle_geometry(points, radii, bb_min, bb_max, radius_scale=1.0, max_depth=21, timings=None):
     """input_dict of cpp/lib/asr.cpp:143-312"""
     o = O.Oracle()

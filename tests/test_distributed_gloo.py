@@ -87,6 +87,11 @@ def test_conv_flop_model_matches_survey():
     flops, launches = bench.conv_flops(S, synth.unet5_param_shapes(1))
     assert launches == 44  # 53 convs; conv1a + conv1b of the 9 blocks share a launch
     assert abs(flops / 1e9 - 926) < 1.0
+    # bytes of the same sheet: 14 234 MB gathered + 1 959 MB written + 371.5 MB of filters (fp32, no reuse); compulsory
+    # = every input row once instead of once per pair
+    alg, comp = bench.conv_bytes(S, synth.unet5_param_shapes(1))
+    assert abs(alg / 1e6 - 16564.5) < 0.01 * 16564.5, alg
+    assert comp < 0.35 * alg and comp > 1959e6 + 371.5e6
 
 
 # ---- one scan across ranks: partition + halo exchange ----------------------------------

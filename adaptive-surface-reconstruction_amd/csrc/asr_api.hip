@@ -49,6 +49,9 @@ const OptEntry k_options[] = {
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
+        {"search_quad", "ASR_SEARCH_QUAD", &AsrOptions::search_quad},
+        {"search_quad_stop", "ASR_SEARCH_QUAD_STOP", &AsrOptions::search_quad_stop},
+        {"search_xcd_run", "ASR_SEARCH_XCD_RUN", &AsrOptions::search_xcd_run},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
 };
@@ -1030,40 +1033,56 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     };
     release.set(true);  // the search thread goes on
 
-    // grids (cpp/lib/grid.cpp:245-314); the MFMA tiling orders of all 13 CSRs are computed in one batch at the end
+    // grids (cpp/lib/grid.cpp:245-314).  First the key sets of the coarser grids with their up / down lists (a chain of
+    // four small coarsening steps), then the 55-slot neighbour lists of ALL five grids in one batch
+    // (asr_geom_neighbors_build_batch: one key-map launch, one counting pass, one scan, one read-back, one filling pass
+    // -- the coarse grids used to pay a level-0 kernel's latency each, five times over); the MFMA tiling orders of all
+    // 13 CSRs are computed in one batch at the end.
     std::vector<asr_row_group_job> rg_jobs;
+    for (int i = 1; i < ASR_NUM_GRIDS; ++i) {
+        GridDev& g = ctx->grids[i];
+        g = GridDev();
+        ctx->scratch.reset();
+        GridDev& prev = ctx->grids[i - 1];
+        // CombineSiblings + neighbors_down = invert(up lists) (net_definitions_torch.py:548-559) in one go
+        // (the keys of every grid are location codes of at most the deepest leaf's level: the sort skips the rest)
+        ASR_TRY(asr_geom_coarsen_build(ctx, ctx->persist, prev.keys, prev.v, &g.keys, &g.v, &prev.up_idx,
+                                       &prev.up_kidx, &prev.up_rs, &prev.down_idx, &prev.down_kidx, &prev.down_rs,
+                                       ctx->leaf_lmax >= 0 ? 3 * ctx->leaf_lmax + 1 : 64));
+        prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
+        prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
+        if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        rg_jobs.push_back({prev.up_kidx, prev.up_rs, prev.v, 9, prev.perm_up});
+        rg_jobs.push_back({prev.down_kidx, prev.down_rs, g.v, 9, prev.perm_down});
+        std::string s = std::to_string(i - 1);
+        name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
+        name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
+        name_it(ctx, "up_neighbors_row_splits" + s, prev.up_rs, 8 * (prev.v + 1));
+        name_it(ctx, "down_neighbors_index" + s, prev.down_idx, 4 * prev.v);
+        name_it(ctx, "down_neighbors_kernel_index" + s, prev.down_kidx, prev.v);
+        name_it(ctx, "down_neighbors_row_splits" + s, prev.down_rs, 8 * (g.v + 1));
+        name_it(ctx, "tiling_up" + s, prev.perm_up, 4 * prev.v);
+        name_it(ctx, "tiling_down" + s, prev.perm_down, 4 * g.v);
+        g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
+        g.sizes = arena_alloc<float>(ctx->persist, g.v);
+        if (!g.centers || !g.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
+    }
+    {
+        ctx->scratch.reset();
+        asr_nb_job nb[ASR_NUM_GRIDS];
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) nb[i] = asr_nb_job{ctx->grids[i].keys, ctx->grids[i].v, nullptr, nullptr, nullptr, 0};
+        ASR_TRY(asr_geom_neighbors_build_batch(ctx, ctx->persist, nb, ASR_NUM_GRIDS));
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+            GridDev& g = ctx->grids[i];
+            g.nrs = nb[i].rs;
+            g.nidx = nb[i].idx;
+            g.nkidx = nb[i].kidx;
+            g.p = nb[i].p;
+        }
+    }
     for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
         GridDev& g = ctx->grids[i];
-        if (i > 0) g = GridDev();
-        ctx->scratch.reset();
-        if (i > 0) {
-            GridDev& prev = ctx->grids[i - 1];
-            // CombineSiblings + neighbors_down = invert(up lists) (net_definitions_torch.py:548-559) in one go
-            ASR_TRY(asr_geom_coarsen_build(ctx, ctx->persist, prev.keys, prev.v, &g.keys, &g.v, &prev.up_idx,
-                                           &prev.up_kidx, &prev.up_rs, &prev.down_idx, &prev.down_kidx, &prev.down_rs));
-            prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
-            prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
-            if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            rg_jobs.push_back({prev.up_kidx, prev.up_rs, prev.v, 9, prev.perm_up});
-            rg_jobs.push_back({prev.down_kidx, prev.down_rs, g.v, 9, prev.perm_down});
-            std::string s = std::to_string(i - 1);
-            name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
-            name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
-            name_it(ctx, "up_neighbors_row_splits" + s, prev.up_rs, 8 * (prev.v + 1));
-            name_it(ctx, "down_neighbors_index" + s, prev.down_idx, 4 * prev.v);
-            name_it(ctx, "down_neighbors_kernel_index" + s, prev.down_kidx, prev.v);
-            name_it(ctx, "down_neighbors_row_splits" + s, prev.down_rs, 8 * (g.v + 1));
-            name_it(ctx, "tiling_up" + s, prev.perm_up, 4 * prev.v);
-            name_it(ctx, "tiling_down" + s, prev.perm_down, 4 * g.v);
-        }
-        if (i > 0) {
-            g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
-            g.sizes = arena_alloc<float>(ctx->persist, g.v);
-            if (!g.centers || !g.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
-        }
-        ASR_TRY(asr_geom_neighbors_build(ctx, ctx->persist, g.keys, g.v, &g.nrs, &g.nidx, &g.nkidx,
-                                         &g.p));
         g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
         if (!g.perm_nb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         rg_jobs.push_back({g.nkidx, g.nrs, g.v, 55, g.perm_nb});

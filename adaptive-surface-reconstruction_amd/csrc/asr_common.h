@@ -108,6 +108,9 @@ struct AsrOptions {
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
+    i64 search_quad = 1;          // aggregation search: four voxels per wave (k_radius_quad); 0: one wave per voxel
+    i64 search_xcd_run = 64;      // k_radius_quad: consecutive blocks (16 voxels each) per XCD run (xcd_block); 0 = natural order
+    i64 search_quad_stop = 0;     // ablation of k_radius_quad (results invalid): 1 = look-ups only, 2 = + candidate walk
     i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
     i64 early_cells = 1;            // ... and its cell table, on the search thread
     i64 early_sort = 1;           // overlapped search: its point sort starts on the auxiliary stream beside the octree build
@@ -329,6 +332,17 @@ int asr_geom_neighbors_rows_fill(asr_hip_context* ctx, const u64* keys, i64 v, c
                                  const i64* rs, int32_t* idx, uint8_t* kidx);
 int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* keys, i64 v,
                              i64** rs_out, int32_t** idx_out, uint8_t** kidx_out, i64* num_pairs);
+// the neighbour lists of all grids of a hierarchy in ONE pass: one launch each for the key maps, the counting pass and
+// the filling pass, one scan, one read-back of the pair counts (round 4; was five times count / scan / read-back / fill)
+struct asr_nb_job {
+    const u64* keys;  // in: sorted voxel keys
+    i64 v;
+    i64* rs;          // out (arrays in out_arena)
+    int32_t* idx;
+    uint8_t* kidx;
+    i64 p;
+};
+int asr_geom_neighbors_build_batch(asr_hip_context* ctx, Arena& out_arena, asr_nb_job* jobs, int n);
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
                         int32_t* perm_out, int kbits);
 struct asr_row_group_job {
@@ -346,7 +360,7 @@ int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out
                           uint8_t* down_kidx = nullptr, i64* down_rs = nullptr);
 int asr_geom_coarsen_build(asr_hip_context* ctx, Arena& keep, const u64* keys, i64 v, u64** out_keys, i64* v_out,
                            int32_t** up_idx, uint8_t** up_kidx, i64** up_rs, int32_t** down_idx, uint8_t** down_kidx,
-                           i64** down_rs);
+                           i64** down_rs, int key_bits = 64);  // key_bits: significant bits of the largest key
 int asr_geom_voxel_info(asr_hip_context* ctx, const asr_octree_frame* frame, const u64* keys,
                         i64 v, float* centers, float* sizes);
 // keep: arena for the Morton-ordered point arrays (scratch when null); fill: spos (optional) receives

@@ -19,6 +19,21 @@ using namespace asr_prim;
 
 constexpr int BLK = 256;
 
+// XCD-aware work order.  Workgroups are dealt round-robin to the eight XCDs, each with its own 4 MB L2: with the natural
+// order, spatial neighbours (consecutive rows of a sorted key list) land on eight different L2s and every line they
+// share is fetched eight times -- and evicted before the XCD's next visit to the neighbourhood.  xcd_block() hands each
+// XCD whole runs of `run` consecutive logical blocks (XCD x works through runs x, x + 8, x + 16, ...), so that the reuse
+// between neighbouring rows happens inside one L2 while all XCDs still advance through the list at the same pace.
+// Launch xcd_grid(blocks, run) workgroups and drop logical ids >= blocks.
+__device__ inline i64 xcd_block(i64 b, int run) {
+    const i64 x = b & 7, j = b >> 3;
+    return ((j / run) * 8 + x) * run + (j % run);
+}
+inline unsigned xcd_grid(i64 blocks, int run) {
+    const i64 g = (i64)8 * run;
+    return (unsigned)((blocks + g - 1) / g * g);
+}
+
 // ------------------------------------------------------------------------------------------
 // hash set / map on u64 keys (0 = empty)
 // ------------------------------------------------------------------------------------------
@@ -546,6 +561,119 @@ __global__ void k_neighbors_fill_rows(const u64* keys, HashTab t, const int32_t*
     const i64 i = rows[r];
     const i64 o = rs[i];
     (void)neighbors_of_row(keys, i, t, nidx + o, nkidx + o);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same for ALL grids of a hierarchy in one launch each (asr_geom_neighbors_build_batch): the coarse grids hold a few
+// thousand voxels, whose 13-odd dependent probes cost a level-0 kernel's latency each when launched one by one.  Rows of
+// all jobs share one index space, every job followed by one terminator entry, so that ONE exclusive scan gives every
+// job's row splits (shifted by the job's first value) and the pair counts at the job boundaries.
+// ------------------------------------------------------------------------------------------
+constexpr int NB_MAX_JOBS = 8;
+struct NbBatch {
+    int n;
+    i64 base[NB_MAX_JOBS + 1];  // first entry of each job in the shared index space; base[n] = total
+    i64 v[NB_MAX_JOBS];
+    const u64* keys[NB_MAX_JOBS];
+    HashTab tab[NB_MAX_JOBS];
+    i64* rs[NB_MAX_JOBS];
+    int32_t* idx[NB_MAX_JOBS];
+    uint8_t* kidx[NB_MAX_JOBS];
+};
+__device__ inline int nb_job_of(const NbBatch& b, i64 e) {
+    int j = 0;
+    while (j + 1 < b.n && e >= b.base[j + 1]) ++j;
+    return j;
+}
+__global__ void k_map_build_batch(NbBatch b, int* cnt) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (e >= b.base[b.n]) return;
+    const int j = nb_job_of(b, e);
+    const i64 i = e - b.base[j];
+    if (i >= b.v[j]) return;
+    u64 slot;
+    if (tab_insert(b.tab[j], b.keys[j][i], &slot) < 0)
+        cnt[1] = 1;
+    else
+        b.tab[j].vals[slot] = (int32_t)i;
+}
+__global__ void k_neighbors_count_batch(NbBatch b, i64* counts, u64* masks, int32_t* stage_idx, uint8_t* stage_slot) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (e >= b.base[b.n]) return;
+    const int j = nb_job_of(b, e);
+    const i64 i = e - b.base[j];
+    if (i >= b.v[j]) {  // the job's terminator
+        counts[e] = 0;
+        return;
+    }
+    const HashTab t = b.tab[j];
+    const u64 key = b.keys[j][i];
+    int x, y, z, lev;
+    asr_key_coord(key, x, y, z, lev);
+    u64 m = 0;
+    int n = 1;
+#pragma unroll 6
+    for (int c = 0; c < 36; ++c) {
+        if (c >= 6) {  // a same-level neighbour across a face rules out its children and its parent (k_neighbors_count)
+            const int face = c < 30 ? (c - 6) >> 2 : c - 30;
+            if ((m >> face) & 1) continue;
+        }
+        int slot = 0;
+        const int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
+        if (idx < 0) continue;
+        m |= u64(1) << c;
+        if (n - 1 < NB_STAGE) {
+            stage_idx[e * NB_STAGE + (n - 1)] = idx;
+            stage_slot[e * NB_STAGE + (n - 1)] = (uint8_t)slot;
+        }
+        ++n;
+    }
+    counts[e] = n;
+    masks[e] = m;
+}
+// totals[j] = pairs of job j (scan value at the next job's first entry minus the job's own)
+__global__ void k_nb_totals(NbBatch b, const i64* scan, i64* totals) {
+    const int j = threadIdx.x;
+    if (j < b.n) totals[j] = scan[b.base[j] + b.v[j]] - scan[b.base[j]];
+}
+__global__ void k_neighbors_fill_batch(NbBatch b, const i64* scan, const u64* masks, const int32_t* stage_idx,
+                                       const uint8_t* stage_slot) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (e >= b.base[b.n]) return;
+    const int j = nb_job_of(b, e);
+    const i64 i = e - b.base[j];
+    const i64 first = scan[b.base[j]];
+    i64 o = scan[e] - first;
+    b.rs[j][i] = o;  // (the terminator writes rs[v] = pairs of the job)
+    if (i >= b.v[j]) return;
+    const int n = (int)(scan[e + 1] - first - o);
+    int32_t* nidx = b.idx[j];
+    uint8_t* nkidx = b.kidx[j];
+    nidx[o] = (int32_t)i;
+    nkidx[o] = 0;
+    ++o;
+    if (n - 1 <= NB_STAGE) {  // the candidate order of the counting pass is ascending slot order
+        for (int q = 0; q < n - 1; ++q) {
+            nidx[o + q] = stage_idx[e * NB_STAGE + q];
+            nkidx[o + q] = stage_slot[e * NB_STAGE + q];
+        }
+        return;
+    }
+    const HashTab t = b.tab[j];
+    const u64 key = b.keys[j][i];
+    int x, y, z, lev;
+    asr_key_coord(key, x, y, z, lev);
+    const u64 m = masks[e];
+    for (int c = 0; c < 36; ++c) {
+        if (!((m >> c) & 1)) continue;
+        int slot;
+        const int idx = neighbor_candidate(t, key, x, y, z, lev, c, slot);
+        if (idx >= 0) {
+            nidx[o] = idx;
+            nkidx[o] = (uint8_t)slot;
+            ++o;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1094,6 +1222,182 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
                                     s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Quad queries (round 4, the default light-row pass of the aggregation search): FOUR voxels per wave, 16 lanes each.
+// A light row has ~18 hits among ~115 candidates in 27 cells: one wave per voxel leaves 3/5 of the lanes idle in the
+// cell look-ups and 3/4 in the ranking, and 2.6 M waves of a few microseconds each are what bounds the pass.  Here the
+// 27 look-ups of a voxel are two rounds of its 16 lanes, the candidate walk takes FOUR candidates per lane and round
+// (all four loads in flight: as many rounds per voxel as the one-wave-per-voxel kernel, a quarter of the waves), and the
+// four voxels of a wave share every instruction; no block-level synchronisation.  Output as k_radius_query<2, false>:
+// rows sorted by (squared distance, index) in their fixed slots tmp[q * RADIUS_LIGHT ..]; rows of more than RADIUS_LIGHT
+// hits or RADIUS_GIANT candidates go to the heavy list.
+// ------------------------------------------------------------------------------------------
+constexpr int SQ_VOX = 16;  // voxels per 256-thread block
+template <int U>  // U keys per lane: rows of up to 16 U hits
+__device__ __forceinline__ void quad_rank_out(int h, int hmax, int sl, const u64* keys, const int* pos, u64* out) {
+    u64 mine[U];
+    int rank[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        mine[u] = sl + 16 * u < h ? keys[sl + 16 * u] : ~u64(0);
+        rank[u] = 0;
+    }
+    for (int j = 0; j < hmax; ++j) {  // hmax: the longest row of the wave (uniform trip count)
+        const u64 kj = j < h ? keys[j] : ~u64(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) rank[u] += kj < mine[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (sl + 16 * u < h) out[rank[u]] = (mine[u] & 0xffffffff00000000ull) | (u32)pos[sl + 16 * u];
+}
+__global__ __launch_bounds__(256) void k_radius_quad(asr_octree_frame f, const float4* sorted, const float* centers,
+                                                     const float* sizes, i64 v, CellIndex ci, i64* counts, u64* tmp,
+                                                     int32_t* heavy_out, int* heavy_cnt, uint8_t* is_heavy, int stop,
+                                                     int xrun) {
+    __shared__ int s_pref[SQ_VOX][28];
+    __shared__ int s_beg[SQ_VOX][28];
+    __shared__ u64 s_keys[SQ_VOX][RADIUS_LIGHT];
+    __shared__ int s_pos[SQ_VOX][RADIUS_LIGHT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, sl = lane & 15;
+    const int vox = wave * 4 + sub;
+    const i64 q = (xrun > 0 ? xcd_block(blockIdx.x, xrun) : (i64)blockIdx.x) * SQ_VOX + vox;
+    const bool valid = q < v;
+    if (q == v && sl == 0) counts[v] = 0;
+    float cx = 0.f, cy = 0.f, cz = 0.f, r2 = 0.f;
+    int b0 = 0, n0 = 0, b1 = 0, n1 = 0;
+    if (valid) {
+        cx = centers[3 * q];
+        cy = centers[3 * q + 1];
+        cz = centers[3 * q + 2];
+        const float r = sizes[q];
+        r2 = r * r;
+        const int lev = query_level(f, r);
+        int x, y, z;
+        frame_coord(f, cx, cy, cz, lev, x, y, z);
+        const int lim = (1 << lev) - 1;
+        {
+            const int c = sl;
+            const int xx = x + c % 3 - 1, yy = y + (c / 3) % 3 - 1, zz = z + c / 9 - 1;
+            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
+                cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b0, n0);
+        }
+        if (sl < 11) {
+            const int c = sl + 16;
+            const int xx = x + c % 3 - 1, yy = y + (c / 3) % 3 - 1, zz = z + c / 9 - 1;
+            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
+                cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b1, n1);
+        }
+    }
+    // inclusive prefixes of the cell counts inside the 16-lane group: cells 0..15, then 16..26 on top of their total
+    int p0 = n0, p1 = n1;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const int t0 = __shfl_up(p0, o, 16), t1 = __shfl_up(p1, o, 16);
+        if (sl >= o) {
+            p0 += t0;
+            p1 += t1;
+        }
+    }
+    p1 += __shfl(p0, 15, 16);
+    const int total = __shfl(p1, 10, 16);
+    // The non-empty cells (~8 of 27) compacted: first candidate of the cell and (position of its first point - that), so that
+    // candidate i of the concatenated ranges sits at i + off of the LAST entry whose first candidate is <= i -- a pass of
+    // independent LDS reads (same address within a voxel's lanes) instead of a five-step binary search of dependent ones.
+    const unsigned below = (1u << sl) - 1u;
+    const unsigned e0 = (unsigned)(__ballot(n0 > 0) >> (16 * sub)) & 0xffffu;
+    const unsigned e1 = (unsigned)(__ballot(n1 > 0) >> (16 * sub)) & 0xffffu;
+    const int K = __popc(e0) + __popc(e1);
+    if (n0 > 0) {
+        const int k = __popc(e0 & below);
+        s_pref[vox][k] = p0 - n0;
+        s_beg[vox][k] = b0 - (p0 - n0);
+    }
+    if (n1 > 0) {
+        const int k = __popc(e0) + __popc(e1 & below);
+        s_pref[vox][k] = p1 - n1;
+        s_beg[vox][k] = b1 - (p1 - n1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (stop == 1) {  // ablation: cell look-ups only
+        if (valid && sl == 0) {
+            counts[q] = total & 1;
+            is_heavy[q] = 0;
+        }
+        return;
+    }
+    bool heavy = valid && total > RADIUS_GIANT;
+    int found = 0;
+    const int* pref = s_pref[vox];
+    const int* beg = s_beg[vox];
+    int Kmax = K;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Kmax = max(Kmax, __shfl_xor(Kmax, o, 64));
+    constexpr int CW = 4;  // candidates per lane and round
+    for (int i0 = 0;; i0 += 16 * CW) {
+        const bool active = valid && !heavy && i0 < total;
+        if (!__any(active)) break;
+        bool ok[CW];
+        int pos[CW], off[CW];
+        float4 pt[CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            ok[c] = active && i0 + 16 * c + sl < total;
+            off[c] = 0;
+        }
+        for (int k = 0; k < Kmax; ++k) {  // (entries beyond a voxel's own K are stale or unset: guarded by k < K)
+            const int pk = pref[k], bk = beg[k];
+            const bool mine = k < K;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) off[c] = (mine && i0 + 16 * c + sl >= pk) ? bk : off[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CW; ++c) pos[c] = ok[c] ? i0 + 16 * c + sl + off[c] : 0;
+#pragma unroll
+        for (int c = 0; c < CW; ++c) pt[c] = sorted[pos[c]];  // all loads in flight
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const float d = sqdist3(pt[c].x, pt[c].y, pt[c].z, cx, cy, cz);
+            const bool hit = ok[c] && d < r2;
+            const unsigned m = (unsigned)(__ballot(hit) >> (16 * sub)) & 0xffffu;
+            if (hit) {
+                const int o = found + __popc(m & below);
+                if (o < RADIUS_LIGHT) {
+                    s_keys[vox][o] = ((u64)__float_as_uint(d) << 32) | (u32)__float_as_int(pt[c].w);
+                    s_pos[vox][o] = pos[c];
+                }
+            }
+            found += __popc(m);
+        }
+        if (found > RADIUS_LIGHT) heavy = true;
+    }
+    if (stop == 2) {  // ablation: look-ups + candidate walk
+        if (valid && sl == 0) {
+            counts[q] = found & 1;
+            is_heavy[q] = 0;
+        }
+        return;
+    }
+    const int h = valid && !heavy ? found : 0;
+    if (valid && sl == 0) {
+        counts[q] = h;
+        is_heavy[q] = heavy ? 1 : 0;
+        if (heavy) heavy_out[atomicAdd(heavy_cnt, 1)] = (int32_t)q;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int hmax = h;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) hmax = max(hmax, __shfl_xor(hmax, o, 64));
+    u64* out = tmp + (valid ? q : 0) * RADIUS_LIGHT;
+    if (hmax <= 32)
+        quad_rank_out<2>(h, hmax, sl, s_keys[vox], s_pos[vox], out);
+    else if (hmax <= 64)
+        quad_rank_out<4>(h, hmax, sl, s_keys[vox], s_pos[vox], out);
+    else
+        quad_rank_out<RADIUS_LIGHT / 16>(h, hmax, sl, s_keys[vox], s_pos[vox], out);
+}
+
 // Cell ranges of the heavy rows, looked up ONCE per row (one wave each) and kept for the RADIUS_SPLIT x 4 waves of the
 // counting pass and of the filling pass, which used to repeat the 27 / 64 table look-ups each (2 x 2 x 10^8 probes at
 // 10 M points, three times the light rows' own)
@@ -1126,7 +1430,11 @@ template <bool FILL, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const float4* sorted, const float* centers,
                                                       const float* sizes, const int32_t* heavy, CellIndex ci, AlignedQ aq,
                                                       i64* counts, const i64* hoff, int* cursor, u64* keys_out,
-                                                      int32_t* row_out, const int* hc_pref, const int* hc_beg) {
+                                                      int32_t* row_out, const int* hc_pref, const int* hc_beg,
+                                                      int idx_bits) {
+    // idx_bits > 0 (FILL): ONE sortable key per hit, (row j, squared distance bits, index) = row_bits + 31 + idx_bits
+    // <= 64 bits (distances are >= 0: the sign bit is dropped) -- the rows are then ordered by a single keys-only
+    // radix sort; idx_bits == 0: (distance bits << 32 | index) + the row in row_out, two stable sorts
     constexpr int NCELL = ALIGNED ? 64 : 27;
     __shared__ int s_pref[4][NCELL + 1];
     __shared__ int s_beg[4][NCELL];
@@ -1155,8 +1463,12 @@ __global__ __launch_bounds__(256) void k_radius_heavy(asr_octree_frame f, const 
             o0 = __shfl(o0, 0, 64);
             if (hit) {
                 const i64 o = hoff[j] + o0 + __popcll(m & ((1ull << lane) - 1));
-                keys_out[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
-                row_out[o] = j;
+                if (idx_bits > 0) {
+                    keys_out[o] = ((u64)j << (31 + idx_bits)) | ((u64)__float_as_uint(d) << idx_bits) | (u32)id;
+                } else {
+                    keys_out[o] = ((u64)__float_as_uint(d) << 32) | (u32)id;
+                    row_out[o] = j;
+                }
             }
         }
         found += __popcll(m);
@@ -1228,13 +1540,20 @@ __global__ void k_heavy_counts(const int32_t* heavy, i64 nh, const i64* rs, i64*
 }
 __global__ void k_radius_unpack_heavy(const u64* keys, const int32_t* hrow, i64 num_pairs, const int32_t* heavy,
                                       const i64* hoff, const i64* rs, const float* sizes, const float* radii,
-                                      const int32_t* rank, int32_t* idx, int32_t* spos, float* dist, float* compat) {
+                                      const int32_t* rank, int32_t* idx, int32_t* spos, float* dist, float* compat,
+                                      int idx_bits) {
     i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (p >= num_pairs) return;
-    const int j = hrow[p];
+    u64 k = keys[p];
+    int j;
+    if (idx_bits > 0) {  // (row, distance bits, index) in one key: see k_radius_heavy
+        j = (int)(k >> (31 + idx_bits));
+        k = (((k >> idx_bits) & 0x7fffffffull) << 32) | (k & ((u64(1) << idx_bits) - 1));
+    } else {
+        j = hrow[p];
+    }
     const i64 q = heavy[j];
     const i64 o = rs[q] + (p - hoff[j]);
-    const u64 k = keys[p];
     const int32_t id = (int32_t)(k & 0xffffffffu);
     idx[o] = id;
     if (spos) spos[o] = rank[id];
@@ -2171,6 +2490,79 @@ int asr_geom_neighbors_build(asr_hip_context* ctx, Arena& out_arena, const u64* 
     }
 }
 
+int asr_geom_neighbors_build_batch(asr_hip_context* ctx, Arena& out_arena, asr_nb_job* jobs, int n) {
+    if (n < 1 || n > NB_MAX_JOBS) ASR_FAIL(ctx, ASR_HIP_EINVAL, "neighbors_build_batch: 1..%d jobs", NB_MAX_JOBS);
+    ASR_TRY(ensure_flags(ctx));
+    NbBatch b;
+    b.n = n;
+    i64 total = 0;
+    for (int j = 0; j < n; ++j) {
+        if (jobs[j].v <= 0 || !jobs[j].keys) ASR_FAIL(ctx, ASR_HIP_EINVAL, "neighbors_build_batch: empty grid");
+        b.base[j] = total;
+        b.v[j] = jobs[j].v;
+        b.keys[j] = jobs[j].keys;
+        total += jobs[j].v + 1;
+        jobs[j].rs = arena_alloc<i64>(out_arena, jobs[j].v + 1);
+        if (!jobs[j].rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        b.rs[j] = jobs[j].rs;
+        b.idx[j] = nullptr;
+        b.kidx[j] = nullptr;
+    }
+    b.base[n] = total;
+    for (int grow = 0;; grow += 2) {  // key maps that overflowed (see TabProbe) are rebuilt four times the size
+        u64 caps[NB_MAX_JOBS], cap_sum = 0;
+        for (int j = 0; j < n; ++j) {
+            caps[j] = next_pow2((u64)std::max<i64>(1024, 2 * jobs[j].v)) << grow;
+            cap_sum += caps[j];
+        }
+        u64* tkeys = arena_alloc<u64>(ctx->scratch, cap_sum);  // one allocation, one memset for all tables
+        int32_t* tvals = arena_alloc<int32_t>(ctx->scratch, cap_sum);
+        i64* counts = arena_alloc<i64>(ctx->scratch, total + 1);
+        i64* scan = arena_alloc<i64>(ctx->scratch, total + 1);
+        u64* masks = arena_alloc<u64>(ctx->scratch, total);
+        int32_t* st_idx = arena_alloc<int32_t>(ctx->scratch, (size_t)total * NB_STAGE);
+        uint8_t* st_slot = arena_alloc<uint8_t>(ctx->scratch, (size_t)total * NB_STAGE);
+        i64* totals = arena_alloc<i64>(ctx->scratch, NB_MAX_JOBS);
+        if (!tkeys || !tvals || !counts || !scan || !masks || !st_idx || !st_slot || !totals)
+            ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        u64 off = 0;
+        for (int j = 0; j < n; ++j) {
+            b.tab[j] = HashTab{tkeys + off, tvals + off, caps[j] - 1};
+            off += caps[j];
+        }
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(tkeys, 0, cap_sum * sizeof(u64), ctx->stream));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(counts + total, 0, sizeof(i64), ctx->stream));
+        k_map_build_batch<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, ctx->d_flags);
+        ASR_CHECK_LAUNCH(ctx);
+        k_neighbors_count_batch<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, counts, masks, st_idx, st_slot);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(scan_counts(ctx, ctx->scratch, counts, scan, total + 1));
+        k_nb_totals<<<1, 64, 0, ctx->stream>>>(b, scan, totals);
+        ASR_CHECK_LAUNCH(ctx);
+        int host_flags[16];
+        i64 host_totals[NB_MAX_JOBS];
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(host_flags, ctx->d_flags, 16 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(host_totals, totals, n * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (host_flags[1]) {
+            if (grow >= 6) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "voxel key map overflow");
+            continue;
+        }
+        for (int j = 0; j < n; ++j) {
+            jobs[j].p = host_totals[j];
+            jobs[j].idx = arena_alloc<int32_t>(out_arena, jobs[j].p);
+            jobs[j].kidx = arena_alloc<uint8_t>(out_arena, jobs[j].p);
+            if (!jobs[j].idx || !jobs[j].kidx) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            b.idx[j] = jobs[j].idx;
+            b.kidx[j] = jobs[j].kidx;
+        }
+        k_neighbors_fill_batch<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, scan, masks, st_idx, st_slot);
+        ASR_CHECK_LAUNCH(ctx);
+        return ASR_HIP_OK;
+    }
+}
+
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,
                         int32_t* perm_out, int kbits) {
     if (kbits < 1 || kbits > 56) kbits = 56;  // slot masks only use bits below the kernel size
@@ -2335,7 +2727,7 @@ int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out
 // kernel), one size read-back, outputs allocated from `keep`.
 int asr_geom_coarsen_build(asr_hip_context* ctx, Arena& keep, const u64* keys, i64 v, u64** out_keys, i64* v_out,
                            int32_t** up_idx, uint8_t** up_kidx, i64** up_rs, int32_t** down_idx, uint8_t** down_kidx,
-                           i64** down_rs) {
+                           i64** down_rs, int key_bits) {
     ASR_TRY(ensure_flags(ctx));
     *v_out = 0;
     if (v <= 0) return ASR_HIP_OK;
@@ -2360,7 +2752,8 @@ int asr_geom_coarsen_build(asr_hip_context* ctx, Arena& keep, const u64* keys, i
     i64* cnt = arena_alloc<i64>(ctx->scratch, vo + 1);
     if (!*out_keys || !*up_idx || !*up_kidx || !*up_rs || !*down_idx || !*down_kidx || !*down_rs || !cnt)
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, *out_keys, s_u, s_s, vo, 64)));
+    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, *out_keys, s_u, s_s, vo,
+                                      key_bits >= 1 && key_bits <= 64 ? key_bits : 64)));
     k_coarsen_up<<<grid_for(vo, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, vo, *up_idx, *up_kidx);
     ASR_CHECK_LAUNCH(ctx);
     k_iota64<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(*up_rs, v + 1);
@@ -2645,6 +3038,8 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, std::max(lmax, ltab), st, keep, true, false, radii));
     }
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
+    // quad queries (k_radius_quad): the default light-row pass with full-size cells
+    const bool quad = !st.aligned_main && ctx->opt.search_quad != 0;
     st.tmp = arena_alloc<u64>(ctx->scratch, (size_t)v * RADIUS_LIGHT);
     st.heavy = arena_alloc<int32_t>(ctx->scratch, v);
     st.is_heavy = arena_alloc<uint8_t>(ctx->scratch, v);
@@ -2660,7 +3055,15 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         ASR_CHECK_LAUNCH(ctx);
     }
     const unsigned qgrid = grid_for(v + 1, 4);
-    if (st.aligned_main)
+    if (quad)
+    {
+        const int xrun = (int)std::max<i64>(0, ctx->opt.search_xcd_run);
+        const i64 nb = (v + 1 + SQ_VOX - 1) / SQ_VOX;
+        k_radius_quad<<<xrun > 0 ? xcd_grid(nb, xrun) : (unsigned)nb, BLK, 0, ctx->stream>>>(
+                *frame, st.sorted, centers, sizes, v, st.index(), counts, st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy,
+                (int)ctx->opt.search_quad_stop, xrun);
+    }
+    else if (st.aligned_main)
         k_radius_query<2, true><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts,
                                                                 st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy);
     else
@@ -2687,13 +3090,13 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
                                                                        st.index(), st.aq, st.hc_pref, st.hc_beg);
             k_radius_heavy<false, true><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
                     *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr,
-                    st.hc_pref, st.hc_beg);
+                    st.hc_pref, st.hc_beg, 0);
         } else {
             k_radius_heavy_cells<false><<<cgrid, BLK, 0, ctx->stream>>>(*frame, centers, sizes, st.heavy, (int)st.num_heavy,
                                                                         st.index(), st.aq, st.hc_pref, st.hc_beg);
             k_radius_heavy<false, false><<<dim3((unsigned)st.num_heavy, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
                     *frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, counts, nullptr, nullptr, nullptr, nullptr,
-                    st.hc_pref, st.hc_beg);
+                    st.hc_pref, st.hc_beg, 0);
         }
         ASR_CHECK_LAUNCH(ctx);
     }
@@ -2847,31 +3250,40 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
         i64 hp = 0;
         ASR_TRY(read_i64(ctx, hoff + nh, &hp));
         if (hp >= (i64(1) << 32)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "too many aggregation pairs");
+        // One key per hit when (row, 31 distance bits, index) fits 64 bits: a single keys-only radix sort over exactly those
+        // bits orders all heavy rows by (squared distance, index) -- distances are >= 0, their float bits order like
+        // unsigned integers.  Otherwise two stable sorts: by the (distance, index) key, then by the row (a segmented sort
+        // spends 1.6 ms on the few 10^4-entry rows).
+        const int row_bits = bits_for(nh + 1);
+        int idx_bits = bits_for(std::max<i64>(n, 2));
+        if (row_bits + 31 + idx_bits > 64) idx_bits = 0;
         u64* k_u = arena_alloc<u64>(ctx->scratch, hp);
         u64* k_s = arena_alloc<u64>(ctx->scratch, hp);
-        int32_t* t_row = arena_alloc<int32_t>(ctx->scratch, hp);
-        if (!k_u || !k_s || !t_row) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        int32_t* t_row = idx_bits ? nullptr : arena_alloc<int32_t>(ctx->scratch, hp);
+        if (!k_u || !k_s || (!idx_bits && !t_row)) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         int* cursor = arena_alloc<int>(ctx->scratch, nh);
         if (!cursor) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_HIP_CHECK(ctx, hipMemsetAsync(cursor, 0, (size_t)nh * sizeof(int), ctx->stream));
         if (st.aligned)
             k_radius_heavy<true, true><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
                     st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row,
-                    st.hc_pref, st.hc_beg);
+                    st.hc_pref, st.hc_beg, idx_bits);
         else
             k_radius_heavy<true, false><<<dim3((unsigned)nh, RADIUS_SPLIT), BLK, 0, ctx->stream>>>(
                     st.frame, st.sorted, centers, sizes, st.heavy, st.index(), st.aq, nullptr, hoff, cursor, k_u, t_row,
-                    st.hc_pref, st.hc_beg);
+                    st.hc_pref, st.hc_beg, idx_bits);
         ASR_CHECK_LAUNCH(ctx);
-        // order by (row, squared distance, index) with two stable radix sorts: by the 64-bit key, then
-        // by the row (a segmented sort spends 1.6 ms on the few 10^4-entry rows)
-        int32_t* t_row_s = arena_alloc<int32_t>(ctx->scratch, hp);
-        if (!t_row_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, k_s, t_row, t_row_s, hp, 64)));
-        ASR_TRY((sort_pairs<int32_t, u64>(ctx, ctx->scratch, t_row_s, t_row, k_s, k_u, hp, bits_for(nh + 1))));
-        k_s = k_u;  // sorted keys; t_row holds the sorted rows
+        if (idx_bits) {
+            ASR_TRY(sort_keys(ctx, ctx->scratch, k_u, k_s, hp, row_bits + 31 + idx_bits));
+        } else {
+            int32_t* t_row_s = arena_alloc<int32_t>(ctx->scratch, hp);
+            if (!t_row_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, k_s, t_row, t_row_s, hp, 64)));
+            ASR_TRY((sort_pairs<int32_t, u64>(ctx, ctx->scratch, t_row_s, t_row, k_s, k_u, hp, bits_for(nh + 1))));
+            k_s = k_u;  // sorted keys; t_row holds the sorted rows
+        }
         k_radius_unpack_heavy<<<grid_for(hp, BLK), BLK, 0, ctx->stream>>>(k_s, t_row, hp, st.heavy, hoff, rs, sizes,
-                                                                        radii, st.rank, idx, spos, dist, compat);
+                                                                        radii, st.rank, idx, spos, dist, compat, idx_bits);
         ASR_CHECK_LAUNCH(ctx);
     }
     st.valid = false;

@@ -39,6 +39,7 @@ const OptEntry k_options[] = {
         {"sconv_dry", "ASR_SCONV_DRY", &AsrOptions::sconv_dry},
         {"row_segment", "ASR_ROW_SEGMENT", &AsrOptions::row_segment},
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
+        {"row_ranked", "ASR_ROW_RANKED", &AsrOptions::row_ranked},
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
         {"plan_arena", "ASR_PLAN_ARENA", &AsrOptions::plan_arena},
         {"sconv16_min_blocks", "ASR_SCONV16_MIN_BLOCKS", &AsrOptions::sconv16_min_blocks},
@@ -49,9 +50,7 @@ const OptEntry k_options[] = {
         {"build_search", "ASR_BUILD_SEARCH", &AsrOptions::build_search},
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
-        {"search_quad", "ASR_SEARCH_QUAD", &AsrOptions::search_quad},
-        {"search_quad_stop", "ASR_SEARCH_QUAD_STOP", &AsrOptions::search_quad_stop},
-        {"search_xcd_run", "ASR_SEARCH_XCD_RUN", &AsrOptions::search_xcd_run},
+        {"search_priority", "ASR_SEARCH_PRIORITY", &AsrOptions::search_priority},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
 };
@@ -922,7 +921,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             // on the caller's stream
             int prio_least = 0, prio_greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-            ASR_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->aux->stream, hipStreamNonBlocking, prio_least));
+            const int prio = ctx->opt.search_priority >= 2 ? prio_greatest
+                             : (ctx->opt.search_priority == 1 ? (prio_least + prio_greatest) / 2 : prio_least);
+            ASR_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->aux->stream, hipStreamNonBlocking, prio));
             ctx->aux_stream_owned = true;
             ASR_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
             ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t0));

@@ -104,13 +104,13 @@ struct AsrOptions {
     i64 plan_arena = 0;           // asr_hip_sparse_conv_plan_create: 1 = memory from the context's plan arena (no hipMalloc /
                                   // hipFree per plan; all such plans die with asr_hip_context_plan_arena_reset)
     i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
+    i64 row_ranked = 1;           // row regrouping: sort on (job, segment, rank of the slot mask) keys, all lists in one sort
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
-    i64 search_quad = 1;          // aggregation search: four voxels per wave (k_radius_quad); 0: one wave per voxel
-    i64 search_xcd_run = 64;      // k_radius_quad: consecutive blocks (16 voxels each) per XCD run (xcd_block); 0 = natural order
-    i64 search_quad_stop = 0;     // ablation of k_radius_quad (results invalid): 1 = look-ups only, 2 = + candidate walk
+    i64 search_priority = 2;      // priority of the search's stream (set before the first build): 0 lowest, 1 middle, 2 highest
+                                  // (round 4: the search is the longer of the two chains; 9.6 -> 8.8 ms on its stream)
     i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
     i64 early_cells = 1;            // ... and its cell table, on the search thread
     i64 early_sort = 1;           // overlapped search: its point sort starts on the auxiliary stream beside the octree build

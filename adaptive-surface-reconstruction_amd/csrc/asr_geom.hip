@@ -19,21 +19,6 @@ using namespace asr_prim;
 
 constexpr int BLK = 256;
 
-// XCD-aware work order.  Workgroups are dealt round-robin to the eight XCDs, each with its own 4 MB L2: with the natural
-// order, spatial neighbours (consecutive rows of a sorted key list) land on eight different L2s and every line they
-// share is fetched eight times -- and evicted before the XCD's next visit to the neighbourhood.  xcd_block() hands each
-// XCD whole runs of `run` consecutive logical blocks (XCD x works through runs x, x + 8, x + 16, ...), so that the reuse
-// between neighbouring rows happens inside one L2 while all XCDs still advance through the list at the same pace.
-// Launch xcd_grid(blocks, run) workgroups and drop logical ids >= blocks.
-__device__ inline i64 xcd_block(i64 b, int run) {
-    const i64 x = b & 7, j = b >> 3;
-    return ((j / run) * 8 + x) * run + (j % run);
-}
-inline unsigned xcd_grid(i64 blocks, int run) {
-    const i64 g = (i64)8 * run;
-    return (unsigned)((blocks + g - 1) / g * g);
-}
-
 // ------------------------------------------------------------------------------------------
 // hash set / map on u64 keys (0 = empty)
 // ------------------------------------------------------------------------------------------
@@ -1222,182 +1207,6 @@ __global__ __launch_bounds__(256) void k_radius_query(asr_octree_frame f, const 
                                     s_pref[wave], s_beg[wave], s_keys[kw], s_pos[kw]);
 }
 
-// ------------------------------------------------------------------------------------------
-// Quad queries (round 4, the default light-row pass of the aggregation search): FOUR voxels per wave, 16 lanes each.
-// A light row has ~18 hits among ~115 candidates in 27 cells: one wave per voxel leaves 3/5 of the lanes idle in the
-// cell look-ups and 3/4 in the ranking, and 2.6 M waves of a few microseconds each are what bounds the pass.  Here the
-// 27 look-ups of a voxel are two rounds of its 16 lanes, the candidate walk takes FOUR candidates per lane and round
-// (all four loads in flight: as many rounds per voxel as the one-wave-per-voxel kernel, a quarter of the waves), and the
-// four voxels of a wave share every instruction; no block-level synchronisation.  Output as k_radius_query<2, false>:
-// rows sorted by (squared distance, index) in their fixed slots tmp[q * RADIUS_LIGHT ..]; rows of more than RADIUS_LIGHT
-// hits or RADIUS_GIANT candidates go to the heavy list.
-// ------------------------------------------------------------------------------------------
-constexpr int SQ_VOX = 16;  // voxels per 256-thread block
-template <int U>  // U keys per lane: rows of up to 16 U hits
-__device__ __forceinline__ void quad_rank_out(int h, int hmax, int sl, const u64* keys, const int* pos, u64* out) {
-    u64 mine[U];
-    int rank[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        mine[u] = sl + 16 * u < h ? keys[sl + 16 * u] : ~u64(0);
-        rank[u] = 0;
-    }
-    for (int j = 0; j < hmax; ++j) {  // hmax: the longest row of the wave (uniform trip count)
-        const u64 kj = j < h ? keys[j] : ~u64(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) rank[u] += kj < mine[u];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-        if (sl + 16 * u < h) out[rank[u]] = (mine[u] & 0xffffffff00000000ull) | (u32)pos[sl + 16 * u];
-}
-__global__ __launch_bounds__(256) void k_radius_quad(asr_octree_frame f, const float4* sorted, const float* centers,
-                                                     const float* sizes, i64 v, CellIndex ci, i64* counts, u64* tmp,
-                                                     int32_t* heavy_out, int* heavy_cnt, uint8_t* is_heavy, int stop,
-                                                     int xrun) {
-    __shared__ int s_pref[SQ_VOX][28];
-    __shared__ int s_beg[SQ_VOX][28];
-    __shared__ u64 s_keys[SQ_VOX][RADIUS_LIGHT];
-    __shared__ int s_pos[SQ_VOX][RADIUS_LIGHT];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane >> 4, sl = lane & 15;
-    const int vox = wave * 4 + sub;
-    const i64 q = (xrun > 0 ? xcd_block(blockIdx.x, xrun) : (i64)blockIdx.x) * SQ_VOX + vox;
-    const bool valid = q < v;
-    if (q == v && sl == 0) counts[v] = 0;
-    float cx = 0.f, cy = 0.f, cz = 0.f, r2 = 0.f;
-    int b0 = 0, n0 = 0, b1 = 0, n1 = 0;
-    if (valid) {
-        cx = centers[3 * q];
-        cy = centers[3 * q + 1];
-        cz = centers[3 * q + 2];
-        const float r = sizes[q];
-        r2 = r * r;
-        const int lev = query_level(f, r);
-        int x, y, z;
-        frame_coord(f, cx, cy, cz, lev, x, y, z);
-        const int lim = (1 << lev) - 1;
-        {
-            const int c = sl;
-            const int xx = x + c % 3 - 1, yy = y + (c / 3) % 3 - 1, zz = z + c / 9 - 1;
-            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
-                cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b0, n0);
-        }
-        if (sl < 11) {
-            const int c = sl + 16;
-            const int xx = x + c % 3 - 1, yy = y + (c / 3) % 3 - 1, zz = z + c / 9 - 1;
-            if (xx >= 0 && yy >= 0 && zz >= 0 && xx <= lim && yy <= lim && zz <= lim)
-                cell_range(ci, asr_morton3d((u64)xx, (u64)yy, (u64)zz), lev, b1, n1);
-        }
-    }
-    // inclusive prefixes of the cell counts inside the 16-lane group: cells 0..15, then 16..26 on top of their total
-    int p0 = n0, p1 = n1;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const int t0 = __shfl_up(p0, o, 16), t1 = __shfl_up(p1, o, 16);
-        if (sl >= o) {
-            p0 += t0;
-            p1 += t1;
-        }
-    }
-    p1 += __shfl(p0, 15, 16);
-    const int total = __shfl(p1, 10, 16);
-    // The non-empty cells (~8 of 27) compacted: first candidate of the cell and (position of its first point - that), so that
-    // candidate i of the concatenated ranges sits at i + off of the LAST entry whose first candidate is <= i -- a pass of
-    // independent LDS reads (same address within a voxel's lanes) instead of a five-step binary search of dependent ones.
-    const unsigned below = (1u << sl) - 1u;
-    const unsigned e0 = (unsigned)(__ballot(n0 > 0) >> (16 * sub)) & 0xffffu;
-    const unsigned e1 = (unsigned)(__ballot(n1 > 0) >> (16 * sub)) & 0xffffu;
-    const int K = __popc(e0) + __popc(e1);
-    if (n0 > 0) {
-        const int k = __popc(e0 & below);
-        s_pref[vox][k] = p0 - n0;
-        s_beg[vox][k] = b0 - (p0 - n0);
-    }
-    if (n1 > 0) {
-        const int k = __popc(e0) + __popc(e1 & below);
-        s_pref[vox][k] = p1 - n1;
-        s_beg[vox][k] = b1 - (p1 - n1);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (stop == 1) {  // ablation: cell look-ups only
-        if (valid && sl == 0) {
-            counts[q] = total & 1;
-            is_heavy[q] = 0;
-        }
-        return;
-    }
-    bool heavy = valid && total > RADIUS_GIANT;
-    int found = 0;
-    const int* pref = s_pref[vox];
-    const int* beg = s_beg[vox];
-    int Kmax = K;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) Kmax = max(Kmax, __shfl_xor(Kmax, o, 64));
-    constexpr int CW = 4;  // candidates per lane and round
-    for (int i0 = 0;; i0 += 16 * CW) {
-        const bool active = valid && !heavy && i0 < total;
-        if (!__any(active)) break;
-        bool ok[CW];
-        int pos[CW], off[CW];
-        float4 pt[CW];
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-            ok[c] = active && i0 + 16 * c + sl < total;
-            off[c] = 0;
-        }
-        for (int k = 0; k < Kmax; ++k) {  // (entries beyond a voxel's own K are stale or unset: guarded by k < K)
-            const int pk = pref[k], bk = beg[k];
-            const bool mine = k < K;
-#pragma unroll
-            for (int c = 0; c < CW; ++c) off[c] = (mine && i0 + 16 * c + sl >= pk) ? bk : off[c];
-        }
-#pragma unroll
-        for (int c = 0; c < CW; ++c) pos[c] = ok[c] ? i0 + 16 * c + sl + off[c] : 0;
-#pragma unroll
-        for (int c = 0; c < CW; ++c) pt[c] = sorted[pos[c]];  // all loads in flight
-#pragma unroll
-        for (int c = 0; c < CW; ++c) {
-            const float d = sqdist3(pt[c].x, pt[c].y, pt[c].z, cx, cy, cz);
-            const bool hit = ok[c] && d < r2;
-            const unsigned m = (unsigned)(__ballot(hit) >> (16 * sub)) & 0xffffu;
-            if (hit) {
-                const int o = found + __popc(m & below);
-                if (o < RADIUS_LIGHT) {
-                    s_keys[vox][o] = ((u64)__float_as_uint(d) << 32) | (u32)__float_as_int(pt[c].w);
-                    s_pos[vox][o] = pos[c];
-                }
-            }
-            found += __popc(m);
-        }
-        if (found > RADIUS_LIGHT) heavy = true;
-    }
-    if (stop == 2) {  // ablation: look-ups + candidate walk
-        if (valid && sl == 0) {
-            counts[q] = found & 1;
-            is_heavy[q] = 0;
-        }
-        return;
-    }
-    const int h = valid && !heavy ? found : 0;
-    if (valid && sl == 0) {
-        counts[q] = h;
-        is_heavy[q] = heavy ? 1 : 0;
-        if (heavy) heavy_out[atomicAdd(heavy_cnt, 1)] = (int32_t)q;
-    }
-    __builtin_amdgcn_wave_barrier();
-    int hmax = h;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) hmax = max(hmax, __shfl_xor(hmax, o, 64));
-    u64* out = tmp + (valid ? q : 0) * RADIUS_LIGHT;
-    if (hmax <= 32)
-        quad_rank_out<2>(h, hmax, sl, s_keys[vox], s_pos[vox], out);
-    else if (hmax <= 64)
-        quad_rank_out<4>(h, hmax, sl, s_keys[vox], s_pos[vox], out);
-    else
-        quad_rank_out<RADIUS_LIGHT / 16>(h, hmax, sl, s_keys[vox], s_pos[vox], out);
-}
-
 // Cell ranges of the heavy rows, looked up ONCE per row (one wave each) and kept for the RADIUS_SPLIT x 4 waves of the
 // counting pass and of the filling pass, which used to repeat the 27 / 64 table look-ups each (2 x 2 x 10^8 probes at
 // 10 M points, three times the light rows' own)
@@ -2105,6 +1914,85 @@ __global__ void k_rg_apply(RowGroupBatch b, const int32_t* sorted_ids, const int
     b.out[j][r] = (int32_t)(sorted_ids[src] - b.base[j]);
 }
 
+// Ranked keys (round 4): a hierarchy has a few thousand DISTINCT slot masks, so the 54 mask bits of the sort key are replaced
+// by the mask's rank among the distinct masks (same order, same permutation): (job, segment, rank) is 22 bits -- three digit
+// passes over all 13 lists in one sort instead of three passes over the 9-slot lists plus eight over the 55-slot ones.
+// Distinct masks: a small hash set (k_rg_mask_insert: all but the first insertion of a mask are read-only probes), sorted by
+// ONE workgroup in LDS (k_rg_mask_ranks, bitonic), rank written back as the set's value.  More than RG_MAX_MASKS distinct
+// masks: the caller falls back to the full-mask keys.
+constexpr int RG_MAX_MASKS = 4096;
+constexpr int RG_MASK_TAB = 16384;
+__global__ void k_rg_masks(RowGroupBatch b, u64* masks, HashTab t, int* cnt) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (e >= b.base[b.n]) return;
+    const int j = rg_job_of(b, e);
+    const i64 r = e - b.base[j];
+    u64 m = 0;
+    if (r < b.v[j]) {
+        const i64* rs = b.rs[j];
+        const uint8_t* kidx = b.kidx[j];
+        for (i64 p = rs[r]; p < rs[r + 1]; ++p) m |= u64(1) << (kidx[p] & 63);
+        if (tab_insert(t, (m >> 1) + 1) < 0) cnt[1] = 1;
+    }
+    masks[e] = m;
+}
+__global__ __launch_bounds__(1024) void k_rg_mask_ranks(HashTab t, int* cnt) {
+    __shared__ u64 s_key[RG_MAX_MASKS];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (u64 i = threadIdx.x; i <= t.mask; i += blockDim.x) {
+        const u64 k = t.keys[i];
+        if (k) {
+            const int o = atomicAdd(&s_n, 1);
+            if (o < RG_MAX_MASKS) s_key[o] = k;
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (threadIdx.x == 0) cnt[2] = n;
+    if (n > RG_MAX_MASKS) return;
+    for (int i = n + threadIdx.x; i < RG_MAX_MASKS; i += blockDim.x) s_key[i] = ~u64(0);
+    __syncthreads();
+    for (int k = 2; k <= RG_MAX_MASKS; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < RG_MAX_MASKS; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const u64 a = s_key[i], c = s_key[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) {
+                        s_key[i] = c;
+                        s_key[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const i64 slot = tab_find_slot(t, s_key[i]);
+        if (slot >= 0) t.vals[slot] = i;
+    }
+}
+// key = (job, segment, rank of the slot mask) in 4 + 6 + rank_bits bits
+__global__ void k_rg_keys_ranked(RowGroupBatch b, i64 seg, const u64* masks, HashTab t, unsigned* keys, int32_t* ids,
+                                 int rank_bits) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (e >= b.base[b.n]) return;
+    const int j = rg_job_of(b, e);
+    const i64 r = e - b.base[j];
+    unsigned key;
+    if (r < b.v[j]) {
+        const int rank = tab_find(t, (masks[e] >> 1) + 1);
+        key = ((unsigned)j << (6 + rank_bits)) | ((unsigned)(r / seg) << rank_bits) | (unsigned)rank;
+    } else {
+        key = ((unsigned)j << (6 + rank_bits)) | (63u << rank_bits) | ((1u << rank_bits) - 1u);  // padding: last inside the job
+    }
+    keys[e] = key;
+    ids[e] = (int32_t)e;
+}
+
 // ------------------------------------------------------------------------------------------
 // dual cells ("next" row D.1): CreateDualVertexIndices, cpp/lib/grid.cpp:316-459 with the vertex /
 // adjacent-node key algebra of cpp/lib/octreebase.h:86-118.  One thread per leaf, 8 corners each.
@@ -2619,6 +2507,7 @@ int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs
 // all CSRs of one hierarchy in one pass (see k_rg_keys); falls back to the per-CSR routine for shapes the
 // packed key cannot hold
 static int rg_batch_run(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg, int mask_bits);
+static int rg_batch_run_ranked(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg, bool* done);
 int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg) {
     if (seg < 128) seg = 128;
     bool fits = n <= RG_MAX_JOBS && seg % 128 == 0;
@@ -2630,10 +2519,75 @@ int asr_geom_row_groups_batch(asr_hip_context* ctx, const asr_row_group_job* job
     }
     // The radix sort of the keys is what this routine costs.  Lists with few slots (the 9-slot up / down lists: more than
     // half of all rows of a hierarchy) go through it with 19-bit keys, three digit passes instead of eight.
+    if (ctx->opt.row_ranked) {  // all lists in one sort on (job, segment, rank of the mask) keys
+        bool done = false;
+        ASR_TRY(rg_batch_run_ranked(ctx, jobs, n, seg, &done));
+        if (done) return ASR_HIP_OK;
+    }
     std::vector<asr_row_group_job> small_jobs, wide_jobs;
     for (int j = 0; j < n; ++j) (jobs[j].kbits <= 10 ? small_jobs : wide_jobs).push_back(jobs[j]);
     if (!small_jobs.empty()) ASR_TRY(rg_batch_run(ctx, small_jobs.data(), (int)small_jobs.size(), seg, 9));
     if (!wide_jobs.empty()) ASR_TRY(rg_batch_run(ctx, wide_jobs.data(), (int)wide_jobs.size(), seg, 54));
+    return ASR_HIP_OK;
+}
+// *done = false: more than RG_MAX_MASKS distinct masks (or a full mask set): nothing written, the caller sorts on full masks
+static int rg_batch_run_ranked(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg, bool* done) {
+    *done = false;
+    ASR_TRY(ensure_flags(ctx));
+    RowGroupBatch b;
+    b.n = 0;
+    i64 total = 0;
+    for (int j = 0; j < n; ++j) {
+        if (jobs[j].v <= 0) continue;
+        b.base[b.n] = total;
+        b.v[b.n] = jobs[j].v;
+        b.kidx[b.n] = jobs[j].kidx;
+        b.rs[b.n] = jobs[j].rs;
+        b.out[b.n] = jobs[j].perm_out;
+        total += (jobs[j].v + 127) / 128 * 128;
+        ++b.n;
+    }
+    if (b.n == 0) {
+        *done = true;
+        return ASR_HIP_OK;
+    }
+    b.base[b.n] = total;
+    if (total >= (i64(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "row_groups: too many rows");
+    u64* masks = arena_alloc<u64>(ctx->scratch, total);
+    unsigned* keys = arena_alloc<unsigned>(ctx->scratch, total);
+    unsigned* keys_s = arena_alloc<unsigned>(ctx->scratch, total);
+    int32_t* ids = arena_alloc<int32_t>(ctx->scratch, total);
+    int32_t* ids_s = arena_alloc<int32_t>(ctx->scratch, total);
+    const i64 nc = total / 128;
+    int32_t* ckey = arena_alloc<int32_t>(ctx->scratch, nc);
+    int32_t* ckey_s = arena_alloc<int32_t>(ctx->scratch, nc);
+    int32_t* cid = arena_alloc<int32_t>(ctx->scratch, nc);
+    int32_t* cid_s = arena_alloc<int32_t>(ctx->scratch, nc);
+    if (!masks || !keys || !keys_s || !ids || !ids_s || !ckey || !ckey_s || !cid || !cid_s)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    HashTab t;
+    ASR_TRY(make_table(ctx, ctx->scratch, RG_MASK_TAB, true, t));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    k_rg_masks<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, masks, t, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    k_rg_mask_ranks<<<1, 1024, 0, ctx->stream>>>(t, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    int host[16];
+    ASR_TRY(read_flags(ctx, host));
+    if (host[1] || host[2] > RG_MAX_MASKS) return ASR_HIP_OK;  // too many distinct masks for the ranked keys
+    const int rank_bits = bits_for(std::max(host[2], 2));
+    k_rg_keys_ranked<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, seg, masks, t, keys, ids, rank_bits);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY((sort_pairs<unsigned, int32_t>(ctx, ctx->scratch, keys, keys_s, ids, ids_s, total, 4 + 6 + rank_bits)));
+    const int lpt = ctx->opt.row_lpt != 0;
+    if (lpt) {
+        k_rg_chunk_keys<<<grid_for(nc * 64, BLK), BLK, 0, ctx->stream>>>(b, seg, ids_s, masks, ckey, cid);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, ckey, ckey_s, cid, cid_s, nc, 17)));
+    }
+    k_rg_apply<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, ids_s, cid_s, lpt);
+    ASR_CHECK_LAUNCH(ctx);
+    *done = true;
     return ASR_HIP_OK;
 }
 static int rg_batch_run(asr_hip_context* ctx, const asr_row_group_job* jobs, int n, i64 seg, int mask_bits) {
@@ -3038,8 +2992,6 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         ASR_TRY(build_point_index(ctx, frame, pts, n, lmin, std::max(lmax, ltab), st, keep, true, false, radii));
     }
     i64* counts = arena_alloc<i64>(ctx->scratch, v + 1);
-    // quad queries (k_radius_quad): the default light-row pass with full-size cells
-    const bool quad = !st.aligned_main && ctx->opt.search_quad != 0;
     st.tmp = arena_alloc<u64>(ctx->scratch, (size_t)v * RADIUS_LIGHT);
     st.heavy = arena_alloc<int32_t>(ctx->scratch, v);
     st.is_heavy = arena_alloc<uint8_t>(ctx->scratch, v);
@@ -3055,15 +3007,7 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         ASR_CHECK_LAUNCH(ctx);
     }
     const unsigned qgrid = grid_for(v + 1, 4);
-    if (quad)
-    {
-        const int xrun = (int)std::max<i64>(0, ctx->opt.search_xcd_run);
-        const i64 nb = (v + 1 + SQ_VOX - 1) / SQ_VOX;
-        k_radius_quad<<<xrun > 0 ? xcd_grid(nb, xrun) : (unsigned)nb, BLK, 0, ctx->stream>>>(
-                *frame, st.sorted, centers, sizes, v, st.index(), counts, st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy,
-                (int)ctx->opt.search_quad_stop, xrun);
-    }
-    else if (st.aligned_main)
+    if (st.aligned_main)
         k_radius_query<2, true><<<qgrid, BLK, 0, ctx->stream>>>(*frame, st.sorted, centers, sizes, v, st.index(), st.aq, counts,
                                                                 st.tmp, st.heavy, ctx->d_flags + 10, st.is_heavy);
     else

@@ -93,23 +93,19 @@ def test_grid_hierarchy_bit_exact(case, gpu):
             keys = nxt
 
 
-@pytest.mark.parametrize("quad", [1, 0], ids=["quad", "wave-per-voxel"])
 @pytest.mark.parametrize("hash_level", [-1, 0, 8], ids=["auto", "binary-search", "hash-to-8"])
-def test_multi_radius_search(case, gpu, hash_level, quad):
+def test_multi_radius_search(case, gpu, hash_level):
     """hash_level: finest level of the search's cell hash table; finer query levels find their cells by binary search in
-    the Morton-sorted codes (auto: levels whose cells hold fewer than two points; 0: every level).  quad: the light-row
-    pass with four voxels per wave (k_radius_quad, the default) or one wave per voxel (k_radius_query)"""
+    the Morton-sorted codes (auto: levels whose cells hold fewer than two points; 0: every level)"""
     g = case["grids"][0]
     ctx = case["ops"].context(gpu)
     ctx.set_option("search_hash_level", hash_level)
-    ctx.set_option("search_quad", quad)
     try:
         idx, dist, rs, compat = case["ops"].multi_radius_search(
             case["frame"], case["tpts"], case["trad"], torch.from_numpy(g["voxel_centers"]).to(gpu),
             torch.from_numpy(g["voxel_sizes"]).to(gpu))
     finally:
         ctx.set_option("search_hash_level", -1)
-        ctx.set_option("search_quad", 1)
     o_idx, o_dist, o_rs, o_compat = case["o"].radius_search(case["pts"], case["rad"],
                                                             g["voxel_centers"], g["voxel_sizes"])
     assert np.array_equal(rs.cpu().numpy(), o_rs)

@@ -98,6 +98,34 @@ class ImplicitSizes(ctypes.Structure):
     ]
 
 
+# grouped point-to-point exchange / MAX all-reduce of asr_shard_comm (include/asr_hip.h)
+SHARD_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p)
+SHARD_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class ShardComm(ctypes.Structure):
+    _fields_ = [
+        ("user", ctypes.c_void_p),
+        ("rank", ctypes.c_int),
+        ("world", ctypes.c_int),
+        ("exchange", SHARD_EXCHANGE_FN),
+        ("allreduce_max_u32", SHARD_ALLREDUCE_FN),
+    ]
+
+
+class ShardStats(ctypes.Structure):
+    _fields_ = [
+        ("owned_rows", ctypes.c_int64 * ASR_NUM_GRIDS),
+        ("halo_rows_recv", ctypes.c_int64 * ASR_NUM_GRIDS),
+        ("bytes_sent", ctypes.c_int64),
+        ("bytes_received", ctypes.c_int64),
+        ("exchanges", ctypes.c_int64),
+    ]
+
+
 # every symbol declared in include/asr_hip.h (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "asr_hip_context_create", "asr_hip_context_destroy", "asr_hip_context_set_stream",
@@ -117,6 +145,8 @@ EXPORTS = [
     "asr_hip_reduce_subarrays_sum", "asr_hip_decode_mlp", "asr_hip_implicit_build",
     "asr_hip_implicit_network", "asr_hip_implicit_aggregate", "asr_hip_implicit_forward", "asr_hip_implicit_get",
     "asr_hip_implicit_stage_ms",
+    "asr_hip_implicit_forward_sharded", "asr_hip_shard_comm_rccl_unique_id", "asr_hip_shard_comm_rccl_create",
+    "asr_hip_shard_comm_rccl_destroy",
 ]
 
 _lib = None
@@ -138,7 +168,8 @@ def load():
         lib.asr_hip_sparse_conv_packed_bytes.restype = ctypes.c_size_t
         for name, cls in (("asr_octree_frame", OctreeFrame), ("asr_sparse_conv_args", SparseConvArgs),
                           ("asr_weight", Weight), ("asr_implicit_params", ImplicitParams),
-                          ("asr_implicit_sizes", ImplicitSizes)):
+                          ("asr_implicit_sizes", ImplicitSizes), ("asr_shard_comm", ShardComm),
+                          ("asr_shard_stats", ShardStats)):
             if lib.asr_hip_struct_size(name.encode()) != ctypes.sizeof(cls):
                 raise AsrHipError("ABI mismatch: struct %s has a different size in libasr_hip.so"
                                   % name)

@@ -129,6 +129,25 @@ class ImplicitPipeline:
         self.sizes = sizes
         return self.get("values")
 
+    def forward_sharded(self, comm, points, normals, radii, bb_min, bb_max):
+        """The whole path with the network half sharded over the ranks of `comm` (asr_hip.shardcomm: RcclComm over xGMI,
+        HostStagedComm for tests) INSIDE the library (asr_hip_implicit_forward_sharded): every rank passes the whole
+        cloud, computes the rows it owns and returns the complete values[V0, 2], bit-identical to forward().
+        self.shard_stats: owned rows, halo rows, bytes and grouped exchanges of this forward."""
+        self._check(points, normals, radii)
+        self._stream()
+        p = self._params(bb_min, bb_max)
+        sizes = ImplicitSizes()
+        stats = _lib.ShardStats()
+        self.ctx.call("asr_hip_implicit_forward_sharded", comm.handle(), ptr(points), ptr(normals), ptr(radii),
+                      ctypes.c_int64(points.shape[0]), self._table, len(self._weights), ctypes.byref(p),
+                      ctypes.byref(sizes), ctypes.c_void_p(0), ctypes.byref(stats))
+        self.sizes = sizes
+        self.shard_stats = {"owned_rows": list(stats.owned_rows), "halo_rows_recv": list(stats.halo_rows_recv),
+                            "bytes_sent": int(stats.bytes_sent), "bytes_received": int(stats.bytes_received),
+                            "exchanges": int(stats.exchanges)}
+        return self.get("values")
+
     def build(self, points, radii, bb_min, bb_max):
         """geometry half only (octree, grids, aggregation neighbours)"""
         self._check(points, points, radii)

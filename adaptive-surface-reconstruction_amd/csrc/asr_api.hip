@@ -93,6 +93,8 @@ size_t asr_hip_struct_size(const char* name) {
     if (!strcmp(name, "asr_weight")) return sizeof(asr_weight);
     if (!strcmp(name, "asr_implicit_params")) return sizeof(asr_implicit_params);
     if (!strcmp(name, "asr_implicit_sizes")) return sizeof(asr_implicit_sizes);
+    if (!strcmp(name, "asr_shard_comm")) return sizeof(asr_shard_comm);
+    if (!strcmp(name, "asr_shard_stats")) return sizeof(asr_shard_stats);
     return 0;
 }
 
@@ -670,6 +672,19 @@ struct Net {
     WeightTable wt;
     int precision = 0;  // 0 = exact f32 MFMA, ASR_CONV16_F16, ASR_CONV16_BF16X3, ASR_CONV16_F16X2 (asr_implicit_params.precision)
     int num_amax = 0;
+    // sharded forward (ctx->shard): importance arrays are valid on the owned rows only and travel with the halo of the
+    // features -- except this one, the aggregation's per-pair array, which every rank holds in full (quirk B.2)
+    const float* replicated_imp = nullptr;
+
+    // rows / plan of a convolution over the list `rs` and the halo exchange of its input (no-op on one GPU)
+    int shard_hook(const i64* rs, Feat in, const float* imp, const int32_t** perm, i64* num_out,
+                   const asr_conv_plan** plan) {
+        *plan = nullptr;
+        if (!ctx->shard) return ASR_HIP_OK;
+        float* imp_x = (imp && imp != replicated_imp) ? const_cast<float*>(imp) : nullptr;
+        return asr_shard_before_conv(ctx, ctx->shard, rs, in.p, in.ld * (i64)esz(), in.c * (i64)esz(), imp_x, perm, num_out,
+                                     plan);
+    }
 
     // f16x2: a zeroed device scalar for the running maximum of one activation buffer (nullptr in the other modes)
     unsigned* new_amax() {
@@ -713,13 +728,19 @@ struct Net {
     }
     // dispatch of one assembled argument block: f32 kernel or a 16-bit variant; out_f32: the layer's output
     // feeds the decoder (f32 `code`)
-    int launch(asr_sparse_conv_args& a, const asr_weight* ka, const asr_weight* kb, bool out_f32) {
+    int launch(asr_sparse_conv_args& a, const asr_weight* ka, const asr_weight* kb, bool out_f32,
+               const asr_conv_plan* shard_plan = nullptr) {
         if (precision == 0) return asr_conv_sparse(ctx, &a);
         const void* pk = nullptr;
         ASR_TRY(packed(ka, kb, &pk));
-        auto pl = ctx->conv_plans.find(a.neighbors_row_splits);
-        return asr_conv_sparse16(ctx, &a, pk, precision, precision == ASR_CONV16_F16 && !out_f32,
-                                 pl == ctx->conv_plans.end() ? nullptr : &pl->second);
+        const asr_conv_plan* plan = shard_plan;
+        if (!ctx->shard) {
+            auto pl = ctx->conv_plans.find(a.neighbors_row_splits);
+            plan = pl == ctx->conv_plans.end() ? nullptr : &pl->second;
+        }
+        ASR_TRY(asr_conv_sparse16(ctx, &a, pk, precision, precision == ASR_CONV16_F16 && !out_f32, plan));
+        if (ctx->shard) ASR_TRY(asr_shard_after_conv(ctx, ctx->shard, a.out_absmax));
+        return ASR_HIP_OK;
     }
 
     int get(const std::string& name, int ndim, const asr_weight** out) {
@@ -745,6 +766,8 @@ struct Net {
             ASR_FAIL(ctx, ASR_HIP_EWEIGHT, "weight '%s.kernel' has shape [%lld,%lld,%lld], expected [%d,%d,%d]",
                      prefix.c_str(), (long long)k->shape[0], (long long)k->shape[1],
                      (long long)k->shape[2], K, in.c, expect_cout);
+        const asr_conv_plan* shard_plan = nullptr;
+        ASR_TRY(shard_hook(rs, in, imp, &perm, &num_out, &shard_plan));
         asr_sparse_conv_args a;
         memset(&a, 0, sizeof(a));
         a.filters = k->data;
@@ -770,7 +793,7 @@ struct Net {
         a.row_perm = perm;
         a.inp_absmax = in.amax;
         a.out_absmax = out_amax;
-        return launch(a, k, nullptr, out_f32);
+        return launch(a, k, nullptr, out_f32, shard_plan);
     }
     // conv1a + conv1b of a block in one launch (second filter bank of asr_sparse_conv_args): same
     // gather, one extra column tile.  Falls back to two launches for widths the fused kernel does not take.
@@ -793,6 +816,8 @@ struct Net {
             return conv(name + ".conv1b", K, in, nidx, nk, rs, perm, num_out, num_inp, imp, 1, col(out, ca), out_ld,
                         cb, out_imp, nullptr, 0, false, out_amax);
         }
+        const asr_conv_plan* shard_plan = nullptr;
+        ASR_TRY(shard_hook(rs, in, imp, &perm, &num_out, &shard_plan));
         asr_sparse_conv_args a;
         memset(&a, 0, sizeof(a));
         a.filters = ka->data;
@@ -820,7 +845,7 @@ struct Net {
         a.algo = 2;
         a.inp_absmax = in.amax;
         a.out_absmax = out_amax;
-        return launch(a, ka, kb, false);
+        return launch(a, ka, kb, false, shard_plan);
     }
     int cout_of(const std::string& prefix, int* c) {
         const asr_weight* k;
@@ -1217,6 +1242,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     float* feats1 = ctx->feats1;
     float* imp_pairs = ctx->importance;
     const int C0 = ctx->feats1_width;
+    net.replicated_imp = imp_pairs;
 
     // the per-PAIR importance array is indexed with grid-0 VOXEL indices
     // (net_definitions_torch.py:572-578 -> common_torch.py:125).  torch would raise on P < V0.
@@ -1340,6 +1366,8 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_TRY(asr_conv_decode(ctx, code, V0, c_dec[0], w1->data, b1->data, (int)w1->shape[0], w2->data,
                             b2->data, (int)w2->shape[0], w3->data,
                             prm->scale_sdf ? g[0].sizes : nullptr, values));
+    // sharded forward: the decoder ran over all rows, this rank's are the valid ones; the owners' rows are gathered
+    if (ctx->shard) ASR_TRY(asr_shard_stitch(ctx, ctx->shard, values));
     ctx->values = values;
     name_it(ctx, "values", values, 8 * (size_t)V0);
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
@@ -1388,6 +1416,29 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points, const fl
     ASR_TRY(implicit_network(ctx, points, normals, n, weights, num_weights, prm, nullptr));
     if (sizes) *sizes = ctx->sizes;
     return ASR_HIP_OK;
+}
+int asr_hip_implicit_forward_sharded(asr_hip_context* ctx, const asr_shard_comm* comm, const float* points,
+                                     const float* normals, const float* radii, int64_t n, const asr_weight* weights,
+                                     int num_weights, const asr_implicit_params* prm, asr_implicit_sizes* sizes,
+                                     float* values_out, asr_shard_stats* stats) {
+    CTX_GUARD(ctx);
+    if (!comm || !prm || (num_weights > 0 && !weights)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward_sharded: null argument");
+    if (n > 0 && (!points || !normals || !radii))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward_sharded: points is null!");  // cpp/lib/asr.cpp:101-103
+    if (prm->precision == ASR_CONV16_F16)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward_sharded: the f16-activation network is not sharded (precision 0, "
+                                      "ASR_CONV16_BF16X3 or ASR_CONV16_F16X2)");
+    if (!ctx->opt.build_search) ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward_sharded needs option build_search");
+    ASR_TRY(implicit_build(ctx, points, radii, n, prm));  // the whole cloud's geometry on every rank
+    if (sizes) *sizes = ctx->sizes;
+    asr_shard_state* st = nullptr;
+    ASR_TRY(asr_shard_build(ctx, comm, prm->precision != 0 && ctx->opt.sconv_plan, &st));
+    ctx->shard = st;
+    const int rc = implicit_network(ctx, points, normals, n, weights, num_weights, prm, values_out);
+    ctx->shard = nullptr;
+    if (stats) *stats = *asr_shard_get_stats(st);
+    asr_shard_free(st);
+    return rc;
 }
 int asr_hip_implicit_get(asr_hip_context* ctx, const char* name, void* dst, size_t* nbytes) {
     CTX_GUARD(ctx);

@@ -217,6 +217,7 @@ struct asr_hip_context {
     // callers that update weights in place call asr_hip_context_weights_changed (the copies are made again).
     typedef std::tuple<const void*, const void*, i64, i64, i64, i64, int> PackedKey;
     std::map<PackedKey, void*> packed_weights;
+    struct asr_shard_state* shard = nullptr;  // set while asr_hip_implicit_forward_sharded runs its network half
 };
 
 #define ASR_FAIL(ctx, code, ...)                         \
@@ -311,6 +312,17 @@ __device__ static inline u64 asr_hash64(u64 k) {
     k ^= k >> 33;
     return k;
 }
+
+// one scan over several GPUs (asr_shard.hip): ownership, owned row lists / plans, halo lists of the 13 neighbour lists
+// of the last implicit_build; hooks of the network driver
+struct asr_shard_state;
+int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_plans, asr_shard_state** out);
+void asr_shard_free(asr_shard_state* st);
+const asr_shard_stats* asr_shard_get_stats(const asr_shard_state* st);
+int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void* rs, void* feat, i64 ld_bytes, i64 row_bytes,
+                          float* imp, const int32_t** perm, i64* num_out, const asr_conv_plan** plan);
+int asr_shard_after_conv(asr_hip_context* ctx, asr_shard_state* st, unsigned* out_amax);
+int asr_shard_stitch(asr_hip_context* ctx, asr_shard_state* st, float* values);
 
 // internal entry points shared between translation units
 int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,

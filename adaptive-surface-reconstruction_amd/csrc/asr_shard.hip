@@ -1,0 +1,692 @@
+// asr_shard.hip -- one scan over several GPUs inside the library (BASELINE config C4; include/asr_hip.h
+// asr_hip_implicit_forward_sharded).  The reference has no multi-device path (cpp/lib/asr.cpp:161-163); what defines
+// the halo is the stencil of its operators: one face ring per 55-slot convolution on the same / child / parent level
+// (cpp/lib/grid.cpp:99-170), parent <-> children for the transitions (cpp/lib/grid.cpp:206-242).
+//
+// Every rank has built the geometry of the whole cloud (implicit_build), so ownership and all send / receive lists are
+// derived locally, on the device, without negotiation:
+//   * grid-0 voxels are cut into `world` contiguous ranges of the Morton order of their cells (location codes sort
+//     level-major: keys are normalised to level 21 first) with equal numbers of neighbour pairs; a coarser voxel belongs
+//     to the owner of its first child, a carried voxel keeps its owner -- every level is cut by the same curve;
+//   * per neighbour list (5 x 55-slot, 4 up, 4 down): the owned output rows in the list's MFMA tiling order, a row-group
+//     plan for exactly those rows, and per peer the input rows to send / to receive (ascending, same order on both sides);
+//   * before a convolution the boundary rows of its input buffer (+ their importance) travel point to point, packed into
+//     one message per peer; the f16x2 running maximum of an output buffer is MAX-reduced over the ranks; the owned values
+//     are all-gathered at the end.
+// Transport: asr_shard_comm (two primitives on device buffers).  The RCCL implementation loads librccl.so at run time.
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+#include <rccl/rccl.h>
+
+#include "asr_common.h"
+#include "asr_prim.h"
+
+using namespace asr_prim;
+
+namespace {
+constexpr int BLK = 256;
+constexpr int SHARD_MAX_WORLD = 64;
+
+// level-21 Morton code of a voxel's minimum corner: a space-filling order across levels
+__global__ void k_shard_codes(const u64* keys, i64 v, u64* codes, int32_t* ids) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    const u64 k = keys[i];
+    const int lev = asr_key_level(k);
+    codes[i] = (k ^ (u64(1) << (3 * lev))) << (3 * (ASR_MAX_LEVEL - lev));
+    ids[i] = (int32_t)i;
+}
+__global__ void k_shard_weights(const int32_t* order, const i64* rs, i64 v, i64* w) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    const i64 q = order[i];
+    w[i] = rs[q + 1] - rs[q];
+}
+// owner of the voxel at position i of the Morton order: equal pair counts per rank (midpoint rule)
+__global__ void k_shard_owner0(const int32_t* order, const i64* w, const i64* cum, i64 v, int world, int32_t* owner) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    const i64 total = cum[v - 1];
+    i64 o = total > 0 ? ((2 * cum[i] - w[i]) * world) / (2 * total) : 0;
+    o = o < 0 ? 0 : (o > world - 1 ? world - 1 : o);
+    owner[order[i]] = (int32_t)o;
+}
+// a coarse voxel belongs to the owner of its first child (slot 0); a carried voxel (slot 8) keeps its owner
+__global__ void k_shard_coarser(const int32_t* owner_f, const int32_t* up_idx, const uint8_t* up_kidx, i64 v_f,
+                                int32_t* owner_c) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v_f) return;
+    const int k = up_kidx[i];
+    if (k == 0 || k == 8) owner_c[up_idx[i]] = owner_f[i];
+}
+__global__ void k_shard_flag_rows(const int32_t* perm, const int32_t* owner, int rank, i64 n, uint8_t* flags) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flags[i] = owner[perm ? perm[i] : (int32_t)i] == rank ? 1 : 0;
+}
+// halo of one neighbour list: F[d * v_in + i] = rank d needs my input row i, G[s * v_in + i] = I need input row i of rank s
+__global__ void k_shard_halo_flags(const int32_t* idx, const i64* rs, i64 v_out, i64 v_in, const int32_t* owner_out,
+                                   const int32_t* owner_in, int me, uint8_t* F, uint8_t* G) {
+    const i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (r >= v_out) return;
+    const int d = owner_out[r];
+    for (i64 p = rs[r], pe = rs[r + 1]; p < pe; ++p) {
+        const i64 i = idx[p];
+        const int s = owner_in[i];
+        if (d == s) continue;
+        if (d == me) G[(i64)s * v_in + i] = 1;
+        if (s == me) F[(i64)d * v_in + i] = 1;
+    }
+}
+// selected positions p = peer * v_in + row (ascending): per-peer boundaries and the row index in place
+__global__ void k_shard_split(int32_t* list, const i64* count, i64 v_in, int world, i64* offs) {
+    const i64 n = *count;
+    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (t <= world) {  // offs[t] = first entry of peer t
+        const i64 key = t * v_in;
+        i64 lo = 0, hi = n;
+        while (lo < hi) {
+            const i64 mid = (lo + hi) >> 1;
+            if ((i64)(u32)list[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        offs[t] = lo;
+    }
+}
+__global__ void k_shard_to_rows(int32_t* list, const i64* count, i64 v_in) {
+    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (t < *count) list[t] = (int32_t)((i64)(u32)list[t] % v_in);
+}
+__global__ void k_shard_iota(int32_t* out, i64 n) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+}
+__global__ void k_shard_bounds(const int32_t* sorted_owner, i64 v, int world, i64* offs) {
+    const int t = threadIdx.x;
+    if (t > world) return;
+    i64 lo = 0, hi = v;
+    while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        if (sorted_owner[mid] < t)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    offs[t] = lo;
+}
+
+// message layout of one peer: [n rows x row_dwords][n importance values (optional)]
+struct PackDesc {
+    int npeer;
+    i64 row_first[SHARD_MAX_WORLD + 1];  // first row (in the concatenated row list) of each peer's message
+    i64 msg_dword[SHARD_MAX_WORLD + 1];  // first dword of each peer's message in the staging buffer
+};
+__global__ void k_shard_pack(PackDesc d, const int32_t* rows, const unsigned* buf, i64 ld_dwords, int row_dwords,
+                             const float* imp, unsigned* stage) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    const i64 total = d.row_first[d.npeer];
+    if (e >= total * (row_dwords + (imp ? 1 : 0))) return;
+    const i64 nfeat = total * row_dwords;
+    if (e < nfeat) {
+        const i64 j = e / row_dwords;
+        const int c = (int)(e % row_dwords);
+        int p = 0;
+        while (p + 1 < d.npeer && j >= d.row_first[p + 1]) ++p;
+        stage[d.msg_dword[p] + (j - d.row_first[p]) * row_dwords + c] = buf[(i64)rows[j] * ld_dwords + c];
+    } else {
+        const i64 j = e - nfeat;
+        int p = 0;
+        while (p + 1 < d.npeer && j >= d.row_first[p + 1]) ++p;
+        const i64 np = d.row_first[p + 1] - d.row_first[p];
+        stage[d.msg_dword[p] + np * row_dwords + (j - d.row_first[p])] = __float_as_uint(imp[rows[j]]);
+    }
+}
+__global__ void k_shard_unpack(PackDesc d, const int32_t* rows, unsigned* buf, i64 ld_dwords, int row_dwords, float* imp,
+                               const unsigned* stage) {
+    const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    const i64 total = d.row_first[d.npeer];
+    if (e >= total * (row_dwords + (imp ? 1 : 0))) return;
+    const i64 nfeat = total * row_dwords;
+    if (e < nfeat) {
+        const i64 j = e / row_dwords;
+        const int c = (int)(e % row_dwords);
+        int p = 0;
+        while (p + 1 < d.npeer && j >= d.row_first[p + 1]) ++p;
+        buf[(i64)rows[j] * ld_dwords + c] = stage[d.msg_dword[p] + (j - d.row_first[p]) * row_dwords + c];
+    } else {
+        const i64 j = e - nfeat;
+        int p = 0;
+        while (p + 1 < d.npeer && j >= d.row_first[p + 1]) ++p;
+        const i64 np = d.row_first[p + 1] - d.row_first[p];
+        imp[rows[j]] = __uint_as_float(stage[d.msg_dword[p] + np * row_dwords + (j - d.row_first[p])]);
+    }
+}
+}  // namespace
+
+// out = the elements of `in` whose flag is set, in order; *count (device) = how many
+template <class In>
+static int shard_select(asr_hip_context* ctx, In in, const uint8_t* flags, int32_t* out, i64* count, size_t n) {
+    size_t tb = 0;
+    ASR_HIP_CHECK(ctx, rocprim::select(nullptr, tb, in, flags, out, count, n, ctx->stream));
+    void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+    if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, rocprim::select(tmp, tb, in, flags, out, count, n, ctx->stream));
+    return ASR_HIP_OK;
+}
+
+// halo of one neighbour list: rows of the INPUT buffer, concatenated per peer (ascending peer, ascending row)
+struct ShardCsr {
+    const int32_t* perm = nullptr;  // owned output rows in the list's tiling order
+    i64 num_out = 0;
+    asr_conv_plan plan;
+    bool has_plan = false;
+    const int32_t* send_rows = nullptr;
+    const int32_t* recv_rows = nullptr;
+    std::vector<int> send_peer, recv_peer;  // peers with a non-empty message
+    std::vector<i64> send_first, recv_first;  // first row of each of those messages, + total
+};
+struct asr_shard_state {
+    asr_shard_comm comm;
+    int rank = 0, world = 1;
+    std::map<const void*, ShardCsr> csr;  // keyed by the list's row-splits pointer
+    int32_t* owner[ASR_NUM_GRIDS] = {};
+    int32_t* rows0 = nullptr;  // grid-0 rows grouped by owner (ascending rows within)
+    i64 rows0_off[SHARD_MAX_WORLD + 1] = {};
+    Arena mem;
+    unsigned* stage_send = nullptr;
+    unsigned* stage_recv = nullptr;
+    size_t stage_cap = 0;  // dwords each
+    asr_shard_stats stats;
+};
+
+static int shard_stage(asr_hip_context* ctx, asr_shard_state* st, size_t dwords) {
+    if (dwords <= st->stage_cap) return ASR_HIP_OK;
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (st->stage_send) (void)hipFree(st->stage_send);
+    if (st->stage_recv) (void)hipFree(st->stage_recv);
+    st->stage_send = st->stage_recv = nullptr;
+    const size_t cap = dwords + dwords / 4 + 1024;
+    ASR_HIP_CHECK(ctx, hipMalloc((void**)&st->stage_send, cap * 4));
+    ASR_HIP_CHECK(ctx, hipMalloc((void**)&st->stage_recv, cap * 4));
+    st->stage_cap = cap;
+    return ASR_HIP_OK;
+}
+
+void asr_shard_free(asr_shard_state* st) {
+    if (!st) return;
+    if (st->stage_send) (void)hipFree(st->stage_send);
+    if (st->stage_recv) (void)hipFree(st->stage_recv);
+    st->mem.release();
+    delete st;
+}
+
+const asr_shard_stats* asr_shard_get_stats(const asr_shard_state* st) { return &st->stats; }
+
+// the 13 neighbour lists of the hierarchy: (rows-level, input-level, arrays)
+namespace {
+struct ListRef {
+    const int32_t* idx;
+    const uint8_t* kidx;
+    const i64* rs;
+    const int32_t* perm;
+    i64 v_out, v_in;
+    int lvl_out, lvl_in, K;
+};
+std::vector<ListRef> shard_lists(asr_hip_context* ctx) {
+    std::vector<ListRef> L;
+    GridDev* g = ctx->grids;
+    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+        L.push_back({g[i].nidx, g[i].nkidx, g[i].nrs, g[i].perm_nb, g[i].v, g[i].v, i, i, 55});
+        if (i + 1 < ASR_NUM_GRIDS) {
+            L.push_back({g[i].up_idx, g[i].up_kidx, g[i].up_rs, g[i].perm_up, g[i].v, g[i + 1].v, i, i + 1, 9});
+            L.push_back({g[i].down_idx, g[i].down_kidx, g[i].down_rs, g[i].perm_down, g[i + 1].v, g[i].v, i + 1, i, 9});
+        }
+    }
+    return L;
+}
+}  // namespace
+
+int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_plans, asr_shard_state** out) {
+    *out = nullptr;
+    if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || comm->world > SHARD_MAX_WORLD)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: bad communicator (world 1..%d)", SHARD_MAX_WORLD);
+    if (comm->world > 1 && (!comm->exchange || !comm->allreduce_max_u32))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: the communicator lacks exchange / allreduce_max_u32");
+    asr_shard_state* st = new asr_shard_state();
+    struct Guard {
+        asr_shard_state*& p;
+        ~Guard() {
+            if (p) asr_shard_free(p);
+        }
+    };
+    asr_shard_state* guarded = st;
+    Guard guard{guarded};
+    st->comm = *comm;
+    st->rank = comm->rank;
+    st->world = comm->world;
+    st->mem.min_slab = size_t(8) << 20;
+    memset(&st->stats, 0, sizeof(st->stats));
+    GridDev* g = ctx->grids;
+    const std::vector<ListRef> L = shard_lists(ctx);
+    const int world = st->world, me = st->rank;
+    if (world == 1) {  // everything is mine: the monolithic driver's own orders and plans
+        for (const ListRef& l : L) {
+            ShardCsr c;
+            c.perm = l.perm;
+            c.num_out = l.v_out;
+            auto it = ctx->conv_plans.find(l.rs);
+            if (it != ctx->conv_plans.end()) {
+                c.plan = it->second;
+                c.has_plan = true;
+            }
+            c.send_first.push_back(0);
+            c.recv_first.push_back(0);
+            st->csr[l.rs] = c;
+        }
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) st->stats.owned_rows[i] = g[i].v;
+        guarded = nullptr;
+        *out = st;
+        return ASR_HIP_OK;
+    }
+    ASR_TRY(ensure_flags(ctx));
+    ctx->scratch.reset();
+    // ---- ownership ----
+    const i64 V0 = g[0].v;
+    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+        st->owner[i] = arena_alloc<int32_t>(st->mem, g[i].v);
+        if (!st->owner[i]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    }
+    {
+        u64* codes = arena_alloc<u64>(ctx->scratch, V0);
+        u64* codes_s = arena_alloc<u64>(ctx->scratch, V0);
+        int32_t* ids = arena_alloc<int32_t>(ctx->scratch, V0);
+        int32_t* order = arena_alloc<int32_t>(ctx->scratch, V0);
+        i64* w = arena_alloc<i64>(ctx->scratch, V0);
+        i64* cum = arena_alloc<i64>(ctx->scratch, V0);
+        if (!codes || !codes_s || !ids || !order || !w || !cum) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_shard_codes<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(g[0].keys, V0, codes, ids);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes, codes_s, ids, order, V0, 63)));
+        k_shard_weights<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, g[0].nrs, V0, w);
+        ASR_CHECK_LAUNCH(ctx);
+        size_t tb = 0;
+        ASR_HIP_CHECK(ctx, rocprim::inclusive_scan(nullptr, tb, w, cum, (size_t)V0, rocprim::plus<i64>(), ctx->stream));
+        void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+        if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, rocprim::inclusive_scan(tmp, tb, w, cum, (size_t)V0, rocprim::plus<i64>(), ctx->stream));
+        k_shard_owner0<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, w, cum, V0, world, st->owner[0]);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    for (int i = 0; i + 1 < ASR_NUM_GRIDS; ++i) {
+        k_shard_coarser<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(st->owner[i], g[i].up_idx, g[i].up_kidx, g[i].v,
+                                                                        st->owner[i + 1]);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    // ---- per list: owned rows in tiling order, halo lists (device passes first, ONE read-back of all sizes) ----
+    const int nl = (int)L.size();
+    // device counters: per list [0] owned rows, [1] send total, [2] recv total, then (world + 1) send offsets, (world + 1)
+    // recv offsets; + the stitch offsets
+    const int per = 3 + 2 * (world + 1);
+    i64* d_cnt = arena_alloc<i64>(ctx->scratch, (size_t)nl * per + world + 1);
+    if (!d_cnt) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nl * per + world + 1) * sizeof(i64), ctx->stream));
+    std::vector<int32_t*> t_perm(nl), t_send(nl), t_recv(nl);
+    i64 v_in_max = 0;
+    for (const ListRef& l : L) v_in_max = std::max(v_in_max, l.v_in);
+    uint8_t* F = arena_alloc<uint8_t>(ctx->scratch, (size_t)world * v_in_max);
+    uint8_t* G = arena_alloc<uint8_t>(ctx->scratch, (size_t)world * v_in_max);
+    uint8_t* rflags = arena_alloc<uint8_t>(ctx->scratch, (size_t)std::max(v_in_max, g[0].v));
+    if (!F || !G || !rflags) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    for (int j = 0; j < nl; ++j) {
+        const ListRef& l = L[j];
+        i64* cnt = d_cnt + (size_t)j * per;
+        // owned output rows, in tiling order
+        t_perm[j] = arena_alloc<int32_t>(st->mem, l.v_out);
+        if (!t_perm[j]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_shard_flag_rows<<<grid_for(l.v_out, BLK), BLK, 0, ctx->stream>>>(l.perm, st->owner[l.lvl_out], me, l.v_out, rflags);
+        ASR_CHECK_LAUNCH(ctx);
+        if (l.perm)
+            ASR_TRY(shard_select(ctx, l.perm, rflags, t_perm[j], cnt + 0, (size_t)l.v_out));
+        else
+            ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), rflags, t_perm[j], cnt + 0, (size_t)l.v_out));
+        // halo flags -> ascending (peer, row) lists
+        const size_t nf = (size_t)world * l.v_in;
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(F, 0, nf, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(G, 0, nf, ctx->stream));
+        k_shard_halo_flags<<<grid_for(l.v_out, BLK), BLK, 0, ctx->stream>>>(l.idx, l.rs, l.v_out, l.v_in, st->owner[l.lvl_out],
+                                                                           st->owner[l.lvl_in], me, F, G);
+        ASR_CHECK_LAUNCH(ctx);
+        if (nf >= (size_t(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: world x voxels exceeds 2^31");
+        // a rank sends / receives at most all input rows once per peer; the lists are bounded by the list's pair count too
+        const size_t cap = std::min<size_t>(nf, (size_t)std::max<i64>(l.v_out * (l.K == 55 ? 55 : 8), 1));
+        t_send[j] = arena_alloc<int32_t>(ctx->scratch, cap);
+        t_recv[j] = arena_alloc<int32_t>(ctx->scratch, cap);
+        if (!t_send[j] || !t_recv[j]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), F, t_send[j], cnt + 1, nf));
+        ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), G, t_recv[j], cnt + 2, nf));
+        k_shard_split<<<1, 128, 0, ctx->stream>>>(t_send[j], cnt + 1, l.v_in, world, cnt + 3);
+        k_shard_split<<<1, 128, 0, ctx->stream>>>(t_recv[j], cnt + 2, l.v_in, world, cnt + 3 + world + 1);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    // stitch: grid-0 rows grouped by owner
+    {
+        int32_t* ids = arena_alloc<int32_t>(ctx->scratch, V0);
+        int32_t* own_s = arena_alloc<int32_t>(ctx->scratch, V0);
+        st->rows0 = arena_alloc<int32_t>(st->mem, V0);
+        if (!ids || !own_s || !st->rows0) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_shard_iota<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(ids, V0);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<int32_t, int32_t>(ctx, ctx->scratch, st->owner[0], own_s, ids, st->rows0, V0, bits_for(world + 1))));
+        k_shard_bounds<<<1, 128, 0, ctx->stream>>>(own_s, V0, world, d_cnt + (size_t)nl * per);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    std::vector<i64> h_cnt((size_t)nl * per + world + 1);
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(h_cnt.data(), d_cnt, h_cnt.size() * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p <= world; ++p) st->rows0_off[p] = h_cnt[(size_t)nl * per + p];
+    // exact-size halo lists (rows instead of (peer, row) positions), plans of the owned rows
+    std::vector<asr_conv_plan> plans;
+    std::vector<int> plan_of;
+    for (int j = 0; j < nl; ++j) {
+        const ListRef& l = L[j];
+        const i64* c = &h_cnt[(size_t)j * per];
+        ShardCsr cs;
+        cs.perm = t_perm[j];
+        cs.num_out = c[0];
+        const i64 ns = c[1], nr = c[2];
+        i64* cnt = d_cnt + (size_t)j * per;
+        if (ns > 0) {
+            int32_t* rows = arena_alloc<int32_t>(st->mem, ns);
+            if (!rows) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            k_shard_to_rows<<<grid_for(ns, BLK), BLK, 0, ctx->stream>>>(t_send[j], cnt + 1, l.v_in);
+            ASR_CHECK_LAUNCH(ctx);
+            ASR_HIP_CHECK(ctx, hipMemcpyAsync(rows, t_send[j], ns * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            cs.send_rows = rows;
+        }
+        if (nr > 0) {
+            int32_t* rows = arena_alloc<int32_t>(st->mem, nr);
+            if (!rows) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            k_shard_to_rows<<<grid_for(nr, BLK), BLK, 0, ctx->stream>>>(t_recv[j], cnt + 2, l.v_in);
+            ASR_CHECK_LAUNCH(ctx);
+            ASR_HIP_CHECK(ctx, hipMemcpyAsync(rows, t_recv[j], nr * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            cs.recv_rows = rows;
+        }
+        for (int p = 0; p < world; ++p) {
+            const i64 s0 = c[3 + p], s1 = c[3 + p + 1];
+            if (s1 > s0) {
+                cs.send_peer.push_back(p);
+                cs.send_first.push_back(s0);
+            }
+            const i64 r0 = c[3 + world + 1 + p], r1 = c[3 + world + 1 + p + 1];
+            if (r1 > r0) {
+                cs.recv_peer.push_back(p);
+                cs.recv_first.push_back(r0);
+            }
+        }
+        cs.send_first.push_back(ns);
+        cs.recv_first.push_back(nr);
+        if (l.K == 55) st->stats.halo_rows_recv[l.lvl_out] = nr;
+        if (l.K == 55) st->stats.owned_rows[l.lvl_out] = cs.num_out;
+        st->csr[l.rs] = cs;
+        if (want_plans && cs.num_out > 0) {
+            asr_conv_plan pl;
+            pl.nidx = l.idx;
+            pl.kidx = l.kidx;
+            pl.rs = l.rs;
+            pl.perm = cs.perm;
+            pl.num_out = cs.num_out;
+            pl.K = l.K;
+            plans.push_back(pl);
+            plan_of.push_back(j);
+        }
+    }
+    if (!plans.empty()) {
+        ASR_TRY(asr_geom_conv_plan_batch(ctx, st->mem, plans.data(), (int)plans.size()));
+        for (size_t q = 0; q < plans.size(); ++q) {
+            ShardCsr& cs = st->csr[L[plan_of[q]].rs];
+            cs.plan = plans[q];
+            cs.has_plan = true;
+        }
+    }
+    guarded = nullptr;
+    *out = st;
+    return ASR_HIP_OK;
+}
+
+// before a convolution over the list `rs`: the rows it computes (perm, num_out, plan) and the halo exchange of its input
+int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void* rs, void* feat, i64 ld_bytes, i64 row_bytes,
+                          float* imp, const int32_t** perm, i64* num_out, const asr_conv_plan** plan) {
+    auto it = st->csr.find(rs);
+    if (it == st->csr.end()) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "sharded forward: convolution over an unknown neighbour list");
+    ShardCsr& c = it->second;
+    *perm = c.perm;
+    *num_out = c.num_out;
+    *plan = c.has_plan ? &c.plan : nullptr;
+    const i64 ns = c.send_first.back(), nr = c.recv_first.back();
+    if (st->world == 1 || (ns == 0 && nr == 0)) return ASR_HIP_OK;
+    if (ld_bytes % 4 || row_bytes % 4 || (uintptr_t)feat % 4)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: feature rows must be multiples of 4 bytes");
+    const int row_dwords = (int)(row_bytes / 4);
+    const i64 per_row = row_dwords + (imp ? 1 : 0);
+    ASR_TRY(shard_stage(ctx, st, (size_t)std::max(ns, nr) * per_row));
+    PackDesc ds, dr;
+    ds.npeer = (int)c.send_peer.size();
+    dr.npeer = (int)c.recv_peer.size();
+    std::vector<const void*> sbuf(ds.npeer);
+    std::vector<void*> rbuf(dr.npeer);
+    std::vector<size_t> sbytes(ds.npeer), rbytes(dr.npeer);
+    for (int p = 0; p <= ds.npeer; ++p) {
+        ds.row_first[p] = c.send_first[p];
+        ds.msg_dword[p] = c.send_first[p] * per_row;
+    }
+    for (int p = 0; p <= dr.npeer; ++p) {
+        dr.row_first[p] = c.recv_first[p];
+        dr.msg_dword[p] = c.recv_first[p] * per_row;
+    }
+    for (int p = 0; p < ds.npeer; ++p) {
+        sbuf[p] = st->stage_send + ds.msg_dword[p];
+        sbytes[p] = (size_t)(ds.msg_dword[p + 1] - ds.msg_dword[p]) * 4;
+    }
+    for (int p = 0; p < dr.npeer; ++p) {
+        rbuf[p] = st->stage_recv + dr.msg_dword[p];
+        rbytes[p] = (size_t)(dr.msg_dword[p + 1] - dr.msg_dword[p]) * 4;
+    }
+    if (ns > 0) {
+        k_shard_pack<<<grid_for(ns * per_row, BLK), BLK, 0, ctx->stream>>>(ds, c.send_rows, (const unsigned*)feat, ld_bytes / 4,
+                                                                          row_dwords, imp, st->stage_send);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    if (st->comm.exchange(st->comm.user, ds.npeer, c.send_peer.data(), sbuf.data(), sbytes.data(), dr.npeer,
+                          c.recv_peer.data(), rbuf.data(), rbytes.data(), (void*)ctx->stream) != 0)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the halo exchange failed");
+    if (nr > 0) {
+        k_shard_unpack<<<grid_for(nr * per_row, BLK), BLK, 0, ctx->stream>>>(dr, c.recv_rows, (unsigned*)feat, ld_bytes / 4,
+                                                                            row_dwords, imp, st->stage_recv);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    st->stats.bytes_sent += ns * per_row * 4;
+    st->stats.bytes_received += nr * per_row * 4;
+    st->stats.exchanges += 1;
+    return ASR_HIP_OK;
+}
+
+// after a convolution that keeps a running maximum (f16x2): the tensor's maximum is the largest over the ranks
+int asr_shard_after_conv(asr_hip_context* ctx, asr_shard_state* st, unsigned* out_amax) {
+    if (!out_amax || st->world == 1) return ASR_HIP_OK;
+    if (st->comm.allreduce_max_u32(st->comm.user, out_amax, 1, (void*)ctx->stream) != 0)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the MAX all-reduce failed");
+    return ASR_HIP_OK;
+}
+
+// values [V0, 2]: this rank's rows are valid; afterwards all rows are (all-gather of the owned rows)
+int asr_shard_stitch(asr_hip_context* ctx, asr_shard_state* st, float* values) {
+    if (st->world == 1) return ASR_HIP_OK;
+    const int world = st->world, me = st->rank;
+    const i64 V0 = st->rows0_off[world];
+    const i64 mine = st->rows0_off[me + 1] - st->rows0_off[me];
+    ASR_TRY(shard_stage(ctx, st, (size_t)V0 * 2));
+    // my rows packed once, sent to every peer; the peers' rows land at their offsets of the grouped row list
+    PackDesc dm;
+    dm.npeer = 1;
+    dm.row_first[0] = 0;
+    dm.row_first[1] = mine;
+    dm.msg_dword[0] = 0;
+    dm.msg_dword[1] = mine * 2;
+    if (mine > 0) {
+        k_shard_pack<<<grid_for(mine * 2, BLK), BLK, 0, ctx->stream>>>(dm, st->rows0 + st->rows0_off[me], (const unsigned*)values,
+                                                                      2, 2, nullptr, st->stage_send);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    std::vector<int> speer, rpeer;
+    std::vector<const void*> sbuf;
+    std::vector<void*> rbuf;
+    std::vector<size_t> sbytes, rbytes;
+    for (int p = 0; p < world; ++p) {
+        if (p == me) continue;
+        if (mine > 0) {
+            speer.push_back(p);
+            sbuf.push_back(st->stage_send);
+            sbytes.push_back((size_t)mine * 8);
+        }
+        const i64 np = st->rows0_off[p + 1] - st->rows0_off[p];
+        if (np > 0) {
+            rpeer.push_back(p);
+            rbuf.push_back(st->stage_recv + st->rows0_off[p] * 2);
+            rbytes.push_back((size_t)np * 8);
+        }
+    }
+    if (st->comm.exchange(st->comm.user, (int)speer.size(), speer.data(), sbuf.data(), sbytes.data(), (int)rpeer.size(),
+                          rpeer.data(), rbuf.data(), rbytes.data(), (void*)ctx->stream) != 0)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the all-gather of the values failed");
+    for (int p = 0; p < world; ++p) {
+        const i64 np = st->rows0_off[p + 1] - st->rows0_off[p];
+        if (p == me || np == 0) continue;
+        PackDesc dp;
+        dp.npeer = 1;
+        dp.row_first[0] = 0;
+        dp.row_first[1] = np;
+        dp.msg_dword[0] = st->rows0_off[p] * 2;
+        dp.msg_dword[1] = st->rows0_off[p + 1] * 2;
+        k_shard_unpack<<<grid_for(np * 2, BLK), BLK, 0, ctx->stream>>>(dp, st->rows0 + st->rows0_off[p], (unsigned*)values, 2, 2,
+                                                                     nullptr, st->stage_recv);
+        ASR_CHECK_LAUNCH(ctx);
+        st->stats.bytes_received += np * 8;
+    }
+    st->stats.bytes_sent += mine * 8 * (world - 1);
+    st->stats.exchanges += 1;
+    return ASR_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// RCCL transport (librccl.so loaded at run time: the library itself does not link against it)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    bool ok() const {
+        return lib && GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce;
+    }
+};
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (a.lib) {
+            a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
+            a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
+            a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+            a.GroupStart = (decltype(a.GroupStart))dlsym(a.lib, "ncclGroupStart");
+            a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.lib, "ncclGroupEnd");
+            a.Send = (decltype(a.Send))dlsym(a.lib, "ncclSend");
+            a.Recv = (decltype(a.Recv))dlsym(a.lib, "ncclRecv");
+            a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
+        }
+        return a;
+    }();
+    return api;
+}
+struct RcclComm {
+    asr_shard_comm base;
+    ncclComm_t comm = nullptr;
+};
+int rccl_exchange(void* user, int nsend, const int* send_peer, const void* const* send_buf, const size_t* send_bytes,
+                  int nrecv, const int* recv_peer, void* const* recv_buf, const size_t* recv_bytes, void* stream) {
+    RcclComm* c = (RcclComm*)user;
+    RcclApi& a = rccl();
+    if (nsend == 0 && nrecv == 0) return 0;
+    if (a.GroupStart() != ncclSuccess) return 1;
+    int bad = 0;
+    for (int i = 0; i < nsend; ++i)
+        bad |= a.Send(send_buf[i], send_bytes[i], ncclUint8, send_peer[i], c->comm, (hipStream_t)stream) != ncclSuccess;
+    for (int i = 0; i < nrecv; ++i)
+        bad |= a.Recv(recv_buf[i], recv_bytes[i], ncclUint8, recv_peer[i], c->comm, (hipStream_t)stream) != ncclSuccess;
+    if (a.GroupEnd() != ncclSuccess) return 1;
+    return bad;
+}
+int rccl_allreduce_max(void* user, uint32_t* buf, size_t n, void* stream) {
+    RcclComm* c = (RcclComm*)user;
+    return rccl().AllReduce(buf, buf, n, ncclUint32, ncclMax, c->comm, (hipStream_t)stream) != ncclSuccess;
+}
+}  // namespace
+
+extern "C" {
+int asr_hip_shard_comm_rccl_unique_id(asr_hip_context* ctx, void* unique_id_out) {
+    if (!ctx) return ASR_HIP_EINVAL;
+    if (!unique_id_out) ASR_FAIL(ctx, ASR_HIP_EINVAL, "rccl_unique_id: null output");
+    if (!rccl().ok()) ASR_FAIL(ctx, ASR_HIP_ENODEV, "librccl.so could not be loaded");
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) ASR_FAIL(ctx, ASR_HIP_EHIP, "ncclGetUniqueId failed");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(unique_id_out, &id, sizeof(id));
+    return ASR_HIP_OK;
+}
+int asr_hip_shard_comm_rccl_create(asr_hip_context* ctx, const void* unique_id, int rank, int world,
+                                   asr_shard_comm** comm_out) {
+    if (!ctx) return ASR_HIP_EINVAL;
+    if (!unique_id || !comm_out || world < 1 || rank < 0 || rank >= world)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "rccl_create: bad argument");
+    *comm_out = nullptr;
+    if (!rccl().ok()) ASR_FAIL(ctx, ASR_HIP_ENODEV, "librccl.so could not be loaded");
+    ASR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    RcclComm* c = new RcclComm();
+    if (rccl().CommInitRank(&c->comm, world, id, rank) != ncclSuccess) {
+        delete c;
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "ncclCommInitRank failed (rank %d of %d)", rank, world);
+    }
+    c->base.user = c;
+    c->base.rank = rank;
+    c->base.world = world;
+    c->base.exchange = rccl_exchange;
+    c->base.allreduce_max_u32 = rccl_allreduce_max;
+    *comm_out = &c->base;
+    return ASR_HIP_OK;
+}
+void asr_hip_shard_comm_rccl_destroy(asr_shard_comm* comm) {
+    if (!comm) return;
+    RcclComm* c = (RcclComm*)comm->user;
+    if (c && c->comm && rccl().ok()) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+}  // extern "C"

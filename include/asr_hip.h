@@ -454,6 +454,51 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points_dev,
                              const float* normals_dev, const float* radii_dev, int64_t n,
                              const asr_weight* weights, int num_weights,
                              const asr_implicit_params* params, asr_implicit_sizes* sizes);
+/* ---- one scan over several GPUs, inside the library (round 4; SURVEY 8(e), BASELINE config C4) ----------------------
+ * The reference has no multi-device path (cpp/lib/asr.cpp:161-163 creates CPU tensors); what defines the halo is the
+ * stencil of its operators: one face ring per 55-slot convolution on the same / child / parent level
+ * (cpp/lib/grid.cpp:99-170) and parent <-> children for the transitions (cpp/lib/grid.cpp:206-242).
+ *
+ * asr_hip_implicit_forward_sharded: every rank holds the whole cloud and builds the geometry + the aggregation stage of
+ * the whole cloud (replicated); the 53 sparse convolutions and the decoder run on the rows the rank OWNS (grid-0 voxels
+ * cut into `world` contiguous ranges of their level-21 Morton order with equal pair counts, a coarser voxel belongs to
+ * the owner of its first child), with one point-to-point exchange of the boundary rows of the input buffer (+ the
+ * importance of those rows) before each convolution, a MAX all-reduce of the f16x2 running maxima, and an all-gather
+ * of the owned values at the end.  Per row the same kernel, plan-group arithmetic and summation order as on one GPU:
+ * the values equal asr_hip_implicit_forward's bit for bit.
+ *
+ * Transport: a table of two collective primitives on DEVICE buffers, enqueued on (or synchronised with) `stream`.
+ * asr_hip_shard_comm_rccl_* provides it over RCCL (librccl.so is loaded at run time); tests plug in a host-staged one.
+ */
+typedef struct asr_shard_comm {
+    void* user;
+    int rank, world;
+    /* grouped point-to-point exchange: message i goes to / comes from peer[i]; all of one call may proceed
+     * concurrently (ncclGroupStart .. ncclGroupEnd).  Buffers are device memory.  0 = ok. */
+    int (*exchange)(void* user, int nsend, const int* send_peer, const void* const* send_buf, const size_t* send_bytes,
+                    int nrecv, const int* recv_peer, void* const* recv_buf, const size_t* recv_bytes, void* stream);
+    /* in-place MAX over the ranks of n uint32 values (f16x2 running maxima: non-negative f32 bit patterns) */
+    int (*allreduce_max_u32)(void* user, uint32_t* buf_dev, size_t n, void* stream);
+} asr_shard_comm;
+
+/* RCCL transport.  unique_id_out / unique_id: the 128 bytes of ncclUniqueId (rank 0 creates, the host broadcasts). */
+int asr_hip_shard_comm_rccl_unique_id(asr_hip_context* ctx, void* unique_id_out);
+int asr_hip_shard_comm_rccl_create(asr_hip_context* ctx, const void* unique_id, int rank, int world,
+                                   asr_shard_comm** comm_out);
+void asr_hip_shard_comm_rccl_destroy(asr_shard_comm* comm);
+
+typedef struct asr_shard_stats {
+    int64_t owned_rows[ASR_NUM_GRIDS];
+    int64_t halo_rows_recv[ASR_NUM_GRIDS]; /* 55-slot lists: rows received per application of the level's stencil */
+    int64_t bytes_sent, bytes_received;    /* halo exchanges + stitch of the last forward                       */
+    int64_t exchanges;                     /* grouped exchanges of the last forward                              */
+} asr_shard_stats;
+
+/* values_out_dev [num_voxels[0], 2] complete on every rank (NULL: stays in the context, "values") */
+int asr_hip_implicit_forward_sharded(asr_hip_context* ctx, const asr_shard_comm* comm, const float* points_dev,
+                                     const float* normals_dev, const float* radii_dev, int64_t n,
+                                     const asr_weight* weights, int num_weights, const asr_implicit_params* params,
+                                     asr_implicit_sizes* sizes, float* values_out_dev, asr_shard_stats* stats);
 /* copies one of the arrays of the last build/forward into dst_dev (device to device).
  * name: "values", "feats1", "importance", "code",
  *       "voxel_keys<i>", "voxel_centers<i>", "voxel_sizes<i>", "neighbors_index<i>",

@@ -122,3 +122,83 @@ def test_sharded_geometry_equals_single_process(gpu, world, fused, precision):
     assert r0["equal"], r0["max_abs_diff"]
     assert sum(i["owned"][0] for i in infos) == r0["v0"]
     assert all(i["halo"]["nb", 0] > 0 for i in infos)
+
+
+# ---- the sharded forward INSIDE the library (asr_hip_implicit_forward_sharded, round 4) ------------------------------
+def _native_worker(rank, world, port, n_points, channel_div, precision, out, fused=0):
+    sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd"), os.path.join(REPO, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from asr_hip import shardcomm, synth
+    from asr_hip.pipeline import ImplicitPipeline
+    if fused:
+        pts, nrm = synth.fused_scan_cloud(fused, n_points // fused, seed=70, device=dev)
+    else:
+        pts, nrm = synth.scan_cloud(n_points, seed=55, device=dev, density_variance=10.0)
+    rad = synth.knn_radii_gpu(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    weights = synth.make_weights(channel_div, seed=6)
+    pipe = ImplicitPipeline(weights, device=dev, precision=precision)
+    comm = shardcomm.HostStagedComm()
+    full = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1]).clone()
+    again = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1])  # a second forward on the same context
+    info = {"rank": rank, "stats": pipe.shard_stats, "repeat_equal": bool(torch.equal(full, again)),
+            "host_exchanges": comm.exchanges}
+    if rank == 0:
+        single = ImplicitPipeline(weights, device=dev, precision=precision).forward(pts, nrm, rad, bb[0], bb[1])
+        info["equal"] = bool(torch.equal(full, single))
+        info["max_abs_diff"] = float((full - single).abs().max())
+        info["v0"] = int(single.shape[0])
+    out.put(info)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_points,channel_div,precision,fused",
+                         [(2, 30000, 2, "f32", 0), (3, 8000, 1, "f32", 0), (2, 30000, 1, "bf16x3", 0),
+                          (2, 30000, 1, "f16x2", 0), (3, 8000, 2, "f16x2", 0), (3, 64000, 2, "f16x2", 8)])
+def test_library_sharded_forward_equals_single_process(gpu, world, n_points, channel_div, precision, fused):
+    """asr_hip_implicit_forward_sharded with 2 - 3 processes on ONE GPU (transport: HostStagedComm over gloo; RCCL needs
+    one GPU per rank): ownership, owned row lists + plans, halo lists, packing, the MAX all-reduce of the f16x2 maxima
+    and the all-gather of the values all inside libasr_hip.so.  The complete values on every rank equal the
+    single-process forward bit for bit; fused = 8: BASELINE config C4 in small."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, n_points, channel_div, precision, out, fused))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    infos = sorted([out.get(timeout=900) for _ in range(world)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = infos[0]
+    assert r0["equal"], r0["max_abs_diff"]
+    assert all(i["repeat_equal"] for i in infos)
+    assert sum(i["stats"]["owned_rows"][0] for i in infos) == r0["v0"]
+    assert all(i["stats"]["halo_rows_recv"][0] > 0 and i["stats"]["exchanges"] > 40 for i in infos)
+    owned = [i["stats"]["owned_rows"][0] for i in infos]
+    assert max(owned) < 1.6 * min(owned)  # equal pair counts per rank give similar row counts
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+def test_library_sharded_forward_world_one_over_rccl(gpu, precision):
+    """world size 1 through the RCCL transport (ncclCommInitRank of one rank inside the library): the sharded driver with
+    every row owned equals the monolithic one bit for bit and adds no exchange"""
+    from asr_hip import shardcomm, synth
+    from asr_hip.pipeline import ImplicitPipeline
+    pts, nrm = synth.scan_cloud(40000, seed=9, device=gpu)
+    rad = synth.knn_radii_gpu(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    weights = synth.make_weights(2, seed=4)
+    pipe = ImplicitPipeline(weights, device=gpu, precision=precision)
+    single = pipe.forward(pts, nrm, rad, bb[0], bb[1]).clone()
+    comm = shardcomm.RcclComm(pipe.ctx)
+    full = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1])
+    assert torch.equal(full, single)
+    assert pipe.shard_stats["exchanges"] == 0 and pipe.shard_stats["owned_rows"][0] == single.shape[0]
+    comm.close()

@@ -123,6 +123,7 @@ class ShardStats(ctypes.Structure):
         ("bytes_sent", ctypes.c_int64),
         ("bytes_received", ctypes.c_int64),
         ("exchanges", ctypes.c_int64),
+        ("exchange_seconds", ctypes.c_double),
     ]
 
 

@@ -145,7 +145,7 @@ class ImplicitPipeline:
         self.sizes = sizes
         self.shard_stats = {"owned_rows": list(stats.owned_rows), "halo_rows_recv": list(stats.halo_rows_recv),
                             "bytes_sent": int(stats.bytes_sent), "bytes_received": int(stats.bytes_received),
-                            "exchanges": int(stats.exchanges)}
+                            "exchanges": int(stats.exchanges), "exchange_seconds": float(stats.exchange_seconds)}
         return self.get("values")
 
     def build(self, points, radii, bb_min, bb_max):

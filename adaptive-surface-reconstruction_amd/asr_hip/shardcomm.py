@@ -22,16 +22,31 @@ class RcclComm:
         self.ctx = ctx
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        uid = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            ctx.call("asr_hip_shard_comm_rccl_unique_id", uid)
-        if self.world > 1:
-            box = [bytes(uid.raw)]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            uid = ctypes.create_string_buffer(box[0], 128)
-        self._h = ctypes.POINTER(_lib.ShardComm)()
-        ctx.call("asr_hip_shard_comm_rccl_create", uid, ctypes.c_int(self.rank), ctypes.c_int(self.world),
-                 ctypes.byref(self._h))
+        # RCCL prints a version banner to STDOUT when it initialises: keep the caller's stdout clean (bench.py prints ONE
+        # json line there) by pointing fd 1 at stderr for the duration of the two calls
+        import os
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            uid = ctypes.create_string_buffer(128)
+            if self.rank == 0:
+                ctx.call("asr_hip_shard_comm_rccl_unique_id", uid)
+            if self.world > 1:
+                box = [bytes(uid.raw)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                uid = ctypes.create_string_buffer(box[0], 128)
+            self._h = ctypes.POINTER(_lib.ShardComm)()
+            ctx.call("asr_hip_shard_comm_rccl_create", uid, ctypes.c_int(self.rank), ctypes.c_int(self.world),
+                     ctypes.byref(self._h))
+        finally:
+            try:
+                ctypes.CDLL(None).fflush(None)  # the banner sits in C stdio's buffer: flush it while fd 1 is still stderr
+            except Exception:
+                pass
+            os.dup2(saved, 1)
+            os.close(saved)
 
     def handle(self):
         return self._h

@@ -632,11 +632,31 @@ def geometry_from_pipeline(pipe):
 
 class ShardedImplicitPipeline:
     """points / normals / radii (replicated on every rank) -> values[V0, 2] with the network half sharded
-    over the ranks of `group`; same call signature as ImplicitPipeline.forward."""
+    over the ranks of `group`; same call signature as ImplicitPipeline.forward.
+
+    native (default; ASR_SHARD_NATIVE=0 or native=False selects the Python reference implementation of this module):
+    the sharded forward INSIDE the library (asr_hip_implicit_forward_sharded, csrc/asr_shard.hip) -- ownership, row lists,
+    plans and halo lists on the device, packed point-to-point exchanges on the library's stream over RCCL
+    (shardcomm.RcclComm when the group's backend is nccl or there is no group; shardcomm.HostStagedComm otherwise).  Both
+    give the monolithic forward's values bit for bit (tests/test_gpu_sharded.py)."""
 
     def __init__(self, weights, device, group=None, point_radius_scale=1.0, octree_max_depth=21, scale_sdf=True,
-                 precision="f32"):
+                 precision="f32", native=None):
+        import os
         from .pipeline import ImplicitPipeline
+        if native is None:
+            native = os.environ.get("ASR_SHARD_NATIVE", "1") != "0"
+        self.native = bool(native)
+        self.precision = precision
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.net = None
+        self._comm = None
+        if self.native:
+            self.pipe = ImplicitPipeline(weights, device=device, point_radius_scale=point_radius_scale,
+                                         octree_max_depth=octree_max_depth, scale_sdf=scale_sdf, precision=precision)
+            return
         self.pipe = ImplicitPipeline(weights, device=device, point_radius_scale=point_radius_scale,
                                      octree_max_depth=octree_max_depth, scale_sdf=scale_sdf)
         self.backend = HipBackend(self.pipe.device, precision, group)
@@ -646,17 +666,60 @@ class ShardedImplicitPipeline:
         self.whole_cloud_aggregation = True
         # sharded_geometry: octree + voxel keys on every rank, neighbour lists, tiling orders, aggregation search and
         # continuous conv for the owned voxels only (sharded_geometry()); None: from 4 ranks on
-        import os
         env = os.environ.get("ASR_SHARDED_GEOMETRY")
         self.sharded_geometry = None if env is None else bool(int(env))
-        self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.net = None
+
+    # ---- reporting (both implementations) ----
+    @property
+    def num_voxels(self):
+        return [int(v) for v in self.pipe.sizes.num_voxels] if self.native else list(self.net.v)
+
+    @property
+    def owned_rows(self):
+        if self.native:
+            return [int(x) for x in self.pipe.shard_stats["owned_rows"]]
+        return [int(r.numel()) for r in self.net.rows]
+
+    @property
+    def halo_rows(self):
+        """rows received per application of a stencil, by list"""
+        if self.native:
+            return {"nb%d" % i: int(x) for i, x in enumerate(self.pipe.shard_stats["halo_rows_recv"])}
+        return {"%s%d" % k: v for k, v in self.net.halo_rows().items()}
+
+    def _native_comm(self):
+        if self._comm is None:
+            from . import shardcomm
+            backend = dist.get_backend(self.group) if dist.is_initialized() else None
+            if backend in (None, "nccl"):
+                self._comm = shardcomm.RcclComm(self.pipe.ctx, self.group)
+            else:
+                self._comm = shardcomm.HostStagedComm(self.group)
+        return self._comm
+
+    def instrumented_forward(self, points, normals, radii, bb_min, bb_max):
+        """one more forward with every halo exchange bracketed by device synchronisations ->
+        {"sent_bytes", "recv_bytes", "exchanges", "seconds"} of this rank (never part of a timed region)"""
+        if self.native:
+            self.pipe.ctx.set_option("shard_timing", 1)
+            try:
+                self.forward(points, normals, radii, bb_min, bb_max)
+            finally:
+                self.pipe.ctx.set_option("shard_timing", 0)
+            st = self.pipe.shard_stats
+            return {"sent_bytes": st["bytes_sent"], "recv_bytes": st["bytes_received"], "exchanges": st["exchanges"],
+                    "seconds": st["exchange_seconds"]}
+        reset_stats(timed=True)
+        self.forward(points, normals, radii, bb_min, bb_max)
+        st = dict(STATS)
+        reset_stats()
+        return {k: st[k] for k in ("sent_bytes", "recv_bytes", "exchanges", "seconds")}
 
     def forward(self, points, normals, radii, bb_min, bb_max):
         from . import _lib
         pipe = self.pipe
+        if self.native:
+            return pipe.forward_sharded(self._native_comm(), points, normals, radii, bb_min, bb_max)
         use_sg = self.sharded_geometry if self.sharded_geometry is not None else self.world >= 4
         if use_sg:
             frame = _lib.frame_init(bb_min, bb_max)

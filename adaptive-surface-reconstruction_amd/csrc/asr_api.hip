@@ -51,6 +51,7 @@ const OptEntry k_options[] = {
         {"cconv_valu", "ASR_CCONV_VALU", &AsrOptions::cconv_valu},
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
         {"search_priority", "ASR_SEARCH_PRIORITY", &AsrOptions::search_priority},
+        {"shard_timing", "ASR_SHARD_TIMING", &AsrOptions::shard_timing},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
 };
@@ -911,6 +912,35 @@ struct Net {
     }
 };
 
+}  // namespace
+// The auxiliary context of the aggregation search: its own stream, arenas, counters.  Stream priority (option
+// "search_priority", fixed when the stream is made): highest by default -- the search is the longer of the two chains of the
+// geometry build (round 4: 9.6 -> 8.8 ms on its stream); it used to be lowest so that its large grids would not starve the
+// small kernels of the main chain.  HIP maps streams to a small number of hardware queues (GPU_MAX_HW_QUEUES, default 4)
+// in creation order: a stream made after a library such as RCCL has made its own may share the main stream's queue, and
+// the two chains then run one after the other (geometry 13.5 instead of 9.5 ms at 10 M points).  asr_hip_shard_comm_rccl_create
+// therefore makes this stream first; processes that initialise RCCL before they create a context should raise
+// GPU_MAX_HW_QUEUES to 8 (bench.py does).
+int asr_ctx_ensure_aux(asr_hip_context* ctx) {
+    if (ctx->aux) return ASR_HIP_OK;
+    ASR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ctx->aux = new asr_hip_context();
+    ctx->aux->device = ctx->device;
+    memset(&ctx->aux->sizes, 0, sizeof(ctx->aux->sizes));
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const int prio = ctx->opt.search_priority >= 2 ? prio_greatest
+                     : (ctx->opt.search_priority == 1 ? (prio_least + prio_greatest) / 2 : prio_least);
+    ASR_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->aux->stream, hipStreamNonBlocking, prio));
+    ctx->aux_stream_owned = true;
+    ASR_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
+    ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t0));
+    ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t1));
+    ctx->aux->opt = ctx->opt;
+    return ASR_HIP_OK;
+}
+
+namespace {
 int implicit_build(asr_hip_context* ctx, const float* points, const float* radii, i64 n,
                    const asr_implicit_params* prm) {
     ASR_TRY(ensure_events(ctx));
@@ -938,23 +968,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     const bool overlap = want_search && ctx->opt.overlap != 0;
     asr_hip_context* sc = ctx;  // context the search runs on
     if (overlap) {
-        if (!ctx->aux) {
-            ctx->aux = new asr_hip_context();
-            ctx->aux->device = ctx->device;
-            memset(&ctx->aux->sizes, 0, sizeof(ctx->aux->sizes));
-            // lowest priority: the search's large grids must not starve the small kernels of the chain
-            // on the caller's stream
-            int prio_least = 0, prio_greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-            const int prio = ctx->opt.search_priority >= 2 ? prio_greatest
-                             : (ctx->opt.search_priority == 1 ? (prio_least + prio_greatest) / 2 : prio_least);
-            ASR_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->aux->stream, hipStreamNonBlocking, prio));
-            ctx->aux_stream_owned = true;
-            ASR_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->aux_ev, hipEventDisableTiming));
-            ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t0));
-            ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t1));
-            ctx->aux->opt = ctx->opt;
-        }
+        ASR_TRY(asr_ctx_ensure_aux(ctx));
         sc = ctx->aux;
         sc->persist.reset();
         sc->scratch.reset();

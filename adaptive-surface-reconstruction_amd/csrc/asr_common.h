@@ -109,6 +109,7 @@ struct AsrOptions {
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
+    i64 shard_timing = 0;         // sharded forward: synchronise around every halo exchange and accumulate its wall time
     i64 search_priority = 2;      // priority of the search's stream (set before the first build): 0 lowest, 1 middle, 2 highest
                                   // (round 4: the search is the longer of the two chains; 9.6 -> 8.8 ms on its stream)
     i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
@@ -313,6 +314,7 @@ __device__ static inline u64 asr_hash64(u64 k) {
     return k;
 }
 
+int asr_ctx_ensure_aux(asr_hip_context* ctx);  // the search's auxiliary context + stream (asr_api.hip)
 // one scan over several GPUs (asr_shard.hip): ownership, owned row lists / plans, halo lists of the 13 neighbour lists
 // of the last implicit_build; hooks of the network driver
 struct asr_shard_state;

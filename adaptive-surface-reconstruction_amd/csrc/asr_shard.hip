@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <vector>
 
@@ -505,9 +506,19 @@ int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void*
                                                                           row_dwords, imp, st->stage_send);
         ASR_CHECK_LAUNCH(ctx);
     }
+    const bool timed = ctx->opt.shard_timing != 0;
+    std::chrono::steady_clock::time_point t0;
+    if (timed) {
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        t0 = std::chrono::steady_clock::now();
+    }
     if (st->comm.exchange(st->comm.user, ds.npeer, c.send_peer.data(), sbuf.data(), sbytes.data(), dr.npeer,
                           c.recv_peer.data(), rbuf.data(), rbytes.data(), (void*)ctx->stream) != 0)
         ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the halo exchange failed");
+    if (timed) {
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        st->stats.exchange_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     if (nr > 0) {
         k_shard_unpack<<<grid_for(nr * per_row, BLK), BLK, 0, ctx->stream>>>(dr, c.recv_rows, (unsigned*)feat, ld_bytes / 4,
                                                                             row_dwords, imp, st->stage_recv);
@@ -668,6 +679,7 @@ int asr_hip_shard_comm_rccl_create(asr_hip_context* ctx, const void* unique_id, 
     *comm_out = nullptr;
     if (!rccl().ok()) ASR_FAIL(ctx, ASR_HIP_ENODEV, "librccl.so could not be loaded");
     ASR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    ASR_TRY(asr_ctx_ensure_aux(ctx));  // the search's stream before RCCL makes its own (hardware queues, see there)
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     RcclComm* c = new RcclComm();

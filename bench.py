@@ -24,6 +24,11 @@ import time
 
 import numpy as np
 
+# HIP maps streams to GPU_MAX_HW_QUEUES (default 4) hardware queues in creation order; with RCCL's own streams made first
+# (torch.distributed's communicator at N > 1) the library's search stream can land on the main stream's queue and the two
+# chains of the geometry build serialise (13.5 instead of 9.5 ms).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(REPO, "adaptive-surface-reconstruction_amd"), REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
@@ -394,16 +399,20 @@ def pipelined_rate(pipe, weights, dev, inputs, n, steps, depth=2):
 def one_scan_line(args, world, n, dt, sharded, extra):
     """bench line of the one-scan mode: ONE cloud over all ranks, total work fixed ("strong")"""
     steps = max(args.steps, 1)
-    net = sharded.net
-    cfg = {"workload": "C3 sharded: one %d-point scan-like synthetic cloud over %d GPU(s) by Morton range; octree + grids "
-                       "replicated (from 4 ranks on: neighbour lists, tiling orders and aggregation for the owned voxels "
-                       "only), 53 sparse convs + decoder on owned rows, halo exchange per convolution "
-                       "(RCCL grouped send/recv), values stitched by all-reduce" % (n, world),
+    how = ("inside the library (asr_hip_implicit_forward_sharded): geometry + aggregation replicated, 53 sparse convs on owned "
+           "rows with one packed RCCL send/recv group per convolution on the library's stream, decoder, values all-gathered"
+           if sharded.native else
+           "Python reference driver (asr_hip/sharding.py): octree + grids replicated (from 4 ranks on: neighbour lists, "
+           "tiling orders and aggregation for the owned voxels only), 53 sparse convs + decoder on owned rows, halo exchange "
+           "per convolution (RCCL grouped send/recv), values stitched by all-reduce")
+    cfg = {"workload": "C3 sharded: one %d-point scan-like synthetic cloud over %d GPU(s) by Morton range; %s"
+                       % (n, world, how),
            "precision": args.precision,
+           "sharded_driver": "library" if sharded.native else "python",
            "points": n,
-           "voxels": net.v,
-           "owned_rows_rank0": [int(r.numel()) for r in net.rows],
-           "halo_rows_rank0": {"%s%d" % k: v for k, v in net.halo_rows().items()},
+           "voxels": sharded.num_voxels,
+           "owned_rows_rank0": sharded.owned_rows,
+           "halo_rows_rank0": sharded.halo_rows,
            "parallelism": "spatial sharding, %d ranks" % world}
     cfg.update(extra)
     return {
@@ -436,7 +445,26 @@ def run_one_scan(args, world, rank, dev, weights, n, barrier, synth, fused=0):
         pts, nrm = synth.scan_cloud(n, seed=rank_seed(0), device=dev, density_variance=args.density_variance)
     radii = synth.knn_radii_gpu(pts, 24)
     bb_min, bb_max = synth.bounding_box(pts, 0.1)
-    sharded = ShardedImplicitPipeline(weights, dev, precision=args.precision if args.precision in SPLIT_PRODUCTS else "f32")
+    prec = args.precision if args.precision in SPLIT_PRODUCTS else "f32"
+    sharded = ShardedImplicitPipeline(weights, dev, precision=prec)
+    fallback = None
+    if sharded.native:
+        # The library's own driver over RCCL; should it fail on ANY rank (communicator, librccl.so), all ranks fall back
+        # together to the Python reference driver of asr_hip/sharding.py
+        ok = 1
+        try:
+            sharded.forward(pts, nrm, radii, bb_min, bb_max)
+        except Exception as e:
+            ok, fallback = 0, "%s: %s" % (type(e).__name__, e)
+        if world > 1:
+            t = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if not ok:
+            del sharded
+            torch.cuda.empty_cache()
+            sharded = ShardedImplicitPipeline(weights, dev, precision=prec, native=False)
+            fallback = fallback or "the library's sharded driver failed on another rank"
     for _ in range(args.warmup):
         sharded.forward(pts, nrm, radii, bb_min, bb_max)
     barrier()
@@ -445,15 +473,19 @@ def run_one_scan(args, world, rank, dev, weights, n, barrier, synth, fused=0):
         values = sharded.forward(pts, nrm, radii, bb_min, bb_max)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
-    assert values.shape[0] == sharded.net.v[0] and bool(torch.isfinite(values).all())
-    sharding.reset_stats(timed=True)   # one more step, instrumented: bytes and wall time of the halo exchanges
-    sharded.forward(pts, nrm, radii, bb_min, bb_max)
-    st = dict(sharding.STATS)
-    sharding.reset_stats()
+    assert values.shape[0] == sharded.num_voxels[0] and bool(torch.isfinite(values).all())
+    # one more step, instrumented: bytes and wall time of the halo exchanges
+    st = sharded.instrumented_forward(pts, nrm, radii, bb_min, bb_max)
     extra = {"halo_bytes_per_step_rank0": {"sent": st["sent_bytes"], "received": st["recv_bytes"]},
              "exchanges_per_step": st["exchanges"],
              "exchange_ms_rank0": round(st["seconds"] * 1e3, 3),
              "exchange_note": "instrumented extra step (device synchronised around every exchange), outside the timed region"}
+    if fallback:
+        extra["library_driver_error"] = fallback
+    try:
+        extra["stage_ms_rank0_last_step"] = {k: round(v, 3) for k, v in sharded.pipe.stage_ms().items()}
+    except Exception:
+        pass
     line = one_scan_line(args, world, n, dt, sharded, extra) if rank == 0 else None
     if line is not None and fused:
         line["scaling"] = "weak"

@@ -492,6 +492,8 @@ typedef struct asr_shard_stats {
     int64_t halo_rows_recv[ASR_NUM_GRIDS]; /* 55-slot lists: rows received per application of the level's stencil */
     int64_t bytes_sent, bytes_received;    /* halo exchanges + stitch of the last forward                       */
     int64_t exchanges;                     /* grouped exchanges of the last forward                              */
+    double exchange_seconds;               /* option "shard_timing": wall time of the exchanges, each bracketed by stream
+                                              synchronisations (instrumented runs only; 0 otherwise)             */
 } asr_shard_stats;
 
 /* values_out_dev [num_voxels[0], 2] complete on every rank (NULL: stays in the context, "values") */

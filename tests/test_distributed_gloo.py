@@ -94,6 +94,31 @@ def test_conv_flop_model_matches_survey():
     assert comp < 0.35 * alg and comp > 1959e6 + 371.5e6
 
 
+def test_one_scan_bench_line_shape():
+    """the line bench.py prints for N > 1 (one scan sharded over the GPUs): "strong" scaling, the halo traffic and
+    exchange time of rank 0, which driver ran -- assembled from a stand-in for the sharded pipeline (no GPU here)"""
+    sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd")]
+    import argparse
+    import json
+    import bench
+
+    class Sharded:
+        native = True
+        num_voxels = [1000, 300, 90, 30, 10]
+        owned_rows = [500, 150, 45, 15, 5]
+        halo_rows = {"nb0": 40, "nb1": 20, "nb2": 10, "nb3": 5, "nb4": 2}
+
+    args = argparse.Namespace(steps=4, warmup=1, precision="f16x2")
+    extra = {"halo_bytes_per_step_rank0": {"sent": 123, "received": 456}, "exchanges_per_step": 54, "exchange_ms_rank0": 1.5}
+    line = json.loads(json.dumps(bench.one_scan_line(args, 2, 10000, 0.2, Sharded(), extra)))
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["unit"] == "points/s"
+    assert abs(line["value"] - 10000 * 4 / 0.2) < 1e-6 and abs(line["ms_per_step"] - 50.0) < 1e-9
+    cfg = line["config"]
+    assert cfg["halo_bytes_per_step_rank0"] == {"sent": 123, "received": 456} and cfg["exchange_ms_rank0"] == 1.5
+    assert cfg["sharded_driver"] == "library" and cfg["owned_rows_rank0"][0] == 500 and "workload" in cfg
+    assert "f16x2" in line["dtype"] and "arithmetic" in line
+
+
 # ---- one scan across ranks: partition + halo exchange (SURVEY 8(e)) ----------------------------------
 def _shard_worker(rank, world, port, n_points, out):
     sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd"), os.path.join(REPO, "tests")]

@@ -41,7 +41,7 @@ def _worker(rank, world, port, n_points, channel_div, precision, out, fused=0, s
     rad = synth.knn_radii_gpu(pts, 24)
     bb = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(channel_div, seed=6)
-    sp = sharding.ShardedImplicitPipeline(weights, dev, precision=precision)
+    sp = sharding.ShardedImplicitPipeline(weights, dev, precision=precision, native=False)  # the Python reference driver
     sp.sharded_geometry = bool(sharded_geometry)
     full = sp.forward(pts, nrm, rad, bb[0], bb[1])
     info = {"rank": rank, "owned": [int(r.numel()) for r in sp.net.rows], "halo": sp.net.halo_rows()}

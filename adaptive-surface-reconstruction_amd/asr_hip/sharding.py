@@ -546,7 +546,7 @@ class HipBackend:
         idx, kidx, rs = csr
         fresh = out is None
         if out is None:  # only the owned rows are written; the others are never read before an exchange fills them
-            out = torch.empty((v_out, kernel.shape[2]), dtype=torch.float32, device=self.device)
+            out = self._new_out((v_out, kernel.shape[2]))
         if self.precision != "f32" and x.shape[1] % 4 == 0:
             perm, plan = self._plan(kernel.shape[0], csr, rows)
             m_in, m_out = self._amax_in(x), self._amax_out(out, fresh)
@@ -557,9 +557,21 @@ class HipBackend:
             if m_out is not None:
                 self._max_over_ranks(m_out)
             return r
+        # f32 kernel (also the fallback of the 16-bit modes for cin % 4 != 0): no running maximum is kept for `out`; a stale
+        # entry of an earlier buffer at the same address must not survive (the consumer then takes one pass over the
+        # buffer -- zero outside the owned rows, see _new_out -- and the maximum over the ranks)
+        self._amax.pop(out.untyped_storage().data_ptr(), None)
         return ops.sparse_conv(kernel, x, idx, kidx, rs, inp_importance=imp, normalize=normalize, bias=bias,
                                relu=True, residual=residual, out=out, return_importance=imp is not None,
                                row_perm=self._rows32(rows), num_rows=rows.numel())
+
+    def _new_out(self, shape):
+        """output buffer of a convolution.  f16x2: zero-filled, because a consumer whose producer kept no running maximum
+        (f32 fallback, non-fused conv1a / conv1b) scans ALL rows for the scale, and the rows this rank does not own would
+        otherwise hold whatever the allocator left there (NaN / Inf would wreck the scale)"""
+        if self.precision == "f16x2":
+            return torch.zeros(shape, dtype=torch.float32, device=self.device)
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     def _rows32(self, rows):
         key = (rows.data_ptr(), int(rows.numel()))
@@ -574,7 +586,7 @@ class HipBackend:
         ca, cb = ka.shape[2], kb.shape[2]
         fresh = out is None
         if out is None:
-            out = torch.empty((v_out, ca + cb), dtype=torch.float32, device=self.device)
+            out = self._new_out((v_out, ca + cb))
         fused = ca % 16 == 8 and cb == 8 and x.shape[1] % 4 == 0
         if fused and self.precision != "f32":
             perm, plan = self._plan(ka.shape[0], csr, rows)
@@ -595,6 +607,7 @@ class HipBackend:
         b, oimp = self.sparse_conv(kb, bb, x, csr, rows, v_out, imp, True)
         out[:, :ca] = a
         out[:, ca:] = b
+        self._amax.pop(out.untyped_storage().data_ptr(), None)  # no running maximum for the assembled buffer
         return out, oimp
 
     def aggregate(self, points, normals, radii, frame, centers, sizes, kernel, bias):

@@ -533,6 +533,20 @@ __device__ inline int neighbors_of_row(const u64* keys, i64 i, const HashTab& t,
     }
     return n;
 }
+// public row lists / key lists are caller data: a bad entry must become an error, not an out-of-bounds write
+__global__ void k_check_rows(const int32_t* rows, i64 nrows, i64 v, int* cnt) {
+    const i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const i64 q = rows[r];
+    if (q < 0 || q >= v || (r > 0 && rows[r - 1] >= q)) cnt[3] = 1;  // in range, strictly ascending
+}
+__global__ void k_check_keys(const u64* keys, i64 n, int* cnt) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = keys[i];
+    // a location code: leading bit at position 3 * level, level <= ASR_MAX_LEVEL (0 is the tables' empty sentinel)
+    if (k == 0 || (63 - __clzll((long long)k)) % 3 != 0) cnt[3] = 1;
+}
 __global__ void k_neighbors_count_rows(const u64* keys, HashTab t, const int32_t* rows, i64 nrows, i64* counts) {
     const i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (r >= nrows) return;
@@ -2119,6 +2133,8 @@ static int grow_keys(asr_hip_context* ctx, Arena& arena, const asr_octree_frame*
                                                              ctx->d_flags, list, lcap);
         ASR_CHECK_LAUNCH(ctx);
         ASR_TRY(read_flags(ctx, host));
+        if (host[3]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree: extra_keys holds a value that is no location code (0 or a leading "
+                                                   "bit that is not at 3 * level)");
         if (host[11]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "octree: points / radii contain non-finite values");
         bool overflow = host[1] != 0;
         int lo = 0, hi = host[0];
@@ -2191,6 +2207,8 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
             ASR_CHECK_LAUNCH(ctx);
         }
         if (num_extra > 0) {  // node keys of other builds (the local octrees of the other ranks): same closure
+            k_check_keys<<<grid_for(num_extra, BLK), BLK, 0, ctx->stream>>>(extra_keys, num_extra, ctx->d_flags);
+            ASR_CHECK_LAUNCH(ctx);
             k_octree_insert_keys<<<grid_for(num_extra, BLK), BLK, 0, ctx->stream>>>(extra_keys, num_extra, t, ctx->d_flags,
                                                                                    list, lcap);
             ASR_CHECK_LAUNCH(ctx);
@@ -2289,6 +2307,17 @@ static int build_key_map_complete(asr_hip_context* ctx, const u64* keys, i64 v, 
     }
 }
 
+static int check_row_list(asr_hip_context* ctx, const int32_t* rows, i64 nrows, i64 v) {
+    ASR_TRY(ensure_flags(ctx));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags + 3, 0, sizeof(int), ctx->stream));
+    k_check_rows<<<grid_for(nrows, BLK), BLK, 0, ctx->stream>>>(rows, nrows, v, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    int host[16];
+    ASR_TRY(read_flags(ctx, host));
+    if (host[3]) ASR_FAIL(ctx, ASR_HIP_EINVAL, "neighbour rows: the row list must be strictly ascending indices in [0, %lld)", (long long)v);
+    return ASR_HIP_OK;
+}
+
 int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* rs, i64* num_pairs) {
     if (v <= 0) {
         *num_pairs = 0;
@@ -2327,6 +2356,7 @@ int asr_geom_neighbors_rows_count(asr_hip_context* ctx, const u64* keys, i64 v, 
     if (!counts) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, (v + 1) * sizeof(i64), ctx->stream));
     if (nrows > 0) {
+        ASR_TRY(check_row_list(ctx, rows, nrows, v));
         k_neighbors_count_rows<<<grid_for(nrows, BLK), BLK, 0, ctx->stream>>>(keys, t, rows, nrows, counts);
         ASR_CHECK_LAUNCH(ctx);
     }
@@ -2339,6 +2369,7 @@ int asr_geom_neighbors_rows_fill(asr_hip_context* ctx, const u64* keys, i64 v, c
     if (v <= 0 || nrows <= 0) return ASR_HIP_OK;
     HashTab t;
     ASR_TRY(build_key_map_complete(ctx, keys, v, t));
+    ASR_TRY(check_row_list(ctx, rows, nrows, v));
     k_neighbors_fill_rows<<<grid_for(nrows, BLK), BLK, 0, ctx->stream>>>(keys, t, rows, nrows, rs, idx, kidx);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;

@@ -3,7 +3,7 @@
 // TorchScript caller -- asr::ReconstructSurface runs model.pt through module.run_method (cpp/lib/asr.cpp:315-326) --
 // reaches the HIP kernels without a Python interpreter: load libasr_open3d_ops.so (torch.ops.load_library in Python,
 // dlopen / link in C++) next to libasr_hip.so.  Every op unpacks pointers and sizes and calls the C ABI
-// (include/asr_hip.h) on torch's current stream; one library context per (thread, device).  Same argument checks as the Python
+// (include/asr_hip.h) on torch's current stream; one library context per device, held under a mutex per op.  Same argument checks as the Python
 // registration (open3d/ml/torch/ops.py), which must not be imported into the same process (one definition per schema).
 #include <ATen/ATen.h>
 #include <ATen/hip/HIPContext.h>
@@ -11,32 +11,46 @@
 #include <torch/library.h>
 
 #include <map>
+#include <mutex>
 #include <tuple>
 
 #include "../../../include/asr_hip.h"
 
 namespace {
 
-// One library context per (thread, device): a context -- its stream, arenas and error text -- is not thread safe, and
-// libtorch callers may run ops of one GPU from several threads (jit fork, multi-threaded C++ programs).
-struct ThreadContexts {
-    std::map<int, asr_hip_context*> ctxs;
-    ~ThreadContexts() {
-        for (auto& kv : ctxs) asr_hip_context_destroy(kv.second);
-    }
+// ONE library context per device, shared by all calling threads and held under a mutex for the duration of an op: a
+// context -- its stream, arenas and error text -- is not thread safe, and libtorch callers may run ops of one GPU from
+// several threads (jit fork, multi-threaded C++ programs).  (Per-thread contexts multiplied the arenas, the auxiliary
+// stream and the packed-weight cache by the number of threads.)  The contexts are never destroyed: at process exit the HIP
+// runtime may already be gone when static destructors run.
+struct DeviceContext {
+    std::mutex mu;
+    asr_hip_context* ctx = nullptr;
 };
-asr_hip_context* context_for(const at::Tensor& t) {
-    static thread_local ThreadContexts tc;
+struct Locked {
+    std::unique_lock<std::mutex> lock;
+    asr_hip_context* c;
+};
+Locked context_for(const at::Tensor& t) {
+    static std::mutex table_mu;
+    static std::map<int, DeviceContext*>* table = new std::map<int, DeviceContext*>();  // leaked on purpose
     TORCH_CHECK(t.is_cuda(), "open3d ops (asr_hip): tensors must live on the GPU");
     const int dev = t.get_device();
-    asr_hip_context*& c = tc.ctxs[dev];
-    auto stream = at::hip::getCurrentHIPStream(dev).stream();
-    if (!c) {
-        c10::DeviceGuard guard(t.device());
-        TORCH_CHECK(asr_hip_context_create(&c, stream) == ASR_HIP_OK, "asr_hip_context_create failed");
+    DeviceContext* dc;
+    {
+        std::lock_guard<std::mutex> g(table_mu);
+        DeviceContext*& slot = (*table)[dev];
+        if (!slot) slot = new DeviceContext();
+        dc = slot;
     }
-    asr_hip_context_set_stream(c, stream);
-    return c;
+    std::unique_lock<std::mutex> lock(dc->mu);
+    auto stream = at::hip::getCurrentHIPStream(dev).stream();
+    if (!dc->ctx) {
+        c10::DeviceGuard guard(t.device());
+        TORCH_CHECK(asr_hip_context_create(&dc->ctx, stream) == ASR_HIP_OK, "asr_hip_context_create failed");
+    }
+    asr_hip_context_set_stream(dc->ctx, stream);
+    return Locked{std::move(lock), dc->ctx};
 }
 
 void check(asr_hip_context* c, int rc, const char* what) {
@@ -78,7 +92,8 @@ at::Tensor sparse_conv(const at::Tensor& filters, const at::Tensor& inp_features
     a.normalize = normalize ? 1 : 0;
     a.out = out.data_ptr<float>();
     a.out_ld = out.stride(0);
-    asr_hip_context* c = context_for(w);
+    Locked held = context_for(w);  // released when the op returns
+    asr_hip_context* c = held.c;
     check(c, asr_hip_sparse_conv_f32(c, &a), "sparse_conv");
     return out;
 }
@@ -107,7 +122,8 @@ at::Tensor continuous_conv(const at::Tensor& filters, const at::Tensor& out_posi
     at::Tensor nimp;
     if (neighbors_importance.numel()) nimp = dev_as(neighbors_importance, at::kFloat, dev);
     at::Tensor out = at::empty({v, w.size(4)}, f.options());
-    asr_hip_context* c = context_for(w);
+    Locked held = context_for(w);  // released when the op returns
+    asr_hip_context* c = held.c;
     check(c,
           asr_hip_continuous_conv_f32(c, w.data_ptr<float>(), op.data_ptr<float>(), ext.data_ptr<float>(),
                                       ip.data_ptr<float>(), f.data_ptr<float>(), idx.data_ptr<int32_t>(),
@@ -128,7 +144,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> invert_neighbors_list(int64_t num
     at::Tensor out_idx = at::empty({idx.size(0)}, idx.options());
     at::Tensor out_rs = at::empty({num_points + 1}, rs.options());
     at::Tensor out_attr = has_attr ? at::empty({idx.size(0)}, attr.options()) : at::empty({0}, inp_attributes.options());
-    asr_hip_context* c = context_for(idx);
+    Locked held = context_for(idx);  // released when the op returns
+    asr_hip_context* c = held.c;
     check(c,
           asr_hip_invert_neighbors_list(c, num_points, idx.data_ptr<int32_t>(), rs.data_ptr<int64_t>(), rs.size(0) - 1,
                                         has_attr ? attr.data_ptr<uint8_t>() : nullptr, out_idx.data_ptr<int32_t>(),
@@ -143,7 +160,8 @@ at::Tensor reduce_subarrays_sum(const at::Tensor& values, const at::Tensor& row_
     const at::Tensor val = dev_as(values, at::kFloat, dev), rs = dev_as(row_splits, at::kLong, dev);
     const int64_t rows = rs.size(0) - 1;
     at::Tensor out = at::empty({rows}, val.options());
-    asr_hip_context* c = context_for(val);
+    Locked held = context_for(val);  // released when the op returns
+    asr_hip_context* c = held.c;
     check(c, asr_hip_reduce_subarrays_sum(c, val.data_ptr<float>(), nullptr, rs.data_ptr<int64_t>(), rows, out.data_ptr<float>()),
           "reduce_subarrays_sum");
     return out;

@@ -41,7 +41,6 @@ const OptEntry k_options[] = {
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"row_ranked", "ASR_ROW_RANKED", &AsrOptions::row_ranked},
         {"sconv_plan", "ASR_SCONV_PLAN", &AsrOptions::sconv_plan},
-        {"sconv_deep", "ASR_SCONV_DEEP", &AsrOptions::sconv_deep},
         {"plan_arena", "ASR_PLAN_ARENA", &AsrOptions::plan_arena},
         {"sconv16_min_blocks", "ASR_SCONV16_MIN_BLOCKS", &AsrOptions::sconv16_min_blocks},
         {"knn_cells", "ASR_KNN_CELLS", &AsrOptions::knn_cells},

@@ -103,7 +103,6 @@ struct AsrOptions {
     i64 knn_cells = 1;            // kNN radius: cell-parallel fast path (0: wave per point only)
     i64 plan_arena = 0;           // asr_hip_sparse_conv_plan_create: 1 = memory from the context's plan arena (no hipMalloc /
                                   // hipFree per plan; all such plans die with asr_hip_context_plan_arena_reset)
-    i64 sconv_deep = 1;           // 16-bit sparse conv, small grids: the deep-pipelined kernel k_sconv_deep16 (0: k_sconv_plan16)
     i64 sconv_plan = 1;           // 16-bit sparse conv: plan-driven kernel where it applies (0: table-driven)
     i64 row_ranked = 1;           // row regrouping: sort on (job, segment, rank of the slot mask) keys, all lists in one sort
     i64 row_lpt = 1;              // longest-first order of the 128-row chunks of a segment

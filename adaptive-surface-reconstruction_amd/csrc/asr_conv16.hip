@@ -947,260 +947,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
 }
 
 
-// ------------------------------------------------------------------------------------------
-// The small-grid kernel (round 4): the same plan-driven gather-GEMM with a DEEP software pipeline.  On the grids of a few
-// 10^4 rows (levels 3 - 4 of the hierarchy) a CU holds one or two 64-row blocks, so nothing hides the latency of a step's
-// weight panel (L2 -> LDS) and of its gathered rows: k_sconv_plan16 issues both one step ahead, a step's MFMAs take 0.05 -
-// 0.2 us, and a step costs ~1 us whatever the column tile (measured: the levels cost the same with NT 2 x 8 chunks and with
-// NT 8 x 2 chunks).  Here a block keeps a RING of four panel buffers -- the panel of step s + 3 is in flight while step s
-// computes -- and four register sets of gathered rows (step s + 4 in flight), and a wave loads ALL neighbour indices of its
-// 16-row group into LDS up front (<= 55 slots x 64 bytes) instead of chasing them one slot ahead.  Every step issues the same
-// sequence of memory instructions, so one counted wait per step (the panel of the NEXT step has landed once at most
-// 2 panel DMAs + 3 gather sets issued after it are in flight) and one barrier order the ring; the loop is unrolled four
-// times so that every buffer and register set is a compile-time name (runtime ring indices make the compiler wait for ALL
-// outstanding DMA in front of every fragment read).  Plain convolutions only (no per-row weights): the two-bank layers of
-// the small grids stay on k_sconv_plan16.  Same tiles, arithmetic and epilogue: results equal k_sconv_plan16's.
-// ------------------------------------------------------------------------------------------
-template <int NT, int KC, int MODE>
-__global__ __launch_bounds__(256, 2) void k_sconv_deep16(asr_sparse_conv_args a, asr_conv_plan_view plan,
-                                                         const u16* __restrict__ packed, int cin_pad, int ctot_pad,
-                                                         int out_f16, const float* __restrict__ zeros) {
-    constexpr int WAVES = 4;
-    constexpr int TM = WAVES * 16;
-    constexpr int NCOL = NT * 16;
-    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : (MODE == ASR_CONV16_F16X2 ? 2 : 1);
-    constexpr int SLOTS = KC / 8;
-    constexpr int NJ = KC / 32;
-    constexpr int PV = PLANES * NCOL * SLOTS;
-    constexpr int PLANE_PIECES = NCOL * SLOTS;
-    constexpr int NCHUNK = PV / 64;
-    constexpr int CHUNKS_PER_PLANE = PLANE_PIECES / 64;
-    constexpr int SV = (NCHUNK + WAVES - 1) / WAVES;
-    constexpr int AW = MODE == ASR_CONV16_F16 ? 1 : 2;
-    constexpr int ESZ = MODE == ASR_CONV16_F16 ? 2 : 4;
-    constexpr int G = NJ * AW;  // gather loads per lane and step
-    static_assert(NCHUNK % WAVES == 0, "every wave must issue the same number of panel DMAs per step (counted waits)");
-    __shared__ __attribute__((aligned(16))) u32x4 s_B0[PV];
-    __shared__ __attribute__((aligned(16))) u32x4 s_B1[PV];
-    __shared__ __attribute__((aligned(16))) u32x4 s_B2[PV];
-    __shared__ __attribute__((aligned(16))) u32x4 s_B3[PV];
-    __shared__ int s_idx[WAVES][56][16];
-    __shared__ unsigned long long s_wm[WAVES];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int nY = ctot_pad / NCOL;
-    i64 tile = blockIdx.x;
-    int ychunk = 0;
-    if (nY > 1) {  // column chunks of one row tile on one XCD, consecutive dispatch slots (see k_sconv_mfma)
-        const i64 r8 = blockIdx.x >> 3;
-        ychunk = (int)(r8 % nY);
-        tile = (r8 / nY) * 8 + (blockIdx.x & 7);
-    }
-    const i64 row0 = tile * TM;
-    if (row0 >= a.num_out) return;
-    const int n0 = ychunk * NCOL;
-    const int K = a.kernel_size;
-    const int cin = a.cin;
-    const int r = lane & 15, g = lane >> 4;
-    const int ncol = r;
-
-    const i64 grp = tile * WAVES + wave;
-    uint4 h = make_uint4(0, 0, 0, 0);
-    if (grp < plan.groups) h = plan.hdr[grp];
-    const unsigned long long wmask =
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.x) |
-             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.y) << 32)) & ((1ull << K) - 1);
-    const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane((int)h.z);
-    if (lane == 0) s_wm[wave] = wmask;
-    constexpr unsigned OOB_OFF = 0xFFFFE000u;
-    constexpr int RSRC_FLAGS = 0x00020000;
-    // all neighbour indices of the wave's group: slot rank q (ascending slots) -> 16 indices, 4 slots per load
-    {
-        const __amdgpu_buffer_rsrc_t rs_p =
-                __builtin_amdgcn_make_buffer_rsrc((void*)plan.pool, 0, (int)plan.pool_bytes, RSRC_FLAGS);
-        const int nslot = __popcll(wmask);
-        for (int q0 = 0; q0 < nslot; q0 += 4) {
-            const int q = q0 + g;
-            const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, q < nslot ? (int)((woff + (unsigned)q) * 64u + r * 4) : (int)OOB_OFF,
-                                                                    0, 0);
-            if (q < nslot) s_idx[wave][q][r] = v;
-        }
-    }
-    __syncthreads();
-    unsigned long long bmask = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) bmask |= s_wm[w];
-    bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
-
-    f32x4 acc[NT];
-    f32x4 tacc[1];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
-    tacc[0] = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 acc_b = {0.f, 0.f, 0.f, 0.f};
-    const float norm4[4] = {0.f, 0.f, 0.f, 0.f};
-
-    const int npanel = (cin + KC - 1) / KC;
-    const i64 plane_stride = (i64)K * ctot_pad * cin_pad;
-    float a_scale = 1.f, unscale[2] = {1.f, 1.f};
-    if constexpr (MODE == ASR_CONV16_F16X2) {
-        const int sa = f16x2_scale_exp(*a.inp_absmax);
-        const int un = -(sa + *(const int*)(packed + PLANES * plane_stride));
-        a_scale = f16x2_pow2(sa);
-        unscale[0] = f16x2_pow2(un / 2);
-        unscale[1] = f16x2_pow2(un - un / 2);
-    }
-    const __amdgpu_buffer_rsrc_t rs_w =
-            __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, (int)(PLANES * plane_stride * 2), RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)a.inp_features, 0, (int)(unsigned)(a.num_inp > 0 ? ((a.num_inp - 1) * a.inp_ld + cin) * ESZ : 0),
-            RSRC_FLAGS);
-    const int lane16 = lane * 16;
-    unsigned w_soff[SV];
-#pragma unroll
-    for (int s = 0; s < SV; ++s) {
-        const int c = s * WAVES + wave;
-        const int pl = c / CHUNKS_PER_PLANE, ci = c % CHUNKS_PER_PLANE;
-        w_soff[s] = (unsigned)((pl * plane_stride + (i64)n0 * KC) * 2 + ci * 1024);
-    }
-    auto dma_panel = [&](const int qk, const int qp, u32x4* dst) __attribute__((always_inline)) {
-        // (wave-uniform by construction; said explicitly, else the loop-carried slot index makes the compiler wrap every
-        // DMA in a waterfall loop, which also costs it the precise wait counts of the gathers)
-        const int soff = __builtin_amdgcn_readfirstlane((((qk < 0 ? 0 : qk) * npanel + qp) * ctot_pad * KC) * 2);
-#pragma unroll
-        for (int s = 0; s < SV; ++s) {
-            const int c = s * WAVES + wave;
-            if (NCHUNK % WAVES == 0 || c < NCHUNK)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)&dst[c * 64], 16,
-                                                         lane16, soff + (int)w_soff[s], 0, 0);
-        }
-    };
-    auto gather_a = [&](const int qk, const int qp, u32x4 (&aq)[G]) __attribute__((always_inline)) {
-        unsigned off = OOB_OFF;
-        const int uk = __builtin_amdgcn_readfirstlane(qk);
-        if (uk >= 0 && ((wmask >> uk) & 1)) {
-            const int idx = s_idx[wave][__popcll(wmask & ((1ull << uk) - 1))][r];
-            if (idx >= 0) off = (unsigned)idx * (unsigned)(a.inp_ld * ESZ) + (unsigned)(8 * g * ESZ);
-        }
-        const int soff = __builtin_amdgcn_readfirstlane(qp * KC * ESZ);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int hh = 0; hh < AW; ++hh)
-                aq[j * AW + hh] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)off + (32 * j + 4 * hh) * ESZ, soff, 0);
-    };
-#define ASR_SEQ_ADVANCE(todo, k, p)                          \
-    if ((k) >= 0 && ++(p) == npanel) {                       \
-        (p) = 0;                                             \
-        (todo) &= (todo)-1;                                  \
-        (k) = (todo) ? __builtin_ctzll(todo) : -1;           \
-    }
-    // (slot, panel) of the steps s .. s + 4
-    unsigned long long todo = bmask;
-    int k0 = bmask ? __builtin_ctzll(bmask) : -1, p0 = 0;
-    int k1 = k0, p1 = p0;
-    ASR_SEQ_ADVANCE(todo, k1, p1)
-    int k2 = k1, p2 = p1;
-    ASR_SEQ_ADVANCE(todo, k2, p2)
-    int k3 = k2, p3 = p2;
-    ASR_SEQ_ADVANCE(todo, k3, p3)
-    int k4 = k3, p4 = p3;
-    ASR_SEQ_ADVANCE(todo, k4, p4)
-    u32x4 q0[G], q1[G], q2[G], q3[G];
-    if (k0 >= 0) {
-        dma_panel(k0, p0, s_B0);
-        dma_panel(k1, p1, s_B1);
-        dma_panel(k2, p2, s_B2);
-        gather_a(k0, p0, q0);
-        gather_a(k1, p1, q1);
-        gather_a(k2, p2, q2);
-        gather_a(k3, p3, q3);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // Tell the compiler's wait-count pass that the four register sets have arrived (it does not read the asm wait above):
-    // otherwise the loop header inherits "just issued" from this path and the first step of every unrolled round drains the
-    // pipeline down to its own panel DMAs.
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-        asm volatile("" : "+v"(q0[i]));
-        asm volatile("" : "+v"(q1[i]));
-        asm volatile("" : "+v"(q2[i]));
-        asm volatile("" : "+v"(q3[i]));
-    }
-    // one step: (k0, p0) with its panel in `cur` and its rows in `aq`; the panel of step + 3 goes to `nxt3`
-    auto step = [&](u32x4 (&aq)[G], const u32x4* cur, u32x4* nxt3) __attribute__((always_inline)) {
-        dma_panel(k3, p3, nxt3);  // first memory instruction of the step: the counted wait below relies on the order
-        __builtin_amdgcn_sched_barrier(0);
-        const bool active = (wmask >> k0) & 1;
-        u32x4 fa[NJ][PLANES];
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if constexpr (MODE == ASR_CONV16_F16) {
-                    fa[j][0] = aq[j];
-                } else if constexpr (MODE == ASR_CONV16_F16X2) {
-                    sconv16_split_f16x2(aq[j * 2], aq[j * 2 + 1], a_scale, fa[j][0], fa[j][PLANES > 1 ? 1 : 0]);
-                } else {
-                    unsigned s0[4], s1[4], s2[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x2 v = {__uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1)]),
-                                         __uint_as_float(aq[j * 2 + (i >> 1)][2 * (i & 1) + 1])};
-                        s0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-                        const f32x2 r1 = {v.x - __uint_as_float(s0[i] << 16), v.y - __uint_as_float(s0[i] & 0xffff0000u)};
-                        s1[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-                        const f32x2 r2 = {r1.x - __uint_as_float(s1[i] << 16), r1.y - __uint_as_float(s1[i] & 0xffff0000u)};
-                        s2[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-                    }
-                    fa[j][0] = (u32x4){s0[0], s0[1], s0[2], s0[3]};
-                    fa[j][PLANES > 1 ? 1 : 0] = (u32x4){s1[0], s1[1], s1[2], s1[3]};
-                    fa[j][PLANES > 2 ? 2 : 0] = (u32x4){s2[0], s2[1], s2[2], s2[3]};
-                }
-            }
-        }
-        gather_a(k4, p4, aq);  // rows of step + 4 into the registers this step has just consumed
-        if (active) {
-            __builtin_amdgcn_s_setprio(1);
-            sconv16_products<NT, KC, MODE, false, false, PLANES, NJ>(fa, cur, acc, tacc, false, ncol, g);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        // the panel of the NEXT step was the first instruction of step - 2: at least 2 panel DMAs and 3 gather sets
-        // have been issued after it
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SV + 3 * G) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        k0 = k1; p0 = p1;
-        k1 = k2; p1 = p2;
-        k2 = k3; p2 = p3;
-        k3 = k4; p3 = p4;
-        ASR_SEQ_ADVANCE(todo, k4, p4)
-    };
-    while (k0 >= 0) {
-        step(q0, s_B0, s_B3);
-        if (k0 < 0) break;
-        step(q1, s_B1, s_B0);
-        if (k0 < 0) break;
-        step(q2, s_B2, s_B1);
-        if (k0 < 0) break;
-        step(q3, s_B3, s_B2);
-    }
-#undef ASR_SEQ_ADVANCE
-    // the DMAs of the steps beyond the end are still in flight: they must not land in the LDS of a later block
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    int q4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const i64 lr = row0 + wave * 16 + 4 * g + i;
-        q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
-    }
-    sconv16_epilogue<NT, MODE, false>(a, acc, acc_b, q4, norm4, n0, ncol, a.cout, a.cout, false, out_f16, zeros, unscale);
-}
-
 }  // namespace
 
 // ==========================================================================================
@@ -1319,32 +1065,6 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
         if (plan->num_out != a.num_out || plan->K < a.kernel_size || plan->perm != a.row_perm)
             ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: the plan was built for another list");
         pv = plan->view();
-    }
-    // small grids (4-wave blocks), plain convolutions: the deep-pipelined kernel with the widest column tile (see there)
-    const int nt_deep = ctot_pad % 128 == 0 ? 8 : (ctot_pad % 64 == 0 ? 4 : 0);
-    const bool deep = use_plan && ctx->opt.sconv_deep && !wide && !dual && !imp && !a.normalize && !a.out_importance &&
-                      !a.force_nt && !a.force_waves && nt_deep != 0 && a.kernel_size <= 56;
-    if (deep) {
-        const i64 tiles_ = (a.num_out + 63) / 64;
-        const i64 ny_ = ctot_pad / (nt_deep * 16);
-        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));
-#define ASR_DEEP(NT_, KC_, M_) \
-    k_sconv_deep16<NT_, KC_, M_><<<grid, dim3(256), 0, ctx->stream>>>(a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros)
-        if (mode == ASR_CONV16_F16X2) {
-            if (nt_deep == 8) ASR_DEEP(8, 32, ASR_CONV16_F16X2); else ASR_DEEP(4, 32, ASR_CONV16_F16X2);
-        } else if (mode == ASR_CONV16_BF16X3) {
-            if (nt_deep == 8) ASR_DEEP(8, 32, ASR_CONV16_BF16X3); else ASR_DEEP(4, 32, ASR_CONV16_BF16X3);
-        } else if (kc64) {
-            if (nt_deep == 8) ASR_DEEP(8, 64, ASR_CONV16_F16); else ASR_DEEP(4, 64, ASR_CONV16_F16);
-        } else {
-            if (nt_deep == 8) ASR_DEEP(8, 32, ASR_CONV16_F16); else ASR_DEEP(4, 32, ASR_CONV16_F16);
-        }
-#undef ASR_DEEP
-        ASR_CHECK_LAUNCH(ctx);
-        char key[64];  // PLAN field 2: k_sconv_deep16
-        snprintf(key, sizeof(key), "%d,%d,0,4,0,%d,2", nt_deep, kc64 ? 64 : 32, mode);
-        ++ctx->sconv_launches[key];
-        return ASR_HIP_OK;
     }
 #define ASR_L16(NT_, KC_, W_, M_, I_, D_)                                                                        \
     {                                                                                                            \

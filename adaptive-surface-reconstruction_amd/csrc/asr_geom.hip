@@ -1966,11 +1966,13 @@ __global__ __launch_bounds__(1024) void k_rg_mask_ranks(HashTab t, int* cnt) {
     const int n = s_n;
     if (threadIdx.x == 0) cnt[2] = n;
     if (n > RG_MAX_MASKS) return;
-    for (int i = n + threadIdx.x; i < RG_MAX_MASKS; i += blockDim.x) s_key[i] = ~u64(0);
+    int m = 2;  // bitonic sort over the next power of two (a hierarchy has ~1500 distinct masks)
+    while (m < n) m <<= 1;
+    for (int i = n + threadIdx.x; i < m; i += blockDim.x) s_key[i] = ~u64(0);
     __syncthreads();
-    for (int k = 2; k <= RG_MAX_MASKS; k <<= 1) {
+    for (int k = 2; k <= m; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < RG_MAX_MASKS; i += blockDim.x) {
+            for (int i = threadIdx.x; i < m; i += blockDim.x) {
                 const int l = i ^ j;
                 if (l > i) {
                     const u64 a = s_key[i], c = s_key[l];

@@ -703,6 +703,50 @@ __global__ void k_coarsen_emit(const u64* keys, i64 v, u64* out_keys, int32_t* o
     out_keys[pos] = st == 1 ? keys[i] >> 3 : keys[i];
     out_src[pos] = (int32_t)i;
 }
+// CombineSiblings without a sort (round 4).  The coarse key set is the kept keys plus one parent per merged group; both
+// sub-sequences are already sorted in input order, and location codes sort level-major, so an emitted key's position in
+// the sorted output is  (#kept keys smaller) + (#parents smaller):
+//   kept key e at input index i:        kept_before[i] + heads_before[lower_bound(keys, e << 3)]
+//   parent e = keys[i] >> 3 of a head:  heads_before[i] + kept_before[lower_bound(keys, e)]
+// (every key of a lower level is smaller; a head with key < 8 e has a parent < e).  One flag pass, one exclusive scan of
+// the packed (kept | heads << 32) counts, one placement pass with a binary search -- instead of a multi-pass radix sort
+// whose dozen launches per level dominate the four small coarsening steps.
+__global__ void k_coarsen_flags(const u64* keys, i64 v, u64* packed) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i > v) return;
+    u64 f = 0;
+    if (i < v) {
+        const int st = coarsen_state(keys, v, i);
+        f = st == 0 ? u64(1) : (st == 1 ? (u64(1) << 32) : 0);
+    }
+    packed[i] = f;
+}
+__global__ void k_coarsen_place(const u64* keys, i64 v, const u64* pre, u64* out_keys, int32_t* out_src) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    const u64 mine = pre[i + 1] - pre[i];  // 1: kept, 1 << 32: head, 0: merged member
+    if (!mine) return;
+    const bool head = (mine >> 32) != 0;
+    const u64 key = keys[i];
+    const u64 e = head ? key >> 3 : key;
+    const u64 probe = head ? e : key << 3;
+    i64 lo = 0, hi = v;  // first input key >= probe (a level-21 key has no children: its probe overflows to "beyond the end")
+    if (!head && asr_key_level(key) >= ASR_MAX_LEVEL) {
+        lo = v;
+    } else {
+        while (lo < hi) {
+            const i64 mid = (lo + hi) >> 1;
+            if (keys[mid] < probe)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+    }
+    const u64 at = pre[lo];
+    const i64 pos = head ? (i64)(pre[i] >> 32) + (i64)(at & 0xffffffffu) : (i64)(pre[i] & 0xffffffffu) + (i64)(at >> 32);
+    out_keys[pos] = e;
+    out_src[pos] = (int32_t)i;
+}
 __global__ void k_coarsen_up(const u64* keys, i64 v, const int32_t* sorted_src, i64 v_out,
                              int32_t* up_idx, uint8_t* up_kidx) {
     i64 p = blockIdx.x * (i64)blockDim.x + threadIdx.x;
@@ -2718,16 +2762,27 @@ int asr_geom_coarsen_build(asr_hip_context* ctx, Arena& keep, const u64* keys, i
     ASR_TRY(ensure_flags(ctx));
     *v_out = 0;
     if (v <= 0) return ASR_HIP_OK;
-    u64* k_u = arena_alloc<u64>(ctx->scratch, v);  // V_out <= V
-    int32_t* s_u = arena_alloc<int32_t>(ctx->scratch, v);
+    (void)key_bits;
+    // flags -> exclusive scan of the packed counts (kept | heads << 32; both below 2^31) -> one read-back of the totals
+    u64* packed = arena_alloc<u64>(ctx->scratch, v + 1);
+    u64* pre = arena_alloc<u64>(ctx->scratch, v + 2);
     int32_t* s_s = arena_alloc<int32_t>(ctx->scratch, v);
-    if (!k_u || !s_u || !s_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
-    k_coarsen_emit<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, k_u, s_u, ctx->d_flags);
+    if (!packed || !pre || !s_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_coarsen_flags<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(keys, v, packed);
     ASR_CHECK_LAUNCH(ctx);
-    int host[16];
-    ASR_TRY(read_flags(ctx, host));
-    const i64 vo = host[5];
+    {
+        size_t tb = 0;
+        ASR_HIP_CHECK(ctx, rocprim::exclusive_scan(nullptr, tb, packed, pre, u64(0), (size_t)(v + 1), rocprim::plus<u64>(),
+                                                   ctx->stream));
+        void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+        if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_HIP_CHECK(ctx, rocprim::exclusive_scan(tmp, tb, packed, pre, u64(0), (size_t)(v + 1), rocprim::plus<u64>(),
+                                                   ctx->stream));
+    }
+    u64 totals = 0;
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(&totals, pre + v, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const i64 vo = (i64)(totals & 0xffffffffu) + (i64)(totals >> 32);
     *v_out = vo;
     *out_keys = arena_alloc<u64>(keep, vo);
     *up_idx = arena_alloc<int32_t>(keep, v);
@@ -2739,8 +2794,8 @@ int asr_geom_coarsen_build(asr_hip_context* ctx, Arena& keep, const u64* keys, i
     i64* cnt = arena_alloc<i64>(ctx->scratch, vo + 1);
     if (!*out_keys || !*up_idx || !*up_kidx || !*up_rs || !*down_idx || !*down_kidx || !*down_rs || !cnt)
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, *out_keys, s_u, s_s, vo,
-                                      key_bits >= 1 && key_bits <= 64 ? key_bits : 64)));
+    k_coarsen_place<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, pre, *out_keys, s_s);
+    ASR_CHECK_LAUNCH(ctx);
     k_coarsen_up<<<grid_for(vo, BLK), BLK, 0, ctx->stream>>>(keys, v, s_s, vo, *up_idx, *up_kidx);
     ASR_CHECK_LAUNCH(ctx);
     k_iota64<<<grid_for(v + 1, BLK), BLK, 0, ctx->stream>>>(*up_rs, v + 1);

@@ -1978,8 +1978,8 @@ __global__ void k_rg_apply(RowGroupBatch b, const int32_t* sorted_ids, const int
 // Distinct masks: a small hash set (k_rg_mask_insert: all but the first insertion of a mask are read-only probes), sorted by
 // ONE workgroup in LDS (k_rg_mask_ranks, bitonic), rank written back as the set's value.  More than RG_MAX_MASKS distinct
 // masks: the caller falls back to the full-mask keys.
-constexpr int RG_MAX_MASKS = 4096;
-constexpr int RG_MASK_TAB = 16384;
+constexpr int RG_MAX_MASKS = 16384;  // 128 KB of LDS for the one sorting workgroup (C3: ~1 500 distinct masks, mixed-density C5: more than 4 096)
+constexpr int RG_MASK_TAB = 65536;
 __global__ void k_rg_masks(RowGroupBatch b, u64* masks, HashTab t, int* cnt) {
     const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (e >= b.base[b.n]) return;

@@ -104,6 +104,10 @@ SHARD_EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int
                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
                                      ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p)
 SHARD_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+SHARD_EXCHANGE_MAX_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_void_p),
+                                         ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 
 class ShardComm(ctypes.Structure):
@@ -113,6 +117,7 @@ class ShardComm(ctypes.Structure):
         ("world", ctypes.c_int),
         ("exchange", SHARD_EXCHANGE_FN),
         ("allreduce_max_u32", SHARD_ALLREDUCE_FN),
+        ("exchange_and_max", SHARD_EXCHANGE_MAX_FN),  # optional (NULL: the two above, one after the other)
     ]
 
 

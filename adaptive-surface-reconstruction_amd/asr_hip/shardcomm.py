@@ -85,7 +85,7 @@ class HostStagedComm:
         self.exchanges = 0
         self._ex = _lib.SHARD_EXCHANGE_FN(self._exchange)
         self._ar = _lib.SHARD_ALLREDUCE_FN(self._allreduce)
-        self._c = _lib.ShardComm(None, self.rank, self.world, self._ex, self._ar)
+        self._c = _lib.ShardComm(None, self.rank, self.world, self._ex, self._ar, _lib.SHARD_EXCHANGE_MAX_FN())
 
     def handle(self):
         return ctypes.byref(self._c)

@@ -683,8 +683,8 @@ struct Net {
         *plan = nullptr;
         if (!ctx->shard) return ASR_HIP_OK;
         float* imp_x = (imp && imp != replicated_imp) ? const_cast<float*>(imp) : nullptr;
-        return asr_shard_before_conv(ctx, ctx->shard, rs, in.p, in.ld * (i64)esz(), in.c * (i64)esz(), imp_x, perm, num_out,
-                                     plan);
+        return asr_shard_before_conv(ctx, ctx->shard, rs, in.p, in.ld * (i64)esz(), in.c * (i64)esz(), imp_x, in.amax, perm,
+                                     num_out, plan);
     }
 
     // f16x2: a zeroed device scalar for the running maximum of one activation buffer (nullptr in the other modes)
@@ -739,9 +739,7 @@ struct Net {
             auto pl = ctx->conv_plans.find(a.neighbors_row_splits);
             plan = pl == ctx->conv_plans.end() ? nullptr : &pl->second;
         }
-        ASR_TRY(asr_conv_sparse16(ctx, &a, pk, precision, precision == ASR_CONV16_F16 && !out_f32, plan));
-        if (ctx->shard) ASR_TRY(asr_shard_after_conv(ctx, ctx->shard, a.out_absmax));
-        return ASR_HIP_OK;
+        return asr_conv_sparse16(ctx, &a, pk, precision, precision == ASR_CONV16_F16 && !out_f32, plan);
     }
 
     int get(const std::string& name, int ndim, const asr_weight** out) {

@@ -322,8 +322,7 @@ int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_p
 void asr_shard_free(asr_shard_state* st);
 const asr_shard_stats* asr_shard_get_stats(const asr_shard_state* st);
 int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void* rs, void* feat, i64 ld_bytes, i64 row_bytes,
-                          float* imp, const int32_t** perm, i64* num_out, const asr_conv_plan** plan);
-int asr_shard_after_conv(asr_hip_context* ctx, asr_shard_state* st, unsigned* out_amax);
+                          float* imp, unsigned* in_amax, const int32_t** perm, i64* num_out, const asr_conv_plan** plan);
 int asr_shard_stitch(asr_hip_context* ctx, asr_shard_state* st, float* values);
 
 // internal entry points shared between translation units

@@ -463,9 +463,11 @@ int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_p
     return ASR_HIP_OK;
 }
 
-// before a convolution over the list `rs`: the rows it computes (perm, num_out, plan) and the halo exchange of its input
+// before a convolution over the list `rs`: the rows it computes (perm, num_out, plan), the halo exchange of its input and
+// -- f16x2: in_amax, the running maximum the producers of the input buffer kept over the rows THEY wrote -- the maximum
+// over the ranks (the tensor's, as on one GPU), in the same group as the exchange where the transport can
 int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void* rs, void* feat, i64 ld_bytes, i64 row_bytes,
-                          float* imp, const int32_t** perm, i64* num_out, const asr_conv_plan** plan) {
+                          float* imp, unsigned* in_amax, const int32_t** perm, i64* num_out, const asr_conv_plan** plan) {
     auto it = st->csr.find(rs);
     if (it == st->csr.end()) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "sharded forward: convolution over an unknown neighbour list");
     ShardCsr& c = it->second;
@@ -473,7 +475,12 @@ int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void*
     *num_out = c.num_out;
     *plan = c.has_plan ? &c.plan : nullptr;
     const i64 ns = c.send_first.back(), nr = c.recv_first.back();
-    if (st->world == 1 || (ns == 0 && nr == 0)) return ASR_HIP_OK;
+    if (st->world == 1) return ASR_HIP_OK;
+    if (ns == 0 && nr == 0) {  // no halo here, but the maximum is a collective: every rank takes part
+        if (in_amax && st->comm.allreduce_max_u32(st->comm.user, in_amax, 1, (void*)ctx->stream) != 0)
+            ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the MAX all-reduce failed");
+        return ASR_HIP_OK;
+    }
     if (ld_bytes % 4 || row_bytes % 4 || (uintptr_t)feat % 4)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: feature rows must be multiples of 4 bytes");
     const int row_dwords = (int)(row_bytes / 4);
@@ -512,9 +519,17 @@ int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void*
         ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         t0 = std::chrono::steady_clock::now();
     }
-    if (st->comm.exchange(st->comm.user, ds.npeer, c.send_peer.data(), sbuf.data(), sbytes.data(), dr.npeer,
-                          c.recv_peer.data(), rbuf.data(), rbytes.data(), (void*)ctx->stream) != 0)
-        ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the halo exchange failed");
+    int bad;
+    if (in_amax && st->comm.exchange_and_max) {
+        bad = st->comm.exchange_and_max(st->comm.user, ds.npeer, c.send_peer.data(), sbuf.data(), sbytes.data(), dr.npeer,
+                                        c.recv_peer.data(), rbuf.data(), rbytes.data(), in_amax, 1, (void*)ctx->stream);
+    } else {
+        bad = in_amax ? st->comm.allreduce_max_u32(st->comm.user, in_amax, 1, (void*)ctx->stream) : 0;
+        if (!bad)
+            bad = st->comm.exchange(st->comm.user, ds.npeer, c.send_peer.data(), sbuf.data(), sbytes.data(), dr.npeer,
+                                    c.recv_peer.data(), rbuf.data(), rbytes.data(), (void*)ctx->stream);
+    }
+    if (bad) ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the halo exchange failed");
     if (timed) {
         ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         st->stats.exchange_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -527,14 +542,6 @@ int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void*
     st->stats.bytes_sent += ns * per_row * 4;
     st->stats.bytes_received += nr * per_row * 4;
     st->stats.exchanges += 1;
-    return ASR_HIP_OK;
-}
-
-// after a convolution that keeps a running maximum (f16x2): the tensor's maximum is the largest over the ranks
-int asr_shard_after_conv(asr_hip_context* ctx, asr_shard_state* st, unsigned* out_amax) {
-    if (!out_amax || st->world == 1) return ASR_HIP_OK;
-    if (st->comm.allreduce_max_u32(st->comm.user, out_amax, 1, (void*)ctx->stream) != 0)
-        ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the MAX all-reduce failed");
     return ASR_HIP_OK;
 }
 
@@ -658,6 +665,20 @@ int rccl_allreduce_max(void* user, uint32_t* buf, size_t n, void* stream) {
     RcclComm* c = (RcclComm*)user;
     return rccl().AllReduce(buf, buf, n, ncclUint32, ncclMax, c->comm, (hipStream_t)stream) != ncclSuccess;
 }
+int rccl_exchange_and_max(void* user, int nsend, const int* send_peer, const void* const* send_buf, const size_t* send_bytes,
+                          int nrecv, const int* recv_peer, void* const* recv_buf, const size_t* recv_bytes, uint32_t* max_buf,
+                          size_t max_n, void* stream) {
+    RcclComm* c = (RcclComm*)user;
+    RcclApi& a = rccl();
+    if (a.GroupStart() != ncclSuccess) return 1;
+    int bad = a.AllReduce(max_buf, max_buf, max_n, ncclUint32, ncclMax, c->comm, (hipStream_t)stream) != ncclSuccess;
+    for (int i = 0; i < nsend; ++i)
+        bad |= a.Send(send_buf[i], send_bytes[i], ncclUint8, send_peer[i], c->comm, (hipStream_t)stream) != ncclSuccess;
+    for (int i = 0; i < nrecv; ++i)
+        bad |= a.Recv(recv_buf[i], recv_bytes[i], ncclUint8, recv_peer[i], c->comm, (hipStream_t)stream) != ncclSuccess;
+    if (a.GroupEnd() != ncclSuccess) return 1;
+    return bad;
+}
 }  // namespace
 
 extern "C" {
@@ -692,6 +713,7 @@ int asr_hip_shard_comm_rccl_create(asr_hip_context* ctx, const void* unique_id, 
     c->base.world = world;
     c->base.exchange = rccl_exchange;
     c->base.allreduce_max_u32 = rccl_allreduce_max;
+    c->base.exchange_and_max = rccl_exchange_and_max;
     *comm_out = &c->base;
     return ASR_HIP_OK;
 }

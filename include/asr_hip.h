@@ -463,8 +463,8 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points_dev,
  * the whole cloud (replicated); the 53 sparse convolutions and the decoder run on the rows the rank OWNS (grid-0 voxels
  * cut into `world` contiguous ranges of their level-21 Morton order with equal pair counts, a coarser voxel belongs to
  * the owner of its first child), with one point-to-point exchange of the boundary rows of the input buffer (+ the
- * importance of those rows) before each convolution, a MAX all-reduce of the f16x2 running maxima, and an all-gather
- * of the owned values at the end.  Per row the same kernel, plan-group arithmetic and summation order as on one GPU:
+ * importance of those rows) before each convolution -- grouped with the MAX all-reduce of the f16x2 running maximum of that
+ * buffer --, and an all-gather of the owned values at the end.  Per row the same kernel, plan-group arithmetic and summation order as on one GPU:
  * the values equal asr_hip_implicit_forward's bit for bit.
  *
  * Transport: a table of two collective primitives on DEVICE buffers, enqueued on (or synchronised with) `stream`.
@@ -479,6 +479,11 @@ typedef struct asr_shard_comm {
                     int nrecv, const int* recv_peer, void* const* recv_buf, const size_t* recv_bytes, void* stream);
     /* in-place MAX over the ranks of n uint32 values (f16x2 running maxima: non-negative f32 bit patterns) */
     int (*allreduce_max_u32)(void* user, uint32_t* buf_dev, size_t n, void* stream);
+    /* optional (NULL: the two calls above, one after the other): both in ONE group -- the maximum of a convolution's
+     * input tensor and the halo of that tensor are needed at the same moment, before the convolution starts */
+    int (*exchange_and_max)(void* user, int nsend, const int* send_peer, const void* const* send_buf,
+                            const size_t* send_bytes, int nrecv, const int* recv_peer, void* const* recv_buf,
+                            const size_t* recv_bytes, uint32_t* max_buf_dev, size_t max_n, void* stream);
 } asr_shard_comm;
 
 /* RCCL transport.  unique_id_out / unique_id: the 128 bytes of ncclUniqueId (rank 0 creates, the host broadcasts). */

@@ -52,6 +52,7 @@ const OptEntry k_options[] = {
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
         {"search_priority", "ASR_SEARCH_PRIORITY", &AsrOptions::search_priority},
         {"shard_timing", "ASR_SHARD_TIMING", &AsrOptions::shard_timing},
+        {"defer_plans", "ASR_DEFER_PLANS", &AsrOptions::defer_plans},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
 };
@@ -939,6 +940,64 @@ int asr_ctx_ensure_aux(asr_hip_context* ctx) {
 }
 
 namespace {
+// MFMA tiling orders of the 13 neighbour lists (one batched regrouping) and, for the 16-bit kernels, their row-group plans.
+// `on`: the context whose stream / scratch arena / flags do the work (the grids' own context, or its auxiliary context when
+// the step runs beside the continuous conv); plans land in `on`'s persist arena, the orders in the arrays implicit_build
+// allocated.
+int build_tilings_and_plans(asr_hip_context* ctx, asr_hip_context* on, int precision) {
+    std::vector<asr_row_group_job> rg_jobs;
+    for (int i = 0; i + 1 < ASR_NUM_GRIDS; ++i) {
+        GridDev& g = ctx->grids[i];
+        rg_jobs.push_back({g.up_kidx, g.up_rs, g.v, 9, g.perm_up});
+        rg_jobs.push_back({g.down_kidx, g.down_rs, ctx->grids[i + 1].v, 9, g.perm_down});
+    }
+    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+        GridDev& g = ctx->grids[i];
+        rg_jobs.push_back({g.nkidx, g.nrs, g.v, 55, g.perm_nb});
+    }
+    on->scratch.reset();
+    if (asr_geom_row_groups_batch(on, rg_jobs.data(), (int)rg_jobs.size(), ASR_ROW_GROUP_SEGMENT) != ASR_HIP_OK) {
+        if (on != ctx) ctx->err = on->err;
+        return ASR_HIP_EHIP;
+    }
+    if (precision != 0 && ctx->opt.sconv_plan) {
+        struct Job {
+            const int32_t* idx;
+            const uint8_t* kidx;
+            const i64* rs;
+            const int32_t* perm;
+            i64 rows;
+            int K;
+        };
+        std::vector<Job> jobs;
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+            GridDev& g = ctx->grids[i];
+            jobs.push_back({g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, 55});
+            if (i + 1 < ASR_NUM_GRIDS) {
+                GridDev& c = ctx->grids[i + 1];
+                jobs.push_back({g.up_idx, g.up_kidx, g.up_rs, g.perm_up, g.v, 9});
+                jobs.push_back({g.down_idx, g.down_kidx, g.down_rs, g.perm_down, c.v, 9});
+            }
+        }
+        std::vector<asr_conv_plan> plans(jobs.size());
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            plans[j].nidx = jobs[j].idx;
+            plans[j].kidx = jobs[j].kidx;
+            plans[j].rs = jobs[j].rs;
+            plans[j].perm = jobs[j].perm;
+            plans[j].num_out = jobs[j].rows;
+            plans[j].K = jobs[j].K;
+        }
+        const int rc = asr_geom_conv_plan_batch(on, on->persist, plans.data(), (int)plans.size());
+        if (rc != ASR_HIP_OK) {
+            if (on != ctx) ctx->err = on->err;
+            return rc;
+        }
+        for (size_t j = 0; j < jobs.size(); ++j) ctx->conv_plans[jobs[j].rs] = plans[j];
+    }
+    return ASR_HIP_OK;
+}
+
 int implicit_build(asr_hip_context* ctx, const float* points, const float* radii, i64 n,
                    const asr_implicit_params* prm) {
     ASR_TRY(ensure_events(ctx));
@@ -1135,42 +1194,12 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         name_it(ctx, "neighbors_row_splits" + s, g.nrs, 8 * (g.v + 1));
         name_it(ctx, "tiling" + s, g.perm_nb, 4 * g.v);
     }
-    ctx->scratch.reset();
-    ASR_TRY(asr_geom_row_groups_batch(ctx, rg_jobs.data(), (int)rg_jobs.size(), ASR_ROW_GROUP_SEGMENT));
-    // row-group plans of every list for the 16-bit kernels: all counting passes first, one read-back of the
-    // pool sizes, then the fills
+    // MFMA tiling orders + row-group plans: here, or -- fused forward, option "defer_plans" -- beside the continuous conv of
+    // the network half (only the U-Net needs them), off the build's critical path
     ctx->conv_plans.clear();
-    if (prm->precision != 0 && ctx->opt.sconv_plan) {
-        struct Job {
-            const int32_t* idx;
-            const uint8_t* kidx;
-            const i64* rs;
-            const int32_t* perm;
-            i64 rows;
-            int K;
-        };
-        std::vector<Job> jobs;
-        for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
-            GridDev& g = ctx->grids[i];
-            jobs.push_back({g.nidx, g.nkidx, g.nrs, g.perm_nb, g.v, 55});
-            if (i + 1 < ASR_NUM_GRIDS) {
-                GridDev& c = ctx->grids[i + 1];
-                jobs.push_back({g.up_idx, g.up_kidx, g.up_rs, g.perm_up, g.v, 9});
-                jobs.push_back({g.down_idx, g.down_kidx, g.down_rs, g.perm_down, c.v, 9});
-            }
-        }
-        std::vector<asr_conv_plan> plans(jobs.size());
-        for (size_t j = 0; j < jobs.size(); ++j) {
-            plans[j].nidx = jobs[j].idx;
-            plans[j].kidx = jobs[j].kidx;
-            plans[j].rs = jobs[j].rs;
-            plans[j].perm = jobs[j].perm;
-            plans[j].num_out = jobs[j].rows;
-            plans[j].K = jobs[j].K;
-        }
-        ASR_TRY(asr_geom_conv_plan_batch(ctx, ctx->persist, plans.data(), (int)plans.size()));
-        for (size_t j = 0; j < jobs.size(); ++j) ctx->conv_plans[jobs[j].rs] = plans[j];
-    }
+    ctx->plans_pending = ctx->defer_plans_now && overlap;
+    ctx->plans_precision = prm->precision;
+    if (!ctx->plans_pending) ASR_TRY(build_tilings_and_plans(ctx, ctx, prm->precision));
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     if (overlap)
@@ -1247,7 +1276,37 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_TRY(ensure_events(ctx));
     Net net{ctx, {weights, num_weights}};
     net.precision = prm->precision;
-    ASR_TRY(implicit_aggregate(ctx, points, normals, n, net));
+    if (ctx->plans_pending && ctx->aux) {
+        // the tiling orders and plans of the last build on the auxiliary stream (own host thread: the step has read-backs),
+        // while this thread enqueues the aggregation stage, which needs neither
+        asr_hip_context* sc = ctx->aux;
+        sc->err.clear();
+        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
+        int plans_rc = ASR_HIP_OK;
+        std::thread worker([&] {
+            if (hipSetDevice(ctx->device) != hipSuccess) {
+                plans_rc = ASR_HIP_EHIP;
+                return;
+            }
+            plans_rc = build_tilings_and_plans(ctx, sc, ctx->plans_precision);
+            if (plans_rc == ASR_HIP_OK && hipStreamSynchronize(sc->stream) != hipSuccess) plans_rc = ASR_HIP_EHIP;
+        });
+        const int agg_rc = implicit_aggregate(ctx, points, normals, n, net);
+        worker.join();
+        ctx->plans_pending = false;
+        if (agg_rc != ASR_HIP_OK) return agg_rc;
+        if (plans_rc != ASR_HIP_OK) {
+            if (ctx->err.empty()) ctx->err = "tiling orders / plans on the auxiliary stream failed";
+            return plans_rc;
+        }
+    } else {
+        if (ctx->plans_pending) {  // (no auxiliary context after all)
+            ASR_TRY(build_tilings_and_plans(ctx, ctx, ctx->plans_precision));
+            ctx->plans_pending = false;
+        }
+        ASR_TRY(implicit_aggregate(ctx, points, normals, n, net));
+    }
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
     const i64 P = ctx->sizes.num_agg_pairs;
@@ -1424,7 +1483,10 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points, const fl
     CTX_GUARD(ctx);
     if (!points || !normals || !radii || n <= 0 || !weights || !prm)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward: points is null!");
-    ASR_TRY(implicit_build(ctx, points, radii, n, prm));
+    ctx->defer_plans_now = ctx->opt.defer_plans != 0;  // both halves in one call: tiling orders + plans can wait for the network half
+    const int brc = implicit_build(ctx, points, radii, n, prm);
+    ctx->defer_plans_now = false;
+    ASR_TRY(brc);
     ASR_TRY(implicit_network(ctx, points, normals, n, weights, num_weights, prm, nullptr));
     if (sizes) *sizes = ctx->sizes;
     return ASR_HIP_OK;

@@ -52,7 +52,6 @@ const OptEntry k_options[] = {
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
         {"search_priority", "ASR_SEARCH_PRIORITY", &AsrOptions::search_priority},
         {"shard_timing", "ASR_SHARD_TIMING", &AsrOptions::shard_timing},
-        {"defer_plans", "ASR_DEFER_PLANS", &AsrOptions::defer_plans},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
 };
@@ -1194,12 +1193,10 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         name_it(ctx, "neighbors_row_splits" + s, g.nrs, 8 * (g.v + 1));
         name_it(ctx, "tiling" + s, g.perm_nb, 4 * g.v);
     }
-    // MFMA tiling orders + row-group plans: here, or -- fused forward, option "defer_plans" -- beside the continuous conv of
-    // the network half (only the U-Net needs them), off the build's critical path
+    // MFMA tiling orders + row-group plans.  (Deferring them to the auxiliary stream beside the continuous conv of the network
+    // half -- only the U-Net needs them -- was measured again in round 4: geometry wall 9.5 -> 8.5-8.9 ms, network wall + 1.2 ms.)
     ctx->conv_plans.clear();
-    ctx->plans_pending = ctx->defer_plans_now && overlap;
-    ctx->plans_precision = prm->precision;
-    if (!ctx->plans_pending) ASR_TRY(build_tilings_and_plans(ctx, ctx, prm->precision));
+    ASR_TRY(build_tilings_and_plans(ctx, ctx, prm->precision));
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     if (overlap)
@@ -1276,37 +1273,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_TRY(ensure_events(ctx));
     Net net{ctx, {weights, num_weights}};
     net.precision = prm->precision;
-    if (ctx->plans_pending && ctx->aux) {
-        // the tiling orders and plans of the last build on the auxiliary stream (own host thread: the step has read-backs),
-        // while this thread enqueues the aggregation stage, which needs neither
-        asr_hip_context* sc = ctx->aux;
-        sc->err.clear();
-        ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));
-        ASR_HIP_CHECK(ctx, hipStreamWaitEvent(sc->stream, ctx->aux_ev, 0));
-        int plans_rc = ASR_HIP_OK;
-        std::thread worker([&] {
-            if (hipSetDevice(ctx->device) != hipSuccess) {
-                plans_rc = ASR_HIP_EHIP;
-                return;
-            }
-            plans_rc = build_tilings_and_plans(ctx, sc, ctx->plans_precision);
-            if (plans_rc == ASR_HIP_OK && hipStreamSynchronize(sc->stream) != hipSuccess) plans_rc = ASR_HIP_EHIP;
-        });
-        const int agg_rc = implicit_aggregate(ctx, points, normals, n, net);
-        worker.join();
-        ctx->plans_pending = false;
-        if (agg_rc != ASR_HIP_OK) return agg_rc;
-        if (plans_rc != ASR_HIP_OK) {
-            if (ctx->err.empty()) ctx->err = "tiling orders / plans on the auxiliary stream failed";
-            return plans_rc;
-        }
-    } else {
-        if (ctx->plans_pending) {  // (no auxiliary context after all)
-            ASR_TRY(build_tilings_and_plans(ctx, ctx, ctx->plans_precision));
-            ctx->plans_pending = false;
-        }
-        ASR_TRY(implicit_aggregate(ctx, points, normals, n, net));
-    }
+    ASR_TRY(implicit_aggregate(ctx, points, normals, n, net));
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
     const i64 P = ctx->sizes.num_agg_pairs;
@@ -1483,10 +1450,7 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points, const fl
     CTX_GUARD(ctx);
     if (!points || !normals || !radii || n <= 0 || !weights || !prm)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward: points is null!");
-    ctx->defer_plans_now = ctx->opt.defer_plans != 0;  // both halves in one call: tiling orders + plans can wait for the network half
-    const int brc = implicit_build(ctx, points, radii, n, prm);
-    ctx->defer_plans_now = false;
-    ASR_TRY(brc);
+    ASR_TRY(implicit_build(ctx, points, radii, n, prm));
     ASR_TRY(implicit_network(ctx, points, normals, n, weights, num_weights, prm, nullptr));
     if (sizes) *sizes = ctx->sizes;
     return ASR_HIP_OK;

@@ -109,7 +109,6 @@ struct AsrOptions {
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
-    i64 defer_plans = 1;          // asr_hip_implicit_forward: tiling orders + plans beside the continuous conv instead of in the build
     i64 shard_timing = 0;         // sharded forward: synchronise around every halo exchange and accumulate its wall time
     i64 search_priority = 2;      // priority of the search's stream (set before the first build): 0 lowest, 1 middle, 2 highest
                                   // (round 4: the search is the longer of the two chains; 9.6 -> 8.8 ms on its stream)
@@ -219,9 +218,6 @@ struct asr_hip_context {
     // callers that update weights in place call asr_hip_context_weights_changed (the copies are made again).
     typedef std::tuple<const void*, const void*, i64, i64, i64, i64, int> PackedKey;
     std::map<PackedKey, void*> packed_weights;
-    bool defer_plans_now = false;  // set by asr_hip_implicit_forward around its build
-    bool plans_pending = false;    // the last build left tiling orders + plans to the network half
-    int plans_precision = 0;
     struct asr_shard_state* shard = nullptr;  // set while asr_hip_implicit_forward_sharded runs its network half
 };
 

@@ -1134,7 +1134,6 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     // (asr_geom_neighbors_build_batch: one key-map launch, one counting pass, one scan, one read-back, one filling pass
     // -- the coarse grids used to pay a level-0 kernel's latency each, five times over); the MFMA tiling orders of all
     // 13 CSRs are computed in one batch at the end.
-    std::vector<asr_row_group_job> rg_jobs;
     for (int i = 1; i < ASR_NUM_GRIDS; ++i) {
         GridDev& g = ctx->grids[i];
         g = GridDev();
@@ -1148,8 +1147,6 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
         prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
         if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        rg_jobs.push_back({prev.up_kidx, prev.up_rs, prev.v, 9, prev.perm_up});
-        rg_jobs.push_back({prev.down_kidx, prev.down_rs, g.v, 9, prev.perm_down});
         std::string s = std::to_string(i - 1);
         name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
         name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
@@ -1181,7 +1178,6 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         GridDev& g = ctx->grids[i];
         g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
         if (!g.perm_nb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        rg_jobs.push_back({g.nkidx, g.nrs, g.v, 55, g.perm_nb});
         ctx->sizes.num_voxels[i] = g.v;
         ctx->sizes.num_pairs[i] = g.p;
         std::string s = std::to_string(i);

@@ -69,6 +69,29 @@ ARITHMETIC = {
 }
 
 
+class quiet_stdout:
+    """RCCL prints a version banner to C stdout when its first communicator is made; the contract is ONE json line on
+    stdout.  Points fd 1 at stderr for the duration of the block and flushes C stdio before switching back."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            self._libc.fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def conv_flops(sizes, shapes):
     """algorithmic FLOP of the 53 sparse convs: 2 * P * Cin * Cout per conv with P the actual pair
     count; a transition has one pair per voxel of the finer grid.  conv1a + conv1b of a
@@ -544,8 +567,10 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world,
-                                device_id=dev if args.backend == "nccl" else None)
+        with quiet_stdout():  # (gloo and RCCL both announce themselves on stdout)
+            dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                    device_id=dev if args.backend == "nccl" else None)
+            dist.barrier()
 
     from asr_hip import synth
     from asr_hip.pipeline import ImplicitPipeline

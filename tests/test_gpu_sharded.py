@@ -159,7 +159,8 @@ def _native_worker(rank, world, port, n_points, channel_div, precision, out, fus
 
 @pytest.mark.parametrize("world,n_points,channel_div,precision,fused",
                          [(2, 30000, 2, "f32", 0), (3, 8000, 1, "f32", 0), (2, 30000, 1, "bf16x3", 0),
-                          (2, 30000, 1, "f16x2", 0), (3, 8000, 2, "f16x2", 0), (3, 64000, 2, "f16x2", 8)])
+                          (2, 30000, 1, "f16x2", 0), (3, 8000, 2, "f16x2", 0), (3, 64000, 2, "f16x2", 8),
+                          (2, 1000000, 1, "f16x2", 0)])
 def test_library_sharded_forward_equals_single_process(gpu, world, n_points, channel_div, precision, fused):
     """asr_hip_implicit_forward_sharded with 2 - 3 processes on ONE GPU (transport: HostStagedComm over gloo; RCCL needs
     one GPU per rank): ownership, owned row lists + plans, halo lists, packing, the MAX all-reduce of the f16x2 maxima

@@ -52,6 +52,7 @@ const OptEntry k_options[] = {
         {"search_half", "ASR_SEARCH_HALF", &AsrOptions::search_half},
         {"search_priority", "ASR_SEARCH_PRIORITY", &AsrOptions::search_priority},
         {"shard_timing", "ASR_SHARD_TIMING", &AsrOptions::shard_timing},
+        {"shard_geometry", "ASR_SHARD_GEOMETRY", &AsrOptions::shard_geometry},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
 };
@@ -160,6 +161,7 @@ static void release_members(asr_hip_context* ctx) {
     ctx->packed_weights.clear();
     asr_geom_release(ctx);
     asr_mesh_release(ctx);
+    asr_shard_release(ctx);
     ctx->persist.release();
     ctx->scratch.release();
     ctx->plan_arena.release();
@@ -190,7 +192,7 @@ void asr_hip_context_set_stream(asr_hip_context* ctx, void* stream) {
 const char* asr_hip_last_error(const asr_hip_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 size_t asr_hip_context_reserved_bytes(const asr_hip_context* ctx) {
     if (!ctx) return 0;
-    size_t t = ctx->persist.reserved() + ctx->scratch.reserved();
+    size_t t = ctx->persist.reserved() + ctx->scratch.reserved() + ctx->shard_mem.reserved() + 8 * ctx->shard_stage_cap;
     if (ctx->aux) t += ctx->aux->persist.reserved() + ctx->aux->scratch.reserved();
     return t;
 }
@@ -997,26 +999,96 @@ int build_tilings_and_plans(asr_hip_context* ctx, asr_hip_context* on, int preci
     return ASR_HIP_OK;
 }
 
-int implicit_build(asr_hip_context* ctx, const float* points, const float* radii, i64 n,
-                   const asr_implicit_params* prm) {
+// what every build starts with: nothing of the previous build survives
+int build_begin(asr_hip_context* ctx, i64 n, const asr_implicit_params* prm) {
     ASR_TRY(ensure_events(ctx));
     ctx->persist.reset();
     ctx->scratch.reset();
     ctx->named.clear();
     ctx->values = ctx->feats1 = ctx->importance = ctx->code = nullptr;
-    // nothing of the previous build survives the arena reset above
     ctx->agg_rs = nullptr;
     ctx->agg_idx = ctx->agg_spos = nullptr;
     ctx->agg_dist = ctx->agg_compat = nullptr;
     ctx->agg_sorted = nullptr;
+    ctx->agg_rows = nullptr;
+    ctx->agg_nq = 0;
+    ctx->agg_qcenters = ctx->agg_qsizes = nullptr;
     ctx->has_search = false;
     ctx->build_mark_ok = false;
+    ctx->conv_plans.clear();
     memset(&ctx->sizes, 0, sizeof(ctx->sizes));
     ctx->sizes.num_points = n;
     if (asr_octree_frame_init(&ctx->frame, prm->bb_min, prm->bb_max) != ASR_HIP_OK)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "degenerate bounding box");
     asr_hip_print("grid building\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:144
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    return ASR_HIP_OK;
+}
+// centres / sizes of the level-0 voxels (= the octree's leaves)
+int build_level0(asr_hip_context* ctx) {
+    GridDev& g0 = ctx->grids[0];
+    g0 = GridDev();
+    g0.v = ctx->num_leaves;
+    g0.keys = ctx->leaves;
+    g0.centers = arena_alloc<float>(ctx->persist, 3 * g0.v);
+    g0.sizes = arena_alloc<float>(ctx->persist, g0.v);
+    if (!g0.centers || !g0.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    return asr_geom_voxel_info(ctx, &ctx->frame, g0.keys, g0.v, g0.centers, g0.sizes);
+}
+// key sets of the coarser grids with their up / down lists: a chain of four small coarsening steps
+// (cpp/lib/grid.cpp:245-314; CombineSiblings + neighbors_down = invert(up lists), net_definitions_torch.py:548-559)
+int build_coarse_grids(asr_hip_context* ctx) {
+    for (int i = 1; i < ASR_NUM_GRIDS; ++i) {
+        GridDev& g = ctx->grids[i];
+        g = GridDev();
+        ctx->scratch.reset();
+        GridDev& prev = ctx->grids[i - 1];
+        // (the keys of every grid are location codes of at most the deepest leaf's level: the sort skips the rest)
+        ASR_TRY(asr_geom_coarsen_build(ctx, ctx->persist, prev.keys, prev.v, &g.keys, &g.v, &prev.up_idx,
+                                       &prev.up_kidx, &prev.up_rs, &prev.down_idx, &prev.down_kidx, &prev.down_rs,
+                                       ctx->leaf_lmax >= 0 ? 3 * ctx->leaf_lmax + 1 : 64));
+        prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
+        prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
+        if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        std::string s = std::to_string(i - 1);
+        name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
+        name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
+        name_it(ctx, "up_neighbors_row_splits" + s, prev.up_rs, 8 * (prev.v + 1));
+        name_it(ctx, "down_neighbors_index" + s, prev.down_idx, 4 * prev.v);
+        name_it(ctx, "down_neighbors_kernel_index" + s, prev.down_kidx, prev.v);
+        name_it(ctx, "down_neighbors_row_splits" + s, prev.down_rs, 8 * (g.v + 1));
+        name_it(ctx, "tiling_up" + s, prev.perm_up, 4 * prev.v);
+        name_it(ctx, "tiling_down" + s, prev.perm_down, 4 * g.v);
+        g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
+        g.sizes = arena_alloc<float>(ctx->persist, g.v);
+        if (!g.centers || !g.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
+    }
+    return ASR_HIP_OK;
+}
+// tiling-order arrays + the names of the per-grid arrays, once the 55-slot lists exist
+int build_grid_names(asr_hip_context* ctx) {
+    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+        GridDev& g = ctx->grids[i];
+        g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
+        if (!g.perm_nb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ctx->sizes.num_voxels[i] = g.v;
+        ctx->sizes.num_pairs[i] = g.p;
+        std::string s = std::to_string(i);
+        name_it(ctx, "voxel_keys" + s, g.keys, 8 * g.v);
+        name_it(ctx, "voxel_centers" + s, g.centers, 12 * g.v);
+        name_it(ctx, "voxel_sizes" + s, g.sizes, 4 * g.v);
+        name_it(ctx, "neighbors_index" + s, g.nidx, 4 * g.p);
+        name_it(ctx, "neighbors_kernel_index" + s, g.nkidx, g.p);
+        name_it(ctx, "neighbors_row_splits" + s, g.nrs, 8 * (g.v + 1));
+        name_it(ctx, "tiling" + s, g.perm_nb, 4 * g.v);
+    }
+    return ASR_HIP_OK;
+}
+
+int implicit_build(asr_hip_context* ctx, const float* points, const float* radii, i64 n,
+                   const asr_implicit_params* prm) {
+    ASR_TRY(build_begin(ctx, n, prm));
     // Aggregation neighbours (cpp/lib/asr.cpp:266-273) on the auxiliary context: its own stream, arenas,
     // counters and host thread, overlapped with the grid hierarchy below.  Both are chains of
     // latency-bound kernels with host round trips for the data-dependent sizes; neither fills the GPU.
@@ -1087,16 +1159,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     if (ctx->num_leaves == 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "no point inside the bounding box");
 
     // level-0 voxel centres / sizes first: the aggregation search only needs those
-    {
-        GridDev& g0 = ctx->grids[0];
-        g0 = GridDev();
-        g0.v = ctx->num_leaves;
-        g0.keys = ctx->leaves;
-        g0.centers = arena_alloc<float>(ctx->persist, 3 * g0.v);
-        g0.sizes = arena_alloc<float>(ctx->persist, g0.v);
-        if (!g0.centers || !g0.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g0.keys, g0.v, g0.centers, g0.sizes));
-    }
+    ASR_TRY(build_level0(ctx));
 
     if (want_search) asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264 (here: concurrent with the grids)
     if (overlap) ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));  // the level-0 voxel centres / sizes are ready
@@ -1134,33 +1197,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     // (asr_geom_neighbors_build_batch: one key-map launch, one counting pass, one scan, one read-back, one filling pass
     // -- the coarse grids used to pay a level-0 kernel's latency each, five times over); the MFMA tiling orders of all
     // 13 CSRs are computed in one batch at the end.
-    for (int i = 1; i < ASR_NUM_GRIDS; ++i) {
-        GridDev& g = ctx->grids[i];
-        g = GridDev();
-        ctx->scratch.reset();
-        GridDev& prev = ctx->grids[i - 1];
-        // CombineSiblings + neighbors_down = invert(up lists) (net_definitions_torch.py:548-559) in one go
-        // (the keys of every grid are location codes of at most the deepest leaf's level: the sort skips the rest)
-        ASR_TRY(asr_geom_coarsen_build(ctx, ctx->persist, prev.keys, prev.v, &g.keys, &g.v, &prev.up_idx,
-                                       &prev.up_kidx, &prev.up_rs, &prev.down_idx, &prev.down_kidx, &prev.down_rs,
-                                       ctx->leaf_lmax >= 0 ? 3 * ctx->leaf_lmax + 1 : 64));
-        prev.perm_up = arena_alloc<int32_t>(ctx->persist, prev.v);
-        prev.perm_down = arena_alloc<int32_t>(ctx->persist, g.v);
-        if (!prev.perm_up || !prev.perm_down) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        std::string s = std::to_string(i - 1);
-        name_it(ctx, "up_neighbors_index" + s, prev.up_idx, 4 * prev.v);
-        name_it(ctx, "up_neighbors_kernel_index" + s, prev.up_kidx, prev.v);
-        name_it(ctx, "up_neighbors_row_splits" + s, prev.up_rs, 8 * (prev.v + 1));
-        name_it(ctx, "down_neighbors_index" + s, prev.down_idx, 4 * prev.v);
-        name_it(ctx, "down_neighbors_kernel_index" + s, prev.down_kidx, prev.v);
-        name_it(ctx, "down_neighbors_row_splits" + s, prev.down_rs, 8 * (g.v + 1));
-        name_it(ctx, "tiling_up" + s, prev.perm_up, 4 * prev.v);
-        name_it(ctx, "tiling_down" + s, prev.perm_down, 4 * g.v);
-        g.centers = arena_alloc<float>(ctx->persist, 3 * g.v);
-        g.sizes = arena_alloc<float>(ctx->persist, g.v);
-        if (!g.centers || !g.sizes) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_voxel_info(ctx, &ctx->frame, g.keys, g.v, g.centers, g.sizes));
-    }
+    ASR_TRY(build_coarse_grids(ctx));
     {
         ctx->scratch.reset();
         asr_nb_job nb[ASR_NUM_GRIDS];
@@ -1174,24 +1211,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             g.p = nb[i].p;
         }
     }
-    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
-        GridDev& g = ctx->grids[i];
-        g.perm_nb = arena_alloc<int32_t>(ctx->persist, g.v);
-        if (!g.perm_nb) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ctx->sizes.num_voxels[i] = g.v;
-        ctx->sizes.num_pairs[i] = g.p;
-        std::string s = std::to_string(i);
-        name_it(ctx, "voxel_keys" + s, g.keys, 8 * g.v);
-        name_it(ctx, "voxel_centers" + s, g.centers, 12 * g.v);
-        name_it(ctx, "voxel_sizes" + s, g.sizes, 4 * g.v);
-        name_it(ctx, "neighbors_index" + s, g.nidx, 4 * g.p);
-        name_it(ctx, "neighbors_kernel_index" + s, g.nkidx, g.p);
-        name_it(ctx, "neighbors_row_splits" + s, g.nrs, 8 * (g.v + 1));
-        name_it(ctx, "tiling" + s, g.perm_nb, 4 * g.v);
-    }
+    ASR_TRY(build_grid_names(ctx));
     // MFMA tiling orders + row-group plans.  (Deferring them to the auxiliary stream beside the continuous conv of the network
     // half -- only the U-Net needs them -- was measured again in round 4: geometry wall 9.5 -> 8.5-8.9 ms, network wall + 1.2 ms.)
-    ctx->conv_plans.clear();
     ASR_TRY(build_tilings_and_plans(ctx, ctx, prm->precision));
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
@@ -1217,6 +1239,133 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     // repeated network() calls on one build do not grow the arena
     arena_mark(ctx->persist, ctx->build_mark);
     ctx->build_mark_ok = true;
+    return ASR_HIP_OK;
+}
+
+// gathers of the compact query list of a rank with sharded geometry, and the scatter of its aggregated rows
+__global__ void k_gather_queries(const int32_t* rows, i64 nq, const float* centers, const float* sizes, const u64* keys,
+                                 float* qc, float* qs, u64* qk) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const i64 r = rows[i];
+    qc[3 * i] = centers[3 * r];
+    qc[3 * i + 1] = centers[3 * r + 1];
+    qc[3 * i + 2] = centers[3 * r + 2];
+    qs[i] = sizes[r];
+    qk[i] = keys[r];
+}
+__global__ void k_scatter_rows(const float* src, const int32_t* rows, i64 nq, int c, float* dst) {
+    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (t >= nq * c) return;
+    const i64 i = t / c;
+    dst[(i64)rows[i] * c + (t - i * c)] = src[t];
+}
+
+// The build of ONE RANK of a cloud cut into Morton ranges (option shard_geometry): octree, voxel keys and the
+// one-entry-per-voxel up / down lists of all five grids on every rank -- cheap integer work that ownership is derived
+// from -- and the expensive parts for the voxels this rank owns only: 55-slot neighbour lists (asr_geom_neighbors_rows_*),
+// row-group plans, the aggregation search.  One stream, no overlap: every step is 1/world of the monolithic one.
+int implicit_build_sharded(asr_hip_context* ctx, const asr_shard_comm* comm, const float* points, const float* radii, i64 n,
+                           const asr_implicit_params* prm, asr_shard_state** st_out) {
+    *st_out = nullptr;
+    ASR_TRY(build_begin(ctx, n, prm));
+    ctx->search_overlapped = false;
+    ctx->pindex.valid = false;
+    ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale, prm->octree_max_depth));
+    ctx->sizes.num_nodes = ctx->num_nodes;
+    name_it(ctx, "nodes", ctx->nodes, 8 * ctx->num_nodes);
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (ctx->num_leaves == 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "no point inside the bounding box");
+    ASR_TRY(build_level0(ctx));
+    ASR_TRY(build_coarse_grids(ctx));
+    GridDev* g = ctx->grids;
+    const i64 V0 = g[0].v;
+
+    asr_shard_state* st = nullptr;
+    ASR_TRY(asr_shard_ownership(ctx, comm, 0, &st));
+    struct Guard {
+        asr_shard_state*& st;
+        bool keep = false;
+        ~Guard() {
+            if (!keep && st) asr_shard_free(st);
+        }
+    } guard{st};
+    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {  // 55-slot lists of the owned rows (rows of other ranks: empty)
+        i64 nrows = 0;
+        const int32_t* rows = asr_shard_level_rows(st, i, &nrows);
+        ctx->scratch.reset();
+        g[i].nrs = arena_alloc<i64>(ctx->persist, g[i].v + 1);
+        if (!g[i].nrs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_geom_neighbors_rows_count(ctx, g[i].keys, g[i].v, rows, nrows, g[i].nrs, &g[i].p));
+        g[i].nidx = arena_alloc<int32_t>(ctx->persist, g[i].p);
+        g[i].nkidx = arena_alloc<uint8_t>(ctx->persist, g[i].p);
+        if (!g[i].nidx || !g[i].nkidx) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ctx->scratch.reset();
+        ASR_TRY(asr_geom_neighbors_rows_fill(ctx, g[i].keys, g[i].v, rows, nrows, g[i].nrs, g[i].nidx, g[i].nkidx));
+    }
+    ASR_TRY(build_grid_names(ctx));
+    ASR_TRY(build_tilings_and_plans(ctx, ctx, 0));  // tiling orders; the plans are per rank (asr_shard_lists)
+    ASR_TRY(asr_shard_lists(ctx, st, prm->precision != 0 && ctx->opt.sconv_plan));
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+
+    // ---- aggregation search over [0, prefix) + the owned rows (cpp/lib/asr.cpp:266-273).  SURVEY B.2: encblock0 reads the
+    // importance of the first V0 PAIRS of the whole cloud's CSR; those belong to the first few percent of the voxels in
+    // index order, which every rank therefore searches itself (no communication).
+    asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264
+    ArenaMark before;
+    arena_mark(ctx->persist, before);
+    i64 prefix = std::min<i64>(V0, std::max<i64>(1024, V0 / 8));
+    i64 agg_pairs = 0, nq = 0;
+    for (;;) {
+        arena_rewind(ctx->persist, before);
+        ctx->scratch.reset();
+        ctx->pindex.valid = false;
+        int32_t* qrows = nullptr;
+        ASR_TRY(asr_shard_query_rows(ctx, st, prefix, ctx->persist, &qrows, &nq));
+        float* qc = arena_alloc<float>(ctx->persist, 3 * nq);
+        float* qs = arena_alloc<float>(ctx->persist, nq);
+        u64* qk = arena_alloc<u64>(ctx->persist, nq);
+        ctx->agg_rs = arena_alloc<i64>(ctx->persist, nq + 1);
+        if (!qc || !qs || !qk || !ctx->agg_rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_gather_queries<<<grid_for(nq, 256), 256, 0, ctx->stream>>>(qrows, nq, g[0].centers, g[0].sizes, g[0].keys, qc, qs, qk);
+        ASR_CHECK_LAUNCH(ctx);
+        ctx->scratch.reset();
+        ASR_TRY(asr_geom_radius_count(ctx, &ctx->frame, points, n, qc, qs, nq, ctx->agg_rs, &agg_pairs, &ctx->persist, radii,
+                                      qk, ctx->leaf_lmin, ctx->leaf_lmax, nullptr));
+        i64 prefix_pairs = 0;
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(&prefix_pairs, ctx->agg_rs + prefix, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (prefix_pairs < V0 && prefix < V0) {
+            prefix = std::min<i64>(V0, 2 * prefix);
+            continue;
+        }
+        // (prefix == V0 and still fewer pairs than voxels: implicit_network reports the reference's out-of-range indexing)
+        ctx->agg_rows = qrows;
+        ctx->agg_nq = nq;
+        ctx->agg_qcenters = qc;
+        ctx->agg_qsizes = qs;
+        break;
+    }
+    ctx->agg_idx = arena_alloc<int32_t>(ctx->persist, agg_pairs);
+    ctx->agg_dist = arena_alloc<float>(ctx->persist, agg_pairs);
+    ctx->agg_compat = arena_alloc<float>(ctx->persist, agg_pairs);
+    ctx->agg_spos = arena_alloc<int32_t>(ctx->persist, agg_pairs);
+    if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat || !ctx->agg_spos)
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_TRY(asr_geom_radius_fill(ctx, points, radii, n, ctx->agg_qcenters, ctx->agg_qsizes, nq, ctx->agg_rs, ctx->agg_idx,
+                                 ctx->agg_dist, ctx->agg_compat, ctx->agg_spos, &ctx->agg_sorted));
+    ctx->has_search = true;
+    ctx->sizes.num_agg_pairs = agg_pairs;  // of THIS rank's query list
+    name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * agg_pairs);
+    name_it(ctx, "aggregation_neighbors_dist", ctx->agg_dist, 4 * agg_pairs);
+    name_it(ctx, "aggregation_scale_compat", ctx->agg_compat, 4 * agg_pairs);
+    name_it(ctx, "aggregation_row_splits", ctx->agg_rs, 8 * (nq + 1));
+    name_it(ctx, "aggregation_rows", const_cast<int32_t*>(ctx->agg_rows), 4 * nq);
+    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    arena_mark(ctx->persist, ctx->build_mark);
+    ctx->build_mark_ok = true;
+    guard.keep = true;
+    *st_out = st;
     return ASR_HIP_OK;
 }
 
@@ -1252,8 +1401,18 @@ int implicit_aggregate(asr_hip_context* ctx, const float* points, const float* n
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(asr_conv_agg_importance(ctx, ctx->agg_compat, ctx->agg_dist, P, imp_pairs));
     // positions, features and pair indices all in Morton order (the search's own point order)
-    ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, feats, feats,
-                           ctx->agg_spos, imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1, 1));
+    if (ctx->agg_nq > 0) {  // sharded geometry: the listed rows only; the others stay zero (f16x2: neutral for the maximum)
+        float* part = arena_alloc<float>(ctx->scratch, (size_t)ctx->agg_nq * C0);
+        if (!part) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        ASR_TRY(asr_conv_cconv(ctx, ck->data, ctx->agg_qcenters, ctx->agg_qsizes, feats, feats, ctx->agg_spos, imp_pairs,
+                               ctx->agg_rs, ctx->agg_nq, 4, C0, 1, cb->data, 1, part, 1));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(feats1, 0, sizeof(float) * (size_t)V0 * C0, ctx->stream));
+        k_scatter_rows<<<grid_for(ctx->agg_nq * C0, 256), 256, 0, ctx->stream>>>(part, ctx->agg_rows, ctx->agg_nq, C0, feats1);
+        ASR_CHECK_LAUNCH(ctx);
+    } else {
+        ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, feats, feats,
+                               ctx->agg_spos, imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1, 1));
+    }
     ctx->feats1 = feats1;
     ctx->importance = imp_pairs;
     ctx->feats1_width = C0;
@@ -1463,10 +1622,17 @@ int asr_hip_implicit_forward_sharded(asr_hip_context* ctx, const asr_shard_comm*
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward_sharded: the f16-activation network is not sharded (precision 0, "
                                       "ASR_CONV16_BF16X3 or ASR_CONV16_F16X2)");
     if (!ctx->opt.build_search) ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward_sharded needs option build_search");
-    ASR_TRY(implicit_build(ctx, points, radii, n, prm));  // the whole cloud's geometry on every rank
-    if (sizes) *sizes = ctx->sizes;
+    // option shard_geometry: 0 = the whole cloud's geometry on every rank (overlapped search, as on one GPU), 1 = lists,
+    // plans and search for the owned voxels only, -1 (default) = 1 from four ranks on
+    const bool own_geometry = comm->world > 1 && (ctx->opt.shard_geometry > 0 || (ctx->opt.shard_geometry < 0 && comm->world >= 4));
     asr_shard_state* st = nullptr;
-    ASR_TRY(asr_shard_build(ctx, comm, prm->precision != 0 && ctx->opt.sconv_plan, &st));
+    if (own_geometry) {
+        ASR_TRY(implicit_build_sharded(ctx, comm, points, radii, n, prm, &st));
+    } else {
+        ASR_TRY(implicit_build(ctx, points, radii, n, prm));
+        ASR_TRY(asr_shard_build(ctx, comm, prm->precision != 0 && ctx->opt.sconv_plan, &st));
+    }
+    if (sizes) *sizes = ctx->sizes;
     ctx->shard = st;
     const int rc = implicit_network(ctx, points, normals, n, weights, num_weights, prm, values_out);
     ctx->shard = nullptr;

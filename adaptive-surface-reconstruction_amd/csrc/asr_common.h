@@ -109,6 +109,7 @@ struct AsrOptions {
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
+    i64 shard_geometry = -1;      // sharded forward: 1 = lists / plans / search for the owned voxels only, 0 = whole cloud on every rank, -1 = 1 from 4 ranks on
     i64 shard_timing = 0;         // sharded forward: synchronise around every halo exchange and accumulate its wall time
     i64 search_priority = 2;      // priority of the search's stream (set before the first build): 0 lowest, 1 middle, 2 highest
                                   // (round 4: the search is the longer of the two chains; 9.6 -> 8.8 ms on its stream)
@@ -189,6 +190,12 @@ struct asr_hip_context {
     int32_t* agg_spos = nullptr;         // neighbour of each aggregation pair as a position in Morton order
     const float4* agg_sorted = nullptr;  // points in Morton order (x, y, z, original index bits)
     bool has_search = false;             // the last implicit_build ran the aggregation search
+    // sharded geometry: the search covered agg_nq (> 0) rows of grid 0 only -- agg_rows lists them, the CSR above and
+    // the query centres / sizes below are compact over that list
+    const int32_t* agg_rows = nullptr;
+    i64 agg_nq = 0;
+    const float* agg_qcenters = nullptr;
+    const float* agg_qsizes = nullptr;
     AsrPointIndex pindex;                // asr_geom_presort
     int search_extras = 0;               // pairs the last aligned search took from the rounding margin (diagnostic)
     int leaf_lmin = -1, leaf_lmax = -1;  // levels of the first / last leaf of the last octree
@@ -218,6 +225,10 @@ struct asr_hip_context {
     // callers that update weights in place call asr_hip_context_weights_changed (the copies are made again).
     typedef std::tuple<const void*, const void*, i64, i64, i64, i64, int> PackedKey;
     std::map<PackedKey, void*> packed_weights;
+    Arena shard_mem;  // ownership, halo lists and plans of the sharded forward (reset per forward, kept across)
+    unsigned* shard_stage_send = nullptr;  // message staging of the halo exchanges (grow-only)
+    unsigned* shard_stage_recv = nullptr;
+    size_t shard_stage_cap = 0;  // dwords each
     struct asr_shard_state* shard = nullptr;  // set while asr_hip_implicit_forward_sharded runs its network half
 };
 
@@ -319,7 +330,15 @@ int asr_ctx_ensure_aux(asr_hip_context* ctx);  // the search's auxiliary context
 // of the last implicit_build; hooks of the network driver
 struct asr_shard_state;
 int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_plans, asr_shard_state** out);
+// the same in two steps for a rank that builds the 55-slot lists of its own rows only (by_pairs 0: equal voxel counts)
+int asr_shard_ownership(asr_hip_context* ctx, const asr_shard_comm* comm, int by_pairs, asr_shard_state** out);
+int asr_shard_lists(asr_hip_context* ctx, asr_shard_state* st, int want_plans);
+const int32_t* asr_shard_level_rows(const asr_shard_state* st, int level, i64* n);
+int asr_shard_query_rows(asr_hip_context* ctx, const asr_shard_state* st, i64 prefix, Arena& keep, int32_t** rows_out,
+                         i64* n_out);
+int asr_shard_world(const asr_shard_state* st);
 void asr_shard_free(asr_shard_state* st);
+void asr_shard_release(asr_hip_context* ctx);  // the context's shard arena and staging buffers
 const asr_shard_stats* asr_shard_get_stats(const asr_shard_state* st);
 int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void* rs, void* feat, i64 ld_bytes, i64 row_bytes,
                           float* imp, unsigned* in_amax, const int32_t** perm, i64* num_out, const asr_conv_plan** plan);

@@ -72,44 +72,121 @@ __global__ void k_shard_flag_rows(const int32_t* perm, const int32_t* owner, int
     if (i >= n) return;
     flags[i] = owner[perm ? perm[i] : (int32_t)i] == rank ? 1 : 0;
 }
-// halo of one neighbour list: F[d * v_in + i] = rank d needs my input row i, G[s * v_in + i] = I need input row i of rank s
-__global__ void k_shard_halo_flags(const int32_t* idx, const i64* rs, i64 v_out, i64 v_in, const int32_t* owner_out,
-                                   const int32_t* owner_in, int me, uint8_t* F, uint8_t* G) {
-    const i64 r = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (r >= v_out) return;
-    const int d = owner_out[r];
-    for (i64 p = rs[r], pe = rs[r + 1]; p < pe; ++p) {
+__global__ void k_shard_owner_by_count(const int32_t* order, i64 v, int world, int32_t* owner) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= v) return;
+    i64 o = (i * world) / v;
+    owner[order[i]] = (int32_t)(o > world - 1 ? world - 1 : o);
+}
+// ---- all neighbour lists of the hierarchy in one pass each (a rank's forward paid ~330 tiny launches for the per-list form) ----
+constexpr int SHARD_LISTS = 3 * ASR_NUM_GRIDS - 2;
+struct ShardBatch {
+    int n, world, me;
+    i64 out_off[SHARD_LISTS + 1];  // prefix sums of the lists' row counts
+    i64 in_off[SHARD_LISTS + 1];   // prefix sums of world * (input rows)
+    const int32_t* perm[SHARD_LISTS];
+    const int32_t* idx[SHARD_LISTS];
+    const i64* rs[SHARD_LISTS];
+    const int32_t* owner_out[SHARD_LISTS];
+    const int32_t* owner_in[SHARD_LISTS];
+    i64 v_in[SHARD_LISTS];
+    int symmetric[SHARD_LISTS];
+};
+__device__ __forceinline__ int shard_list_of(const i64* off, int n, i64 t) {  // the j with off[j] <= t < off[j + 1]
+    int j = 0;
+    while (j + 1 < n && t >= off[j + 1]) ++j;
+    return j;
+}
+// per output row of every list: is the row at this position of the tiling order mine (rflags), and the halo flags of row r
+// F[in_off[j] + d * v_in + i] = rank d needs my input row i, G[.. s * v_in + i] = I need input row i of rank s.
+// symmetric (55-slot lists that hold this rank's rows only): u is in the row of v exactly when v is in the row of u
+// (cpp/lib/grid.cpp:99-170), so rank s needs my row r exactly when r has a neighbour owned by s
+__global__ void k_shard_flags_batch(ShardBatch b, uint8_t* rflags, uint8_t* F, uint8_t* G) {
+    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (t >= b.out_off[b.n]) return;
+    const int j = shard_list_of(b.out_off, b.n, t);
+    const i64 r = t - b.out_off[j];
+    const int32_t* own = b.owner_out[j];
+    rflags[t] = own[b.perm[j] ? b.perm[j][r] : (int32_t)r] == b.me ? 1 : 0;
+    const int d = own[r];
+    const i64 v_in = b.v_in[j];
+    uint8_t* Fj = F + b.in_off[j];
+    uint8_t* Gj = G + b.in_off[j];
+    const int32_t* idx = b.idx[j];
+    const int32_t* oin = b.owner_in[j];
+    const int sym = b.symmetric[j];
+    for (i64 p = b.rs[j][r], pe = b.rs[j][r + 1]; p < pe; ++p) {
         const i64 i = idx[p];
-        const int s = owner_in[i];
+        const int s = oin[i];
         if (d == s) continue;
-        if (d == me) G[(i64)s * v_in + i] = 1;
-        if (s == me) F[(i64)d * v_in + i] = 1;
-    }
-}
-// selected positions p = peer * v_in + row (ascending): per-peer boundaries and the row index in place
-__global__ void k_shard_split(int32_t* list, const i64* count, i64 v_in, int world, i64* offs) {
-    const i64 n = *count;
-    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (t <= world) {  // offs[t] = first entry of peer t
-        const i64 key = t * v_in;
-        i64 lo = 0, hi = n;
-        while (lo < hi) {
-            const i64 mid = (lo + hi) >> 1;
-            if ((i64)(u32)list[mid] < key)
-                lo = mid + 1;
-            else
-                hi = mid;
+        if (d == b.me) {
+            Gj[(i64)s * v_in + i] = 1;
+            if (sym) Fj[(i64)s * v_in + r] = 1;
         }
-        offs[t] = lo;
+        if (!sym && s == b.me) Fj[(i64)d * v_in + i] = 1;
     }
 }
-__global__ void k_shard_to_rows(int32_t* list, const i64* count, i64 v_in) {
-    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (t < *count) list[t] = (int32_t)((i64)(u32)list[t] % v_in);
+__device__ __forceinline__ i64 shard_lower_bound(const int32_t* a, i64 n, i64 key) {
+    i64 lo = 0, hi = n;
+    while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        if ((i64)(u32)a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+// boundaries of the lists (and, in the halo lists, of the peers) in the three selected-position arrays.  cnt, per list:
+// [0] owned rows [1] send total [2] recv total [3] first owned row [4] first send entry [5] first recv entry
+// [6 ..] world + 1 send offsets (relative), then world + 1 recv offsets
+__global__ void k_shard_bounds_batch(ShardBatch b, const int32_t* sel_perm, const i64* n_perm, const int32_t* sel_send,
+                                     const i64* n_send, const int32_t* sel_recv, const i64* n_recv, i64* cnt, int per) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w1 = b.world + 1;
+    const int each = 1 + 2 * w1;
+    if (t >= b.n * each) return;
+    const int j = t / each, k = t - j * each;
+    i64* c = cnt + (size_t)j * per;
+    if (k == 0) {
+        const i64 a = shard_lower_bound(sel_perm, *n_perm, b.out_off[j]);
+        const i64 e = shard_lower_bound(sel_perm, *n_perm, b.out_off[j + 1]);
+        c[0] = e - a;
+        c[3] = a;
+        return;
+    }
+    const bool send = k <= w1;
+    const int p = send ? k - 1 : k - 1 - w1;
+    const int32_t* sel = send ? sel_send : sel_recv;
+    const i64 n = send ? *n_send : *n_recv;
+    const i64 a = shard_lower_bound(sel, n, b.in_off[j]);
+    const i64 e = shard_lower_bound(sel, n, b.in_off[j] + (i64)p * b.v_in[j]);
+    c[6 + (send ? 0 : w1) + p] = e - a;
+    if (p == 0) c[send ? 4 : 5] = a;
+    if (p == b.world) c[send ? 1 : 2] = e - a;
+}
+// selected positions -> row indices, in place: kind 0 = positions of the tiling orders, 1 = (peer, row) positions
+__global__ void k_shard_rows_batch(ShardBatch b, int32_t* sel, const i64* count, int kind) {
+    const i64 n = *count;
+    for (i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+        const i64 pos = (i64)(u32)sel[t];
+        if (kind == 0) {
+            const int j = shard_list_of(b.out_off, b.n, pos);
+            const i64 r = pos - b.out_off[j];
+            sel[t] = b.perm[j] ? b.perm[j][r] : (int32_t)r;
+        } else {
+            const int j = shard_list_of(b.in_off, b.n, pos);
+            sel[t] = (int32_t)((pos - b.in_off[j]) % b.v_in[j]);
+        }
+    }
 }
 __global__ void k_shard_iota(int32_t* out, i64 n) {
     const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int32_t)i;
+}
+__global__ void k_shard_flag_ge(const int32_t* rows, i64 n, int32_t k, uint8_t* flags) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = rows[i] >= k ? 1 : 0;
 }
 __global__ void k_shard_bounds(const int32_t* sorted_owner, i64 v, int world, i64* offs) {
     const int t = threadIdx.x;
@@ -200,34 +277,41 @@ struct asr_shard_state {
     int rank = 0, world = 1;
     std::map<const void*, ShardCsr> csr;  // keyed by the list's row-splits pointer
     int32_t* owner[ASR_NUM_GRIDS] = {};
+    bool owned_lists = false;  // sharded geometry: the 55-slot lists hold the owned rows only (halo by symmetry)
+    int32_t* level_rows[ASR_NUM_GRIDS] = {};  // sharded geometry: owned rows per level, ascending
+    i64 level_nrows[ASR_NUM_GRIDS] = {};
     int32_t* rows0 = nullptr;  // grid-0 rows grouped by owner (ascending rows within)
     i64 rows0_off[SHARD_MAX_WORLD + 1] = {};
-    Arena mem;
-    unsigned* stage_send = nullptr;
+    Arena* mem = nullptr;  // the context's shard arena: kept (and grown) across forwards, a state lives for one
+    unsigned* stage_send = nullptr;  // (the context's staging buffers, grow-only as well)
     unsigned* stage_recv = nullptr;
-    size_t stage_cap = 0;  // dwords each
     asr_shard_stats stats;
 };
 
 static int shard_stage(asr_hip_context* ctx, asr_shard_state* st, size_t dwords) {
-    if (dwords <= st->stage_cap) return ASR_HIP_OK;
-    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (st->stage_send) (void)hipFree(st->stage_send);
-    if (st->stage_recv) (void)hipFree(st->stage_recv);
-    st->stage_send = st->stage_recv = nullptr;
-    const size_t cap = dwords + dwords / 4 + 1024;
-    ASR_HIP_CHECK(ctx, hipMalloc((void**)&st->stage_send, cap * 4));
-    ASR_HIP_CHECK(ctx, hipMalloc((void**)&st->stage_recv, cap * 4));
-    st->stage_cap = cap;
+    if (dwords > ctx->shard_stage_cap) {  // (a hipMalloc costs ~0.4 ms and a device synchronisation: never per forward)
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->shard_stage_send) (void)hipFree(ctx->shard_stage_send);
+        if (ctx->shard_stage_recv) (void)hipFree(ctx->shard_stage_recv);
+        ctx->shard_stage_send = ctx->shard_stage_recv = nullptr;
+        ctx->shard_stage_cap = 0;
+        const size_t cap = dwords + dwords / 4 + 1024;
+        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->shard_stage_send, cap * 4));
+        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->shard_stage_recv, cap * 4));
+        ctx->shard_stage_cap = cap;
+    }
+    st->stage_send = ctx->shard_stage_send;
+    st->stage_recv = ctx->shard_stage_recv;
     return ASR_HIP_OK;
 }
 
-void asr_shard_free(asr_shard_state* st) {
-    if (!st) return;
-    if (st->stage_send) (void)hipFree(st->stage_send);
-    if (st->stage_recv) (void)hipFree(st->stage_recv);
-    st->mem.release();
-    delete st;
+void asr_shard_free(asr_shard_state* st) { delete st; }
+void asr_shard_release(asr_hip_context* ctx) {
+    if (ctx->shard_stage_send) (void)hipFree(ctx->shard_stage_send);
+    if (ctx->shard_stage_recv) (void)hipFree(ctx->shard_stage_recv);
+    ctx->shard_stage_send = ctx->shard_stage_recv = nullptr;
+    ctx->shard_stage_cap = 0;
+    ctx->shard_mem.release();
 }
 
 const asr_shard_stats* asr_shard_get_stats(const asr_shard_state* st) { return &st->stats; }
@@ -256,7 +340,10 @@ std::vector<ListRef> shard_lists(asr_hip_context* ctx) {
 }
 }  // namespace
 
-int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_plans, asr_shard_state** out) {
+// ownership of the voxels of the five grids.  by_pairs: equal numbers of neighbour pairs per rank (the 55-slot list of grid
+// 0 exists); else equal voxel counts (sharded geometry: ownership is decided BEFORE any list exists), and the owned rows of
+// every level are listed (ascending) for the builders that follow.
+int asr_shard_ownership(asr_hip_context* ctx, const asr_shard_comm* comm, int by_pairs, asr_shard_state** out) {
     *out = nullptr;
     if (!comm || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || comm->world > SHARD_MAX_WORLD)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: bad communicator (world 1..%d)", SHARD_MAX_WORLD);
@@ -274,11 +361,87 @@ int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_p
     st->comm = *comm;
     st->rank = comm->rank;
     st->world = comm->world;
-    st->mem.min_slab = size_t(8) << 20;
+    ctx->shard_mem.min_slab = size_t(64) << 20;
+    ctx->shard_mem.reset();
+    st->mem = &ctx->shard_mem;
     memset(&st->stats, 0, sizeof(st->stats));
+    GridDev* g = ctx->grids;
+    const int world = st->world, me = st->rank;
+    (void)me;
+    if (world == 1) {  // everything is mine
+        guarded = nullptr;
+        *out = st;
+        return ASR_HIP_OK;
+    }
+    ASR_TRY(ensure_flags(ctx));
+    ctx->scratch.reset();
+    // ---- ownership ----
+    const i64 V0 = g[0].v;
+    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+        st->owner[i] = arena_alloc<int32_t>((*st->mem), g[i].v);
+        if (!st->owner[i]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    }
+    {
+        u64* codes = arena_alloc<u64>(ctx->scratch, V0);
+        u64* codes_s = arena_alloc<u64>(ctx->scratch, V0);
+        int32_t* ids = arena_alloc<int32_t>(ctx->scratch, V0);
+        int32_t* order = arena_alloc<int32_t>(ctx->scratch, V0);
+        i64* w = arena_alloc<i64>(ctx->scratch, V0);
+        i64* cum = arena_alloc<i64>(ctx->scratch, V0);
+        if (!codes || !codes_s || !ids || !order || !w || !cum) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_shard_codes<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(g[0].keys, V0, codes, ids);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes, codes_s, ids, order, V0, 63)));
+        if (by_pairs) {
+            k_shard_weights<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, g[0].nrs, V0, w);
+            ASR_CHECK_LAUNCH(ctx);
+            size_t tb = 0;
+            ASR_HIP_CHECK(ctx, rocprim::inclusive_scan(nullptr, tb, w, cum, (size_t)V0, rocprim::plus<i64>(), ctx->stream));
+            void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+            if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_HIP_CHECK(ctx, rocprim::inclusive_scan(tmp, tb, w, cum, (size_t)V0, rocprim::plus<i64>(), ctx->stream));
+            k_shard_owner0<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, w, cum, V0, world, st->owner[0]);
+        } else {
+            k_shard_owner_by_count<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, V0, world, st->owner[0]);
+        }
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    for (int i = 0; i + 1 < ASR_NUM_GRIDS; ++i) {
+        k_shard_coarser<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(st->owner[i], g[i].up_idx, g[i].up_kidx, g[i].v,
+                                                                        st->owner[i + 1]);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    if (!by_pairs) {  // sharded geometry: the owned rows of every level, ascending
+        st->owned_lists = true;
+        i64* d_n = arena_alloc<i64>(ctx->scratch, ASR_NUM_GRIDS);
+        i64 vmax = 0;
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) vmax = std::max(vmax, g[i].v);
+        uint8_t* fl = arena_alloc<uint8_t>(ctx->scratch, vmax);
+        if (!d_n || !fl) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+            st->level_rows[i] = arena_alloc<int32_t>((*st->mem), g[i].v);
+            if (!st->level_rows[i]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+            k_shard_flag_rows<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(nullptr, st->owner[i], me, g[i].v, fl);
+            ASR_CHECK_LAUNCH(ctx);
+            ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), fl, st->level_rows[i], d_n + i, (size_t)g[i].v));
+        }
+        i64 h_n[ASR_NUM_GRIDS];
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) st->level_nrows[i] = h_n[i];
+    }
+    guarded = nullptr;
+    *out = st;
+    return ASR_HIP_OK;
+}
+
+// the rest of the shard state once the neighbour lists and their tiling orders exist: owned rows in tiling order, plans,
+// halo lists, stitch lists
+int asr_shard_lists(asr_hip_context* ctx, asr_shard_state* st, int want_plans) {
     GridDev* g = ctx->grids;
     const std::vector<ListRef> L = shard_lists(ctx);
     const int world = st->world, me = st->rank;
+    const i64 V0 = g[0].v;
     if (world == 1) {  // everything is mine: the monolithic driver's own orders and plans
         for (const ListRef& l : L) {
             ShardCsr c;
@@ -294,95 +457,66 @@ int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_p
             st->csr[l.rs] = c;
         }
         for (int i = 0; i < ASR_NUM_GRIDS; ++i) st->stats.owned_rows[i] = g[i].v;
-        guarded = nullptr;
-        *out = st;
         return ASR_HIP_OK;
     }
-    ASR_TRY(ensure_flags(ctx));
     ctx->scratch.reset();
-    // ---- ownership ----
-    const i64 V0 = g[0].v;
-    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
-        st->owner[i] = arena_alloc<int32_t>(st->mem, g[i].v);
-        if (!st->owner[i]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    }
-    {
-        u64* codes = arena_alloc<u64>(ctx->scratch, V0);
-        u64* codes_s = arena_alloc<u64>(ctx->scratch, V0);
-        int32_t* ids = arena_alloc<int32_t>(ctx->scratch, V0);
-        int32_t* order = arena_alloc<int32_t>(ctx->scratch, V0);
-        i64* w = arena_alloc<i64>(ctx->scratch, V0);
-        i64* cum = arena_alloc<i64>(ctx->scratch, V0);
-        if (!codes || !codes_s || !ids || !order || !w || !cum) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_shard_codes<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(g[0].keys, V0, codes, ids);
-        ASR_CHECK_LAUNCH(ctx);
-        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes, codes_s, ids, order, V0, 63)));
-        k_shard_weights<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, g[0].nrs, V0, w);
-        ASR_CHECK_LAUNCH(ctx);
-        size_t tb = 0;
-        ASR_HIP_CHECK(ctx, rocprim::inclusive_scan(nullptr, tb, w, cum, (size_t)V0, rocprim::plus<i64>(), ctx->stream));
-        void* tmp = ctx->scratch.alloc(tb ? tb : 256);
-        if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_HIP_CHECK(ctx, rocprim::inclusive_scan(tmp, tb, w, cum, (size_t)V0, rocprim::plus<i64>(), ctx->stream));
-        k_shard_owner0<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, w, cum, V0, world, st->owner[0]);
-        ASR_CHECK_LAUNCH(ctx);
-    }
-    for (int i = 0; i + 1 < ASR_NUM_GRIDS; ++i) {
-        k_shard_coarser<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(st->owner[i], g[i].up_idx, g[i].up_kidx, g[i].v,
-                                                                        st->owner[i + 1]);
-        ASR_CHECK_LAUNCH(ctx);
-    }
     // ---- per list: owned rows in tiling order, halo lists (device passes first, ONE read-back of all sizes) ----
     const int nl = (int)L.size();
-    // device counters: per list [0] owned rows, [1] send total, [2] recv total, then (world + 1) send offsets, (world + 1)
-    // recv offsets; + the stitch offsets
-    const int per = 3 + 2 * (world + 1);
-    i64* d_cnt = arena_alloc<i64>(ctx->scratch, (size_t)nl * per + world + 1);
+    if (nl != SHARD_LISTS) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "sharded forward: %d neighbour lists?", nl);
+    // device counters per list: see k_shard_bounds_batch; + the stitch offsets
+    const int per = 6 + 2 * (world + 1);
+    i64* d_cnt = arena_alloc<i64>(ctx->scratch, (size_t)nl * per + world + 1 + 3);
     if (!d_cnt) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nl * per + world + 1) * sizeof(i64), ctx->stream));
-    std::vector<int32_t*> t_perm(nl), t_send(nl), t_recv(nl);
-    i64 v_in_max = 0;
-    for (const ListRef& l : L) v_in_max = std::max(v_in_max, l.v_in);
-    uint8_t* F = arena_alloc<uint8_t>(ctx->scratch, (size_t)world * v_in_max);
-    uint8_t* G = arena_alloc<uint8_t>(ctx->scratch, (size_t)world * v_in_max);
-    uint8_t* rflags = arena_alloc<uint8_t>(ctx->scratch, (size_t)std::max(v_in_max, g[0].v));
-    if (!F || !G || !rflags) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, ((size_t)nl * per + world + 1 + 3) * sizeof(i64), ctx->stream));
+    i64* d_tot = d_cnt + (size_t)nl * per + world + 1;  // selected: owned rows, send entries, recv entries
+    ShardBatch B;
+    B.n = nl;
+    B.world = world;
+    B.me = me;
+    B.out_off[0] = B.in_off[0] = 0;
+    size_t cap = 0;  // a rank sends / receives an input row at most once per peer, and no more entries than the list has pairs
     for (int j = 0; j < nl; ++j) {
         const ListRef& l = L[j];
-        i64* cnt = d_cnt + (size_t)j * per;
-        // owned output rows, in tiling order
-        t_perm[j] = arena_alloc<int32_t>(st->mem, l.v_out);
-        if (!t_perm[j]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_shard_flag_rows<<<grid_for(l.v_out, BLK), BLK, 0, ctx->stream>>>(l.perm, st->owner[l.lvl_out], me, l.v_out, rflags);
-        ASR_CHECK_LAUNCH(ctx);
-        if (l.perm)
-            ASR_TRY(shard_select(ctx, l.perm, rflags, t_perm[j], cnt + 0, (size_t)l.v_out));
-        else
-            ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), rflags, t_perm[j], cnt + 0, (size_t)l.v_out));
-        // halo flags -> ascending (peer, row) lists
-        const size_t nf = (size_t)world * l.v_in;
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(F, 0, nf, ctx->stream));
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(G, 0, nf, ctx->stream));
-        k_shard_halo_flags<<<grid_for(l.v_out, BLK), BLK, 0, ctx->stream>>>(l.idx, l.rs, l.v_out, l.v_in, st->owner[l.lvl_out],
-                                                                           st->owner[l.lvl_in], me, F, G);
-        ASR_CHECK_LAUNCH(ctx);
-        if (nf >= (size_t(1) << 31)) ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: world x voxels exceeds 2^31");
-        // a rank sends / receives at most all input rows once per peer; the lists are bounded by the list's pair count too
-        const size_t cap = std::min<size_t>(nf, (size_t)std::max<i64>(l.v_out * (l.K == 55 ? 55 : 8), 1));
-        t_send[j] = arena_alloc<int32_t>(ctx->scratch, cap);
-        t_recv[j] = arena_alloc<int32_t>(ctx->scratch, cap);
-        if (!t_send[j] || !t_recv[j]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), F, t_send[j], cnt + 1, nf));
-        ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), G, t_recv[j], cnt + 2, nf));
-        k_shard_split<<<1, 128, 0, ctx->stream>>>(t_send[j], cnt + 1, l.v_in, world, cnt + 3);
-        k_shard_split<<<1, 128, 0, ctx->stream>>>(t_recv[j], cnt + 2, l.v_in, world, cnt + 3 + world + 1);
-        ASR_CHECK_LAUNCH(ctx);
+        B.out_off[j + 1] = B.out_off[j] + l.v_out;
+        B.in_off[j + 1] = B.in_off[j] + (i64)world * l.v_in;
+        B.perm[j] = l.perm;
+        B.idx[j] = l.idx;
+        B.rs[j] = l.rs;
+        B.owner_out[j] = st->owner[l.lvl_out];
+        B.owner_in[j] = st->owner[l.lvl_in];
+        B.v_in[j] = l.v_in;
+        B.symmetric[j] = st->owned_lists && l.K == 55 ? 1 : 0;
+        cap += std::min<size_t>((size_t)world * l.v_in, (size_t)std::max<i64>(l.K == 55 ? g[l.lvl_out].p : g[std::min(l.lvl_out, l.lvl_in)].v, 1));
     }
+    const i64 n_out = B.out_off[nl], n_in = B.in_off[nl];
+    if (n_in >= (i64(1) << 31) || n_out >= (i64(1) << 31))
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: world x voxels exceeds 2^31");
+    uint8_t* F = arena_alloc<uint8_t>(ctx->scratch, (size_t)n_in);
+    uint8_t* G = arena_alloc<uint8_t>(ctx->scratch, (size_t)n_in);
+    uint8_t* rflags = arena_alloc<uint8_t>(ctx->scratch, (size_t)n_out);
+    int32_t* sel_perm = arena_alloc<int32_t>((*st->mem), (size_t)n_out);
+    int32_t* sel_send = arena_alloc<int32_t>(ctx->scratch, cap);
+    int32_t* sel_recv = arena_alloc<int32_t>(ctx->scratch, cap);
+    if (!F || !G || !rflags || !sel_perm || !sel_send || !sel_recv) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(F, 0, (size_t)n_in, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(G, 0, (size_t)n_in, ctx->stream));
+    k_shard_flags_batch<<<grid_for(n_out, BLK), BLK, 0, ctx->stream>>>(B, rflags, F, G);
+    ASR_CHECK_LAUNCH(ctx);
+    ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), rflags, sel_perm, d_tot + 0, (size_t)n_out));
+    ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), F, sel_send, d_tot + 1, (size_t)n_in));
+    ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), G, sel_recv, d_tot + 2, (size_t)n_in));
+    k_shard_bounds_batch<<<grid_for((i64)nl * (1 + 2 * (world + 1)), 128), 128, 0, ctx->stream>>>(
+            B, sel_perm, d_tot + 0, sel_send, d_tot + 1, sel_recv, d_tot + 2, d_cnt, per);
+    ASR_CHECK_LAUNCH(ctx);
+    k_shard_rows_batch<<<1024, BLK, 0, ctx->stream>>>(B, sel_perm, d_tot + 0, 0);
+    k_shard_rows_batch<<<256, BLK, 0, ctx->stream>>>(B, sel_send, d_tot + 1, 1);
+    k_shard_rows_batch<<<256, BLK, 0, ctx->stream>>>(B, sel_recv, d_tot + 2, 1);
+    ASR_CHECK_LAUNCH(ctx);
     // stitch: grid-0 rows grouped by owner
     {
         int32_t* ids = arena_alloc<int32_t>(ctx->scratch, V0);
         int32_t* own_s = arena_alloc<int32_t>(ctx->scratch, V0);
-        st->rows0 = arena_alloc<int32_t>(st->mem, V0);
+        st->rows0 = arena_alloc<int32_t>((*st->mem), V0);
         if (!ids || !own_s || !st->rows0) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         k_shard_iota<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(ids, V0);
         ASR_CHECK_LAUNCH(ctx);
@@ -390,44 +524,37 @@ int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_p
         k_shard_bounds<<<1, 128, 0, ctx->stream>>>(own_s, V0, world, d_cnt + (size_t)nl * per);
         ASR_CHECK_LAUNCH(ctx);
     }
-    std::vector<i64> h_cnt((size_t)nl * per + world + 1);
+    std::vector<i64> h_cnt((size_t)nl * per + world + 1 + 3);
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(h_cnt.data(), d_cnt, h_cnt.size() * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int p = 0; p <= world; ++p) st->rows0_off[p] = h_cnt[(size_t)nl * per + p];
-    // exact-size halo lists (rows instead of (peer, row) positions), plans of the owned rows
+    // exact-size halo lists, plans of the owned rows
+    const i64 tot_send = h_cnt[(size_t)nl * per + world + 1 + 1], tot_recv = h_cnt[(size_t)nl * per + world + 1 + 2];
+    int32_t* send_all = arena_alloc<int32_t>((*st->mem), (size_t)std::max<i64>(tot_send, 1));
+    int32_t* recv_all = arena_alloc<int32_t>((*st->mem), (size_t)std::max<i64>(tot_recv, 1));
+    if (!send_all || !recv_all) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    if (tot_send > 0)
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(send_all, sel_send, tot_send * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    if (tot_recv > 0)
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(recv_all, sel_recv, tot_recv * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
     std::vector<asr_conv_plan> plans;
     std::vector<int> plan_of;
     for (int j = 0; j < nl; ++j) {
         const ListRef& l = L[j];
         const i64* c = &h_cnt[(size_t)j * per];
         ShardCsr cs;
-        cs.perm = t_perm[j];
+        cs.perm = sel_perm + c[3];
         cs.num_out = c[0];
         const i64 ns = c[1], nr = c[2];
-        i64* cnt = d_cnt + (size_t)j * per;
-        if (ns > 0) {
-            int32_t* rows = arena_alloc<int32_t>(st->mem, ns);
-            if (!rows) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            k_shard_to_rows<<<grid_for(ns, BLK), BLK, 0, ctx->stream>>>(t_send[j], cnt + 1, l.v_in);
-            ASR_CHECK_LAUNCH(ctx);
-            ASR_HIP_CHECK(ctx, hipMemcpyAsync(rows, t_send[j], ns * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-            cs.send_rows = rows;
-        }
-        if (nr > 0) {
-            int32_t* rows = arena_alloc<int32_t>(st->mem, nr);
-            if (!rows) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            k_shard_to_rows<<<grid_for(nr, BLK), BLK, 0, ctx->stream>>>(t_recv[j], cnt + 2, l.v_in);
-            ASR_CHECK_LAUNCH(ctx);
-            ASR_HIP_CHECK(ctx, hipMemcpyAsync(rows, t_recv[j], nr * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-            cs.recv_rows = rows;
-        }
+        if (ns > 0) cs.send_rows = send_all + c[4];
+        if (nr > 0) cs.recv_rows = recv_all + c[5];
         for (int p = 0; p < world; ++p) {
-            const i64 s0 = c[3 + p], s1 = c[3 + p + 1];
+            const i64 s0 = c[6 + p], s1 = c[6 + p + 1];
             if (s1 > s0) {
                 cs.send_peer.push_back(p);
                 cs.send_first.push_back(s0);
             }
-            const i64 r0 = c[3 + world + 1 + p], r1 = c[3 + world + 1 + p + 1];
+            const i64 r0 = c[6 + world + 1 + p], r1 = c[6 + world + 1 + p + 1];
             if (r1 > r0) {
                 cs.recv_peer.push_back(p);
                 cs.recv_first.push_back(r0);
@@ -451,17 +578,60 @@ int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_p
         }
     }
     if (!plans.empty()) {
-        ASR_TRY(asr_geom_conv_plan_batch(ctx, st->mem, plans.data(), (int)plans.size()));
+        ASR_TRY(asr_geom_conv_plan_batch(ctx, (*st->mem), plans.data(), (int)plans.size()));
         for (size_t q = 0; q < plans.size(); ++q) {
             ShardCsr& cs = st->csr[L[plan_of[q]].rs];
             cs.plan = plans[q];
             cs.has_plan = true;
         }
     }
-    guarded = nullptr;
+    return ASR_HIP_OK;
+}
+
+// ownership by pair counts + lists: the geometry of the whole cloud is on every rank
+int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_plans, asr_shard_state** out) {
+    *out = nullptr;
+    asr_shard_state* st = nullptr;
+    ASR_TRY(asr_shard_ownership(ctx, comm, 1, &st));
+    const int rc = asr_shard_lists(ctx, st, want_plans);
+    if (rc != ASR_HIP_OK) {
+        asr_shard_free(st);
+        return rc;
+    }
     *out = st;
     return ASR_HIP_OK;
 }
+const int32_t* asr_shard_level_rows(const asr_shard_state* st, int level, i64* n) {
+    *n = st->level_nrows[level];
+    return st->level_rows[level];
+}
+// rows the aggregation of a rank with sharded geometry covers: [0, prefix) (the importance of the first V0
+// PAIRS is read by every rank) followed by the owned rows >= prefix, ascending
+int asr_shard_query_rows(asr_hip_context* ctx, const asr_shard_state* st, i64 prefix, Arena& keep, int32_t** rows_out,
+                         i64* n_out) {
+    const i64 n_own = st->level_nrows[0];
+    int32_t* q = arena_alloc<int32_t>(keep, prefix + n_own);
+    uint8_t* fl = arena_alloc<uint8_t>(ctx->scratch, n_own > 0 ? n_own : 1);
+    i64* d_n = arena_alloc<i64>(ctx->scratch, 1);
+    if (!q || !fl || !d_n) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    if (prefix > 0) {
+        k_shard_iota<<<grid_for(prefix, BLK), BLK, 0, ctx->stream>>>(q, prefix);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    i64 h_n = 0;
+    if (n_own > 0) {
+        k_shard_flag_ge<<<grid_for(n_own, BLK), BLK, 0, ctx->stream>>>(st->level_rows[0], n_own, (int32_t)prefix, fl);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(shard_select(ctx, st->level_rows[0], fl, q + prefix, d_n, (size_t)n_own));
+        ASR_HIP_CHECK(ctx, hipMemcpyAsync(&h_n, d_n, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
+        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *rows_out = q;
+    *n_out = prefix + h_n;
+    return ASR_HIP_OK;
+}
+int asr_shard_rank(const asr_shard_state* st) { return st->rank; }
+int asr_shard_world(const asr_shard_state* st) { return st->world; }
 
 // before a convolution over the list `rs`: the rows it computes (perm, num_out, plan), the halo exchange of its input and
 // -- f16x2: in_amax, the running maximum the producers of the input buffer kept over the rows THEY wrote -- the maximum

@@ -1,0 +1,67 @@
+"""Compute time of ONE RANK of a one-scan sharding of the 10 M-point bench cloud, on one GPU, with a transport that moves
+nothing (the halo rows keep stale values: the numbers of this run are times, not results).  Ownership, halo lists and
+plans need no communication, so the rank does exactly the work it would do beside `world - 1` peers; what is missing is
+the wire time of the exchanges (bytes per forward are printed).  A PROJECTION of the per-rank compute, not a scaling
+measurement.  usage: python scripts/shard_dry_run.py [n_points]"""
+import ctypes, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd")]
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import torch
+from asr_hip import _lib, synth
+from asr_hip.pipeline import ImplicitPipeline
+
+
+class NullComm:
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self._ex = _lib.SHARD_EXCHANGE_FN(lambda *a: 0)
+        self._ar = _lib.SHARD_ALLREDUCE_FN(lambda *a: 0)
+        self._c = _lib.ShardComm(None, rank, world, self._ex, self._ar, _lib.SHARD_EXCHANGE_MAX_FN())
+
+    def handle(self):
+        return ctypes.byref(self._c)
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+only = [int(x) for x in sys.argv[2:5]] if len(sys.argv) >= 5 else None  # world rank shard_geometry
+dev = torch.device("cuda:0")
+pts, nrm = synth.scan_cloud(n, seed=1000, device=dev)
+radii = synth.knn_radii_gpu(pts, 24)
+bb = synth.bounding_box(pts, 0.1)
+w = synth.make_weights(1, seed=0, init="reference")
+pipe = ImplicitPipeline(w, device=dev, precision="f16x2")
+
+
+def run(name, f, reps=6):
+    for _ in range(2):
+        f()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps * 1e3
+    st = pipe.stage_ms()
+    extra = ""
+    if pipe.shard_stats:
+        s = pipe.shard_stats
+        extra = " owned0 %d halo0 %d sent %.1f MB recv %.1f MB" % (s["owned_rows"][0], s["halo_rows_recv"][0],
+                                                                   s["bytes_sent"] / 1e6, s["bytes_received"] / 1e6)
+    print("%-34s %6.2f ms  geometry %.2f network %.2f%s" % (name, dt, list(st.values())[6], list(st.values())[7], extra), flush=True)
+
+
+pipe.shard_stats = None
+if only:
+    pipe.ctx.set_option("shard_geometry", only[2])
+    c = NullComm(only[1], only[0])
+    run("world %d rank %d shard_geometry %d" % tuple(only), lambda: pipe.forward_sharded(c, pts, nrm, radii, bb[0], bb[1]), reps=3)
+    sys.exit(0)
+run("monolithic", lambda: pipe.forward(pts, nrm, radii, bb[0], bb[1]))
+for world in (2, 4, 8):
+    for geom in (0, 1):
+        pipe.ctx.set_option("shard_geometry", geom)
+        for rank in sorted({0, world // 2, world - 1}):
+            c = NullComm(rank, world)
+            run("world %d rank %d shard_geometry %d" % (world, rank, geom),
+                lambda: pipe.forward_sharded(c, pts, nrm, radii, bb[0], bb[1]))

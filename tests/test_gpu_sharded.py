@@ -125,7 +125,7 @@ def test_sharded_geometry_equals_single_process(gpu, world, fused, precision):
 
 
 # ---- the sharded forward INSIDE the library (asr_hip_implicit_forward_sharded, round 4) ------------------------------
-def _native_worker(rank, world, port, n_points, channel_div, precision, out, fused=0):
+def _native_worker(rank, world, port, n_points, channel_div, precision, out, fused=0, shard_geometry=0):
     sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd"), os.path.join(REPO, "tests")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -142,6 +142,7 @@ def _native_worker(rank, world, port, n_points, channel_div, precision, out, fus
     bb = synth.bounding_box(pts, 0.1)
     weights = synth.make_weights(channel_div, seed=6)
     pipe = ImplicitPipeline(weights, device=dev, precision=precision)
+    pipe.ctx.set_option("shard_geometry", shard_geometry)
     comm = shardcomm.HostStagedComm()
     full = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1]).clone()
     again = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1])  # a second forward on the same context
@@ -184,6 +185,34 @@ def test_library_sharded_forward_equals_single_process(gpu, world, n_points, cha
     assert all(i["stats"]["halo_rows_recv"][0] > 0 and i["stats"]["exchanges"] > 40 for i in infos)
     owned = [i["stats"]["owned_rows"][0] for i in infos]
     assert max(owned) < 1.6 * min(owned)  # equal pair counts per rank give similar row counts
+
+
+@pytest.mark.parametrize("world,n_points,channel_div,precision,fused",
+                         [(2, 30000, 2, "f32", 0), (3, 8000, 1, "f16x2", 0), (2, 48000, 2, "bf16x3", 0),
+                          (3, 64000, 2, "f16x2", 8), (4, 200000, 1, "f16x2", 0), (2, 1000000, 1, "f16x2", 0)])
+def test_library_sharded_geometry_equals_single_process(gpu, world, n_points, channel_div, precision, fused):
+    """option shard_geometry = 1: octree, voxel keys and up / down lists on every rank; 55-slot neighbour lists, row-group
+    plans, aggregation search and continuous conv for the owned voxels only (+ the importance prefix of SURVEY B.2), send
+    lists from the symmetry of the neighbour relation -- all inside libasr_hip.so.  Values equal the single-process
+    forward bit for bit."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, n_points, channel_div, precision, out, fused, 1))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    infos = sorted([out.get(timeout=900) for _ in range(world)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = infos[0]
+    assert r0["equal"], r0["max_abs_diff"]
+    assert all(i["repeat_equal"] for i in infos)
+    assert sum(i["stats"]["owned_rows"][0] for i in infos) == r0["v0"]
+    assert all(i["stats"]["halo_rows_recv"][0] > 0 for i in infos)
+    owned = [i["stats"]["owned_rows"][0] for i in infos]
+    assert max(owned) - min(owned) <= 1  # equal voxel counts per rank
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x2"])

@@ -999,6 +999,25 @@ int build_tilings_and_plans(asr_hip_context* ctx, asr_hip_context* on, int preci
     return ASR_HIP_OK;
 }
 
+// gathers of the compact query list of a rank with sharded geometry, and the scatter of its aggregated rows
+__global__ void k_gather_queries(const int32_t* rows, i64 nq, const float* centers, const float* sizes, const u64* keys,
+                                 float* qc, float* qs, u64* qk) {
+    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const i64 r = rows[i];
+    qc[3 * i] = centers[3 * r];
+    qc[3 * i + 1] = centers[3 * r + 1];
+    qc[3 * i + 2] = centers[3 * r + 2];
+    qs[i] = sizes[r];
+    qk[i] = keys[r];
+}
+__global__ void k_scatter_rows(const float* src, const int32_t* rows, i64 nq, int c, float* dst) {
+    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    if (t >= nq * c) return;
+    const i64 i = t / c;
+    dst[(i64)rows[i] * c + (t - i * c)] = src[t];
+}
+
 // what every build starts with: nothing of the previous build survives
 int build_begin(asr_hip_context* ctx, i64 n, const asr_implicit_params* prm) {
     ASR_TRY(ensure_events(ctx));
@@ -1086,8 +1105,21 @@ int build_grid_names(asr_hip_context* ctx) {
     return ASR_HIP_OK;
 }
 
+// comm / st_out (both or neither): the build of ONE RANK of a cloud cut into Morton ranges (option
+// shard_geometry): octree, voxel keys and the one-entry-per-voxel up / down lists of all five grids on every rank -- cheap
+// integer work that ownership is derived from -- and the expensive parts for the voxels this rank owns only: 55-slot
+// neighbour lists, row-group plans, the aggregation search (+ the importance prefix, see the search below).
 int implicit_build(asr_hip_context* ctx, const float* points, const float* radii, i64 n,
-                   const asr_implicit_params* prm) {
+                   const asr_implicit_params* prm, const asr_shard_comm* comm = nullptr,
+                   asr_shard_state** st_out = nullptr) {
+    asr_shard_state* st = nullptr;
+    struct ShardGuard {  // the state is the caller's only after a complete build
+        asr_shard_state*& st;
+        bool keep = false;
+        ~ShardGuard() {
+            if (!keep && st) asr_shard_free(st);
+        }
+    } shard_guard{st};
     ASR_TRY(build_begin(ctx, n, prm));
     // Aggregation neighbours (cpp/lib/asr.cpp:266-273) on the auxiliary context: its own stream, arenas,
     // counters and host thread, overlapped with the grid hierarchy below.  Both are chains of
@@ -1160,6 +1192,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
 
     // level-0 voxel centres / sizes first: the aggregation search only needs those
     ASR_TRY(build_level0(ctx));
+    if (comm) ASR_TRY(asr_shard_ownership(ctx, comm, 0, &st));  // grid 0 by voxel count: no list exists yet
 
     if (want_search) asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264 (here: concurrent with the grids)
     if (overlap) ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_ev, ctx->stream));  // the level-0 voxel centres / sizes are ready
@@ -1171,19 +1204,60 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             ctx->scratch.reset();
         }
         GridDev& g0 = ctx->grids[0];
-        ctx->agg_rs = arena_alloc<i64>(sc->persist, g0.v + 1);
-        if (!ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
-                                      &agg_pairs, &sc->persist, radii, g0.keys, ctx->leaf_lmin, ctx->leaf_lmax,
-                                      sc->pindex.valid ? &sc->pindex : nullptr));
+        const float* qc = g0.centers;
+        const float* qs = g0.sizes;
+        const u64* qk = g0.keys;
+        i64 nq = g0.v;
+        if (st && asr_shard_world(st) > 1) {
+            // One rank of a sharded cloud searches [0, prefix) + the rows it owns.  SURVEY B.2: encblock0 reads the
+            // importance of the first V0 PAIRS of the whole cloud's CSR; those belong to the first few percent of the
+            // voxels in index order, which every rank therefore searches itself (no communication).
+            ArenaMark before;
+            arena_mark(sc->persist, before);
+            i64 prefix = std::min<i64>(g0.v, std::max<i64>(1024, g0.v / 8));
+            for (;;) {
+                arena_rewind(sc->persist, before);
+                int32_t* qrows = nullptr;
+                ASR_TRY(asr_shard_query_rows(sc, st, prefix, sc->persist, &qrows, &nq));
+                float* c = arena_alloc<float>(sc->persist, 3 * nq);
+                float* z = arena_alloc<float>(sc->persist, nq);
+                u64* k = arena_alloc<u64>(sc->persist, nq);
+                ctx->agg_rs = arena_alloc<i64>(sc->persist, nq + 1);
+                if (!c || !z || !k || !ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
+                k_gather_queries<<<grid_for(nq, 256), 256, 0, sc->stream>>>(qrows, nq, g0.centers, g0.sizes, g0.keys, c, z, k);
+                ASR_CHECK_LAUNCH(sc);
+                ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, c, z, nq, ctx->agg_rs, &agg_pairs, &sc->persist,
+                                              radii, k, ctx->leaf_lmin, ctx->leaf_lmax, sc->pindex.valid ? &sc->pindex : nullptr));
+                i64 prefix_pairs = 0;
+                ASR_HIP_CHECK(sc, hipMemcpyAsync(&prefix_pairs, ctx->agg_rs + prefix, sizeof(i64), hipMemcpyDeviceToHost, sc->stream));
+                ASR_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
+                if (prefix_pairs < g0.v && prefix < g0.v) {
+                    prefix = std::min<i64>(g0.v, 2 * prefix);
+                    continue;
+                }
+                // (prefix == V0 and fewer pairs than voxels: implicit_network reports the reference's out-of-range indexing)
+                ctx->agg_rows = qrows;
+                ctx->agg_nq = nq;
+                ctx->agg_qcenters = qc = c;
+                ctx->agg_qsizes = qs = z;
+                break;
+            }
+        } else {
+            ctx->agg_rs = arena_alloc<i64>(sc->persist, g0.v + 1);
+            if (!ctx->agg_rs) ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
+            ASR_TRY(asr_geom_radius_count(sc, &ctx->frame, points, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs,
+                                          &agg_pairs, &sc->persist, radii, g0.keys, ctx->leaf_lmin, ctx->leaf_lmax,
+                                          sc->pindex.valid ? &sc->pindex : nullptr));
+        }
         ctx->agg_idx = arena_alloc<int32_t>(sc->persist, agg_pairs);
         ctx->agg_dist = arena_alloc<float>(sc->persist, agg_pairs);
         ctx->agg_compat = arena_alloc<float>(sc->persist, agg_pairs);
         ctx->agg_spos = arena_alloc<int32_t>(sc->persist, agg_pairs);
         if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat || !ctx->agg_spos)
             ASR_FAIL(sc, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_radius_fill(sc, points, radii, n, g0.centers, g0.sizes, g0.v, ctx->agg_rs, ctx->agg_idx,
+        ASR_TRY(asr_geom_radius_fill(sc, points, radii, n, qc, qs, nq, ctx->agg_rs, ctx->agg_idx,
                                      ctx->agg_dist, ctx->agg_compat, ctx->agg_spos, &ctx->agg_sorted));
+        (void)qk;
         if (sc != ctx) {
             ASR_HIP_CHECK(sc, hipEventRecord(ctx->aux_t1, sc->stream));
             ASR_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
@@ -1198,10 +1272,17 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     // -- the coarse grids used to pay a level-0 kernel's latency each, five times over); the MFMA tiling orders of all
     // 13 CSRs are computed in one batch at the end.
     ASR_TRY(build_coarse_grids(ctx));
+    if (st) ASR_TRY(asr_shard_ownership_coarser(ctx, st));
     {
         ctx->scratch.reset();
         asr_nb_job nb[ASR_NUM_GRIDS];
-        for (int i = 0; i < ASR_NUM_GRIDS; ++i) nb[i] = asr_nb_job{ctx->grids[i].keys, ctx->grids[i].v, nullptr, nullptr, nullptr, 0};
+        for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+            nb[i] = asr_nb_job{ctx->grids[i].keys, ctx->grids[i].v, nullptr, nullptr, nullptr, 0};
+            if (st && asr_shard_world(st) > 1) {  // this rank's rows only
+                nb[i].owner = asr_shard_owner(st, i);
+                nb[i].me = asr_shard_rank(st);
+            }
+        }
         ASR_TRY(asr_geom_neighbors_build_batch(ctx, ctx->persist, nb, ASR_NUM_GRIDS));
         for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
             GridDev& g = ctx->grids[i];
@@ -1214,7 +1295,12 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
     ASR_TRY(build_grid_names(ctx));
     // MFMA tiling orders + row-group plans.  (Deferring them to the auxiliary stream beside the continuous conv of the network
     // half -- only the U-Net needs them -- was measured again in round 4: geometry wall 9.5 -> 8.5-8.9 ms, network wall + 1.2 ms.)
-    ASR_TRY(build_tilings_and_plans(ctx, ctx, prm->precision));
+    if (st) {  // tiling orders of all rows; the plans are this rank's (asr_shard_lists)
+        ASR_TRY(build_tilings_and_plans(ctx, ctx, 0));
+        ASR_TRY(asr_shard_lists(ctx, st, prm->precision != 0 && ctx->opt.sconv_plan));
+    } else {
+        ASR_TRY(build_tilings_and_plans(ctx, ctx, prm->precision));
+    }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 
     if (overlap)
@@ -1232,140 +1318,18 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * agg_pairs);
         name_it(ctx, "aggregation_neighbors_dist", ctx->agg_dist, 4 * agg_pairs);
         name_it(ctx, "aggregation_scale_compat", ctx->agg_compat, 4 * agg_pairs);
-        name_it(ctx, "aggregation_row_splits", ctx->agg_rs, 8 * (g0.v + 1));
+        name_it(ctx, "aggregation_row_splits", ctx->agg_rs, 8 * ((ctx->agg_nq > 0 ? ctx->agg_nq : g0.v) + 1));
+        if (ctx->agg_nq > 0) name_it(ctx, "aggregation_rows", const_cast<int32_t*>(ctx->agg_rows), 4 * ctx->agg_nq);
     }
     ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     // everything implicit_network allocates from the persist arena goes above this mark, so that
     // repeated network() calls on one build do not grow the arena
     arena_mark(ctx->persist, ctx->build_mark);
     ctx->build_mark_ok = true;
-    return ASR_HIP_OK;
-}
-
-// gathers of the compact query list of a rank with sharded geometry, and the scatter of its aggregated rows
-__global__ void k_gather_queries(const int32_t* rows, i64 nq, const float* centers, const float* sizes, const u64* keys,
-                                 float* qc, float* qs, u64* qk) {
-    const i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    const i64 r = rows[i];
-    qc[3 * i] = centers[3 * r];
-    qc[3 * i + 1] = centers[3 * r + 1];
-    qc[3 * i + 2] = centers[3 * r + 2];
-    qs[i] = sizes[r];
-    qk[i] = keys[r];
-}
-__global__ void k_scatter_rows(const float* src, const int32_t* rows, i64 nq, int c, float* dst) {
-    const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
-    if (t >= nq * c) return;
-    const i64 i = t / c;
-    dst[(i64)rows[i] * c + (t - i * c)] = src[t];
-}
-
-// The build of ONE RANK of a cloud cut into Morton ranges (option shard_geometry): octree, voxel keys and the
-// one-entry-per-voxel up / down lists of all five grids on every rank -- cheap integer work that ownership is derived
-// from -- and the expensive parts for the voxels this rank owns only: 55-slot neighbour lists (asr_geom_neighbors_rows_*),
-// row-group plans, the aggregation search.  One stream, no overlap: every step is 1/world of the monolithic one.
-int implicit_build_sharded(asr_hip_context* ctx, const asr_shard_comm* comm, const float* points, const float* radii, i64 n,
-                           const asr_implicit_params* prm, asr_shard_state** st_out) {
-    *st_out = nullptr;
-    ASR_TRY(build_begin(ctx, n, prm));
-    ctx->search_overlapped = false;
-    ctx->pindex.valid = false;
-    ASR_TRY(asr_geom_octree_build(ctx, &ctx->frame, points, radii, n, prm->point_radius_scale, prm->octree_max_depth));
-    ctx->sizes.num_nodes = ctx->num_nodes;
-    name_it(ctx, "nodes", ctx->nodes, 8 * ctx->num_nodes);
-    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    if (ctx->num_leaves == 0) ASR_FAIL(ctx, ASR_HIP_EINVAL, "no point inside the bounding box");
-    ASR_TRY(build_level0(ctx));
-    ASR_TRY(build_coarse_grids(ctx));
-    GridDev* g = ctx->grids;
-    const i64 V0 = g[0].v;
-
-    asr_shard_state* st = nullptr;
-    ASR_TRY(asr_shard_ownership(ctx, comm, 0, &st));
-    struct Guard {
-        asr_shard_state*& st;
-        bool keep = false;
-        ~Guard() {
-            if (!keep && st) asr_shard_free(st);
-        }
-    } guard{st};
-    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {  // 55-slot lists of the owned rows (rows of other ranks: empty)
-        i64 nrows = 0;
-        const int32_t* rows = asr_shard_level_rows(st, i, &nrows);
-        ctx->scratch.reset();
-        g[i].nrs = arena_alloc<i64>(ctx->persist, g[i].v + 1);
-        if (!g[i].nrs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_TRY(asr_geom_neighbors_rows_count(ctx, g[i].keys, g[i].v, rows, nrows, g[i].nrs, &g[i].p));
-        g[i].nidx = arena_alloc<int32_t>(ctx->persist, g[i].p);
-        g[i].nkidx = arena_alloc<uint8_t>(ctx->persist, g[i].p);
-        if (!g[i].nidx || !g[i].nkidx) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ctx->scratch.reset();
-        ASR_TRY(asr_geom_neighbors_rows_fill(ctx, g[i].keys, g[i].v, rows, nrows, g[i].nrs, g[i].nidx, g[i].nkidx));
+    if (st_out) {
+        *st_out = st;
+        shard_guard.keep = true;
     }
-    ASR_TRY(build_grid_names(ctx));
-    ASR_TRY(build_tilings_and_plans(ctx, ctx, 0));  // tiling orders; the plans are per rank (asr_shard_lists)
-    ASR_TRY(asr_shard_lists(ctx, st, prm->precision != 0 && ctx->opt.sconv_plan));
-    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-
-    // ---- aggregation search over [0, prefix) + the owned rows (cpp/lib/asr.cpp:266-273).  SURVEY B.2: encblock0 reads the
-    // importance of the first V0 PAIRS of the whole cloud's CSR; those belong to the first few percent of the voxels in
-    // index order, which every rank therefore searches itself (no communication).
-    asr_hip_print("aggregate\n", ASR_HIP_INFO);  // cpp/lib/asr.cpp:264
-    ArenaMark before;
-    arena_mark(ctx->persist, before);
-    i64 prefix = std::min<i64>(V0, std::max<i64>(1024, V0 / 8));
-    i64 agg_pairs = 0, nq = 0;
-    for (;;) {
-        arena_rewind(ctx->persist, before);
-        ctx->scratch.reset();
-        ctx->pindex.valid = false;
-        int32_t* qrows = nullptr;
-        ASR_TRY(asr_shard_query_rows(ctx, st, prefix, ctx->persist, &qrows, &nq));
-        float* qc = arena_alloc<float>(ctx->persist, 3 * nq);
-        float* qs = arena_alloc<float>(ctx->persist, nq);
-        u64* qk = arena_alloc<u64>(ctx->persist, nq);
-        ctx->agg_rs = arena_alloc<i64>(ctx->persist, nq + 1);
-        if (!qc || !qs || !qk || !ctx->agg_rs) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        k_gather_queries<<<grid_for(nq, 256), 256, 0, ctx->stream>>>(qrows, nq, g[0].centers, g[0].sizes, g[0].keys, qc, qs, qk);
-        ASR_CHECK_LAUNCH(ctx);
-        ctx->scratch.reset();
-        ASR_TRY(asr_geom_radius_count(ctx, &ctx->frame, points, n, qc, qs, nq, ctx->agg_rs, &agg_pairs, &ctx->persist, radii,
-                                      qk, ctx->leaf_lmin, ctx->leaf_lmax, nullptr));
-        i64 prefix_pairs = 0;
-        ASR_HIP_CHECK(ctx, hipMemcpyAsync(&prefix_pairs, ctx->agg_rs + prefix, sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
-        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (prefix_pairs < V0 && prefix < V0) {
-            prefix = std::min<i64>(V0, 2 * prefix);
-            continue;
-        }
-        // (prefix == V0 and still fewer pairs than voxels: implicit_network reports the reference's out-of-range indexing)
-        ctx->agg_rows = qrows;
-        ctx->agg_nq = nq;
-        ctx->agg_qcenters = qc;
-        ctx->agg_qsizes = qs;
-        break;
-    }
-    ctx->agg_idx = arena_alloc<int32_t>(ctx->persist, agg_pairs);
-    ctx->agg_dist = arena_alloc<float>(ctx->persist, agg_pairs);
-    ctx->agg_compat = arena_alloc<float>(ctx->persist, agg_pairs);
-    ctx->agg_spos = arena_alloc<int32_t>(ctx->persist, agg_pairs);
-    if (!ctx->agg_idx || !ctx->agg_dist || !ctx->agg_compat || !ctx->agg_spos)
-        ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_TRY(asr_geom_radius_fill(ctx, points, radii, n, ctx->agg_qcenters, ctx->agg_qsizes, nq, ctx->agg_rs, ctx->agg_idx,
-                                 ctx->agg_dist, ctx->agg_compat, ctx->agg_spos, &ctx->agg_sorted));
-    ctx->has_search = true;
-    ctx->sizes.num_agg_pairs = agg_pairs;  // of THIS rank's query list
-    name_it(ctx, "aggregation_neighbors_index", ctx->agg_idx, 4 * agg_pairs);
-    name_it(ctx, "aggregation_neighbors_dist", ctx->agg_dist, 4 * agg_pairs);
-    name_it(ctx, "aggregation_scale_compat", ctx->agg_compat, 4 * agg_pairs);
-    name_it(ctx, "aggregation_row_splits", ctx->agg_rs, 8 * (nq + 1));
-    name_it(ctx, "aggregation_rows", const_cast<int32_t*>(ctx->agg_rows), 4 * nq);
-    ASR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    arena_mark(ctx->persist, ctx->build_mark);
-    ctx->build_mark_ok = true;
-    guard.keep = true;
-    *st_out = st;
     return ASR_HIP_OK;
 }
 
@@ -1623,11 +1587,11 @@ int asr_hip_implicit_forward_sharded(asr_hip_context* ctx, const asr_shard_comm*
                                       "ASR_CONV16_BF16X3 or ASR_CONV16_F16X2)");
     if (!ctx->opt.build_search) ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_forward_sharded needs option build_search");
     // option shard_geometry: 0 = the whole cloud's geometry on every rank (overlapped search, as on one GPU), 1 = lists,
-    // plans and search for the owned voxels only, -1 (default) = 1 from four ranks on
-    const bool own_geometry = comm->world > 1 && (ctx->opt.shard_geometry > 0 || (ctx->opt.shard_geometry < 0 && comm->world >= 4));
+    // plans and search for the owned voxels only, -1 (default) = 1 whenever there is more than one rank
+    const bool own_geometry = comm->world > 1 && (ctx->opt.shard_geometry > 0 || (ctx->opt.shard_geometry < 0 && comm->world >= 2));
     asr_shard_state* st = nullptr;
     if (own_geometry) {
-        ASR_TRY(implicit_build_sharded(ctx, comm, points, radii, n, prm, &st));
+        ASR_TRY(implicit_build(ctx, points, radii, n, prm, comm, &st));
     } else {
         ASR_TRY(implicit_build(ctx, points, radii, n, prm));
         ASR_TRY(asr_shard_build(ctx, comm, prm->precision != 0 && ctx->opt.sconv_plan, &st));

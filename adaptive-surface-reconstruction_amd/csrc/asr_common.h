@@ -109,7 +109,7 @@ struct AsrOptions {
     i64 overlap = 1;              // aggregation search on the auxiliary stream, overlapped with the grids
     i64 cconv_valu = 0;           // 1: whole-path continuous conv with the VALU contraction (k_cconv) instead of k_cconv_mfma
     i64 build_search = 1;         // 0: implicit_build stops after the grids (sharded runs search their own rows)
-    i64 shard_geometry = -1;      // sharded forward: 1 = lists / plans / search for the owned voxels only, 0 = whole cloud on every rank, -1 = 1 from 4 ranks on
+    i64 shard_geometry = -1;      // sharded forward: 1 = lists / plans / search for the owned voxels only, 0 = whole cloud on every rank, -1 = 1 whenever world > 1
     i64 shard_timing = 0;         // sharded forward: synchronise around every halo exchange and accumulate its wall time
     i64 search_priority = 2;      // priority of the search's stream (set before the first build): 0 lowest, 1 middle, 2 highest
                                   // (round 4: the search is the longer of the two chains; 9.6 -> 8.8 ms on its stream)
@@ -332,11 +332,14 @@ struct asr_shard_state;
 int asr_shard_build(asr_hip_context* ctx, const asr_shard_comm* comm, int want_plans, asr_shard_state** out);
 // the same in two steps for a rank that builds the 55-slot lists of its own rows only (by_pairs 0: equal voxel counts)
 int asr_shard_ownership(asr_hip_context* ctx, const asr_shard_comm* comm, int by_pairs, asr_shard_state** out);
+int asr_shard_ownership_coarser(asr_hip_context* ctx, asr_shard_state* st);
+const int32_t* asr_shard_owner(const asr_shard_state* st, int level);
 int asr_shard_lists(asr_hip_context* ctx, asr_shard_state* st, int want_plans);
 const int32_t* asr_shard_level_rows(const asr_shard_state* st, int level, i64* n);
 int asr_shard_query_rows(asr_hip_context* ctx, const asr_shard_state* st, i64 prefix, Arena& keep, int32_t** rows_out,
                          i64* n_out);
 int asr_shard_world(const asr_shard_state* st);
+int asr_shard_rank(const asr_shard_state* st);
 void asr_shard_free(asr_shard_state* st);
 void asr_shard_release(asr_hip_context* ctx);  // the context's shard arena and staging buffers
 const asr_shard_stats* asr_shard_get_stats(const asr_shard_state* st);
@@ -373,6 +376,8 @@ struct asr_nb_job {
     int32_t* idx;
     uint8_t* kidx;
     i64 p;
+    const int32_t* owner = nullptr;  // optional: lists for the rows with owner[row] == me only (the others stay empty)
+    int me = 0;
 };
 int asr_geom_neighbors_build_batch(asr_hip_context* ctx, Arena& out_arena, asr_nb_job* jobs, int n);
 int asr_geom_row_groups(asr_hip_context* ctx, const uint8_t* kidx, const i64* rs, i64 v, i64 seg,

@@ -71,6 +71,24 @@ __device__ inline int tab_insert(const HashTab& t, u64 key, u64* slot_out = null
     }
     return -1;
 }
+// the same for key sets with FEW distinct values among many insertions (the slot masks of the neighbour lists: most rows
+// of a grid share the interior mask, the rows of other ranks of a sharded cloud the empty one): an agent-scope load of one
+// address by every wave of the launch serialises at that address's memory channel, so the probe reads through the caches
+// first.  A key never changes once written: a cached non-zero value is the truth, a cached zero is checked again.
+__device__ inline int tab_insert_shared(const HashTab& t, u64 key) {
+    TabProbe pr = tab_probe(t, key);
+    for (u64 probe = 0; probe <= pr.bmask; ++probe, pr.next()) {
+        const u64 slot = pr.slot();
+        u64 cur = t.keys[slot];
+        if (cur == 0) cur = ld_agent(&t.keys[slot]);
+        if (cur == 0) {
+            cur = atomicCAS((unsigned long long*)&t.keys[slot], 0ull, (unsigned long long)key);
+            if (cur == 0) return 1;
+        }
+        if (cur == key) return 0;
+    }
+    return -1;
+}
 // lookup after the building kernel finished (plain loads)
 __device__ inline bool tab_contains(const HashTab& t, u64 key) {
     TabProbe pr = tab_probe(t, key);
@@ -578,6 +596,8 @@ struct NbBatch {
     i64* rs[NB_MAX_JOBS];
     int32_t* idx[NB_MAX_JOBS];
     uint8_t* kidx[NB_MAX_JOBS];
+    const int32_t* owner[NB_MAX_JOBS];  // optional row filter (one rank of a sharded cloud builds its own rows)
+    int me[NB_MAX_JOBS];
 };
 __device__ inline int nb_job_of(const NbBatch& b, i64 e) {
     int j = 0;
@@ -603,6 +623,11 @@ __global__ void k_neighbors_count_batch(NbBatch b, i64* counts, u64* masks, int3
     const i64 i = e - b.base[j];
     if (i >= b.v[j]) {  // the job's terminator
         counts[e] = 0;
+        return;
+    }
+    if (b.owner[j] && b.owner[j][i] != b.me[j]) {
+        counts[e] = 0;
+        masks[e] = 0;
         return;
     }
     const HashTab t = b.tab[j];
@@ -646,6 +671,7 @@ __global__ void k_neighbors_fill_batch(NbBatch b, const i64* scan, const u64* ma
     b.rs[j][i] = o;  // (the terminator writes rs[v] = pairs of the job)
     if (i >= b.v[j]) return;
     const int n = (int)(scan[e + 1] - first - o);
+    if (n == 0) return;  // a row of another rank
     int32_t* nidx = b.idx[j];
     uint8_t* nkidx = b.kidx[j];
     nidx[o] = (int32_t)i;
@@ -1990,7 +2016,7 @@ __global__ void k_rg_masks(RowGroupBatch b, u64* masks, HashTab t, int* cnt) {
         const i64* rs = b.rs[j];
         const uint8_t* kidx = b.kidx[j];
         for (i64 p = rs[r]; p < rs[r + 1]; ++p) m |= u64(1) << (kidx[p] & 63);
-        if (tab_insert(t, (m >> 1) + 1) < 0) cnt[1] = 1;
+        if (tab_insert_shared(t, (m >> 1) + 1) < 0) cnt[1] = 1;
     }
     masks[e] = m;
 }
@@ -2472,6 +2498,8 @@ int asr_geom_neighbors_build_batch(asr_hip_context* ctx, Arena& out_arena, asr_n
         b.rs[j] = jobs[j].rs;
         b.idx[j] = nullptr;
         b.kidx[j] = nullptr;
+        b.owner[j] = jobs[j].owner;
+        b.me[j] = jobs[j].me;
     }
     b.base[n] = total;
     for (int grow = 0;; grow += 2) {  // key maps that overflowed (see TabProbe) are rebuilt four times the size

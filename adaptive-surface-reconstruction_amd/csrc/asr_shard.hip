@@ -97,11 +97,22 @@ __device__ __forceinline__ int shard_list_of(const i64* off, int n, i64 t) {  //
     while (j + 1 < n && t >= off[j + 1]) ++j;
     return j;
 }
-// per output row of every list: is the row at this position of the tiling order mine (rflags), and the halo flags of row r
-// F[in_off[j] + d * v_in + i] = rank d needs my input row i, G[.. s * v_in + i] = I need input row i of rank s.
+// per output row of every list: is the row at this position of the tiling order mine (rflags), and the halo entries of row
+// r: position in_off[j] + d * v_in + i in the SEND set = rank d needs my input row i, in_off[j] + s * v_in + i in the RECV
+// set = I need input row i of rank s.  The sets are bit sets (first setter of a bit appends the position to the list; a
+// rank's halo is a few percent of its rows, so the lists are short and sorted afterwards).
 // symmetric (55-slot lists that hold this rank's rows only): u is in the row of v exactly when v is in the row of u
 // (cpp/lib/grid.cpp:99-170), so rank s needs my row r exactly when r has a neighbour owned by s
-__global__ void k_shard_flags_batch(ShardBatch b, uint8_t* rflags, uint8_t* F, uint8_t* G) {
+__device__ __forceinline__ void shard_mark(unsigned* bits, i64 pos, int32_t* list, i64* n, i64 cap) {
+    const unsigned bit = 1u << (pos & 31);
+    unsigned* w = bits + (pos >> 5);
+    if (*w & bit) return;  // (bits are only ever set: a cached one is the truth)
+    if (atomicOr(w, bit) & bit) return;
+    const i64 o = (i64)atomicAdd((unsigned long long*)n, 1ull);
+    if (o < cap) list[o] = (int32_t)pos;
+}
+__global__ void k_shard_flags_batch(ShardBatch b, uint8_t* rflags, unsigned* F, unsigned* G, int32_t* send, int32_t* recv,
+                                    i64* n_send, i64* n_recv, i64 cap) {
     const i64 t = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (t >= b.out_off[b.n]) return;
     const int j = shard_list_of(b.out_off, b.n, t);
@@ -110,8 +121,7 @@ __global__ void k_shard_flags_batch(ShardBatch b, uint8_t* rflags, uint8_t* F, u
     rflags[t] = own[b.perm[j] ? b.perm[j][r] : (int32_t)r] == b.me ? 1 : 0;
     const int d = own[r];
     const i64 v_in = b.v_in[j];
-    uint8_t* Fj = F + b.in_off[j];
-    uint8_t* Gj = G + b.in_off[j];
+    const i64 base = b.in_off[j];
     const int32_t* idx = b.idx[j];
     const int32_t* oin = b.owner_in[j];
     const int sym = b.symmetric[j];
@@ -120,10 +130,10 @@ __global__ void k_shard_flags_batch(ShardBatch b, uint8_t* rflags, uint8_t* F, u
         const int s = oin[i];
         if (d == s) continue;
         if (d == b.me) {
-            Gj[(i64)s * v_in + i] = 1;
-            if (sym) Fj[(i64)s * v_in + r] = 1;
+            shard_mark(G, base + (i64)s * v_in + i, recv, n_recv, cap);
+            if (sym) shard_mark(F, base + (i64)s * v_in + r, send, n_send, cap);
         }
-        if (!sym && s == b.me) Fj[(i64)d * v_in + i] = 1;
+        if (!sym && s == b.me) shard_mark(F, base + (i64)d * v_in + i, send, n_send, cap);
     }
 }
 __device__ __forceinline__ i64 shard_lower_bound(const int32_t* a, i64 n, i64 key) {
@@ -261,6 +271,17 @@ static int shard_select(asr_hip_context* ctx, In in, const uint8_t* flags, int32
     return ASR_HIP_OK;
 }
 
+static int shard_sort_u32(asr_hip_context* ctx, const int32_t* in, int32_t* out, i64 n, int end_bit) {
+    size_t tb = 0;
+    const unsigned* kin = reinterpret_cast<const unsigned*>(in);
+    unsigned* kout = reinterpret_cast<unsigned*>(out);
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_keys(nullptr, tb, kin, kout, (size_t)n, 0, end_bit, ctx->stream));
+    void* tmp = ctx->scratch.alloc(tb ? tb : 256);
+    if (!tmp) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, rocprim::radix_sort_keys(tmp, tb, kin, kout, (size_t)n, 0, end_bit, ctx->stream));
+    return ASR_HIP_OK;
+}
+
 // halo of one neighbour list: rows of the INPUT buffer, concatenated per peer (ascending peer, ascending row)
 struct ShardCsr {
     const int32_t* perm = nullptr;  // owned output rows in the list's tiling order
@@ -377,7 +398,7 @@ int asr_shard_ownership(asr_hip_context* ctx, const asr_shard_comm* comm, int by
     ctx->scratch.reset();
     // ---- ownership ----
     const i64 V0 = g[0].v;
-    for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
+    for (int i = 0; i < (by_pairs ? ASR_NUM_GRIDS : 1); ++i) {
         st->owner[i] = arena_alloc<int32_t>((*st->mem), g[i].v);
         if (!st->owner[i]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     }
@@ -406,34 +427,43 @@ int asr_shard_ownership(asr_hip_context* ctx, const asr_shard_comm* comm, int by
         }
         ASR_CHECK_LAUNCH(ctx);
     }
-    for (int i = 0; i + 1 < ASR_NUM_GRIDS; ++i) {
-        k_shard_coarser<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(st->owner[i], g[i].up_idx, g[i].up_kidx, g[i].v,
-                                                                        st->owner[i + 1]);
-        ASR_CHECK_LAUNCH(ctx);
-    }
-    if (!by_pairs) {  // sharded geometry: the owned rows of every level, ascending
-        st->owned_lists = true;
-        i64* d_n = arena_alloc<i64>(ctx->scratch, ASR_NUM_GRIDS);
-        i64 vmax = 0;
-        for (int i = 0; i < ASR_NUM_GRIDS; ++i) vmax = std::max(vmax, g[i].v);
-        uint8_t* fl = arena_alloc<uint8_t>(ctx->scratch, vmax);
-        if (!d_n || !fl) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        for (int i = 0; i < ASR_NUM_GRIDS; ++i) {
-            st->level_rows[i] = arena_alloc<int32_t>((*st->mem), g[i].v);
-            if (!st->level_rows[i]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-            k_shard_flag_rows<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(nullptr, st->owner[i], me, g[i].v, fl);
+    if (by_pairs) {
+        for (int i = 0; i + 1 < ASR_NUM_GRIDS; ++i) {
+            k_shard_coarser<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(st->owner[i], g[i].up_idx, g[i].up_kidx, g[i].v,
+                                                                            st->owner[i + 1]);
             ASR_CHECK_LAUNCH(ctx);
-            ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), fl, st->level_rows[i], d_n + i, (size_t)g[i].v));
         }
-        i64 h_n[ASR_NUM_GRIDS];
-        ASR_HIP_CHECK(ctx, hipMemcpyAsync(h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, ctx->stream));
-        ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < ASR_NUM_GRIDS; ++i) st->level_nrows[i] = h_n[i];
+    } else {  // the owned rows of grid 0, ascending: what the aggregation search of this rank covers
+        st->owned_lists = true;
+        // position i of the Morton order belongs to rank floor(i * world / V0): the count needs no read-back
+        auto first_of = [&](i64 r) { return (r * V0 + world - 1) / world; };
+        st->level_nrows[0] = first_of(me + 1) - first_of(me);
+        i64* d_n = arena_alloc<i64>(ctx->scratch, 1);
+        uint8_t* fl = arena_alloc<uint8_t>(ctx->scratch, V0);
+        st->level_rows[0] = arena_alloc<int32_t>((*st->mem), V0);
+        if (!d_n || !fl || !st->level_rows[0]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_shard_flag_rows<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(nullptr, st->owner[0], me, V0, fl);
+        ASR_CHECK_LAUNCH(ctx);
+        ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), fl, st->level_rows[0], d_n, (size_t)V0));
     }
     guarded = nullptr;
     *out = st;
     return ASR_HIP_OK;
 }
+// owners of the coarser grids (a merged voxel belongs to the owner of its first child), once those grids exist
+int asr_shard_ownership_coarser(asr_hip_context* ctx, asr_shard_state* st) {
+    if (st->world == 1 || st->owner[1]) return ASR_HIP_OK;
+    GridDev* g = ctx->grids;
+    for (int i = 0; i + 1 < ASR_NUM_GRIDS; ++i) {
+        st->owner[i + 1] = arena_alloc<int32_t>((*st->mem), g[i + 1].v);
+        if (!st->owner[i + 1]) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_shard_coarser<<<grid_for(g[i].v, BLK), BLK, 0, ctx->stream>>>(st->owner[i], g[i].up_idx, g[i].up_kidx, g[i].v,
+                                                                        st->owner[i + 1]);
+        ASR_CHECK_LAUNCH(ctx);
+    }
+    return ASR_HIP_OK;
+}
+const int32_t* asr_shard_owner(const asr_shard_state* st, int level) { return st->owner[level]; }
 
 // the rest of the shard state once the neighbour lists and their tiling orders exist: owned rows in tiling order, plans,
 // halo lists, stitch lists
@@ -491,20 +521,30 @@ int asr_shard_lists(asr_hip_context* ctx, asr_shard_state* st, int want_plans) {
     const i64 n_out = B.out_off[nl], n_in = B.in_off[nl];
     if (n_in >= (i64(1) << 31) || n_out >= (i64(1) << 31))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sharded forward: world x voxels exceeds 2^31");
-    uint8_t* F = arena_alloc<uint8_t>(ctx->scratch, (size_t)n_in);
-    uint8_t* G = arena_alloc<uint8_t>(ctx->scratch, (size_t)n_in);
+    const size_t words = ((size_t)n_in + 31) / 32;
+    unsigned* F = arena_alloc<unsigned>(ctx->scratch, words);
+    unsigned* G = arena_alloc<unsigned>(ctx->scratch, words);
     uint8_t* rflags = arena_alloc<uint8_t>(ctx->scratch, (size_t)n_out);
     int32_t* sel_perm = arena_alloc<int32_t>((*st->mem), (size_t)n_out);
-    int32_t* sel_send = arena_alloc<int32_t>(ctx->scratch, cap);
-    int32_t* sel_recv = arena_alloc<int32_t>(ctx->scratch, cap);
-    if (!F || !G || !rflags || !sel_perm || !sel_send || !sel_recv) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(F, 0, (size_t)n_in, ctx->stream));
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(G, 0, (size_t)n_in, ctx->stream));
-    k_shard_flags_batch<<<grid_for(n_out, BLK), BLK, 0, ctx->stream>>>(B, rflags, F, G);
+    int32_t* raw_send = arena_alloc<int32_t>(ctx->scratch, cap);
+    int32_t* raw_recv = arena_alloc<int32_t>(ctx->scratch, cap);
+    if (!F || !G || !rflags || !sel_perm || !raw_send || !raw_recv) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(F, 0, words * 4, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(G, 0, words * 4, ctx->stream));
+    k_shard_flags_batch<<<grid_for(n_out, BLK), BLK, 0, ctx->stream>>>(B, rflags, F, G, raw_send, raw_recv, d_tot + 1, d_tot + 2, (i64)cap);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), rflags, sel_perm, d_tot + 0, (size_t)n_out));
-    ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), F, sel_send, d_tot + 1, (size_t)n_in));
-    ASR_TRY(shard_select(ctx, rocprim::counting_iterator<int32_t>(0), G, sel_recv, d_tot + 2, (size_t)n_in));
+    i64 h_tot[3];
+    ASR_HIP_CHECK(ctx, hipMemcpyAsync(h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
+    ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const i64 tot_send = h_tot[1], tot_recv = h_tot[2];
+    if (tot_send > (i64)cap || tot_recv > (i64)cap) ASR_FAIL(ctx, ASR_HIP_ELOGIC, "sharded forward: halo list overflow");
+    // the lists in ascending (list, peer, row) order, straight into the state's arena
+    int32_t* sel_send = arena_alloc<int32_t>((*st->mem), (size_t)std::max<i64>(tot_send, 1));
+    int32_t* sel_recv = arena_alloc<int32_t>((*st->mem), (size_t)std::max<i64>(tot_recv, 1));
+    if (!sel_send || !sel_recv) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    if (tot_send > 0) ASR_TRY(shard_sort_u32(ctx, raw_send, sel_send, tot_send, bits_for(n_in)));
+    if (tot_recv > 0) ASR_TRY(shard_sort_u32(ctx, raw_recv, sel_recv, tot_recv, bits_for(n_in)));
     k_shard_bounds_batch<<<grid_for((i64)nl * (1 + 2 * (world + 1)), 128), 128, 0, ctx->stream>>>(
             B, sel_perm, d_tot + 0, sel_send, d_tot + 1, sel_recv, d_tot + 2, d_cnt, per);
     ASR_CHECK_LAUNCH(ctx);
@@ -528,15 +568,9 @@ int asr_shard_lists(asr_hip_context* ctx, asr_shard_state* st, int want_plans) {
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(h_cnt.data(), d_cnt, h_cnt.size() * sizeof(i64), hipMemcpyDeviceToHost, ctx->stream));
     ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int p = 0; p <= world; ++p) st->rows0_off[p] = h_cnt[(size_t)nl * per + p];
-    // exact-size halo lists, plans of the owned rows
-    const i64 tot_send = h_cnt[(size_t)nl * per + world + 1 + 1], tot_recv = h_cnt[(size_t)nl * per + world + 1 + 2];
-    int32_t* send_all = arena_alloc<int32_t>((*st->mem), (size_t)std::max<i64>(tot_send, 1));
-    int32_t* recv_all = arena_alloc<int32_t>((*st->mem), (size_t)std::max<i64>(tot_recv, 1));
-    if (!send_all || !recv_all) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    if (tot_send > 0)
-        ASR_HIP_CHECK(ctx, hipMemcpyAsync(send_all, sel_send, tot_send * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    if (tot_recv > 0)
-        ASR_HIP_CHECK(ctx, hipMemcpyAsync(recv_all, sel_recv, tot_recv * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    // plans of the owned rows
+    int32_t* send_all = sel_send;
+    int32_t* recv_all = sel_recv;
     std::vector<asr_conv_plan> plans;
     std::vector<int> plan_of;
     for (int j = 0; j < nl; ++j) {

@@ -7,6 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 out=/tmp/shardtrace_$tag; rm -rf $out
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python $root/scripts/shard_dry_run.py $n $world $rank $geom > $root/gpurun_out/${tag}_shard.log 2>&1
 t=$(find $out -name "*kernel_trace.csv" | head -1)
-python3 $root/scripts/geom_timeline.py $t k_point_codes > $root/gpurun_out/${tag}_shard_timeline.txt
+python3 $root/scripts/geom_timeline.py $t ${MARKER:-k_point_codes} > $root/gpurun_out/${tag}_shard_timeline.txt
 tail -3 $root/gpurun_out/${tag}_shard.log
 tail -1 $root/gpurun_out/${tag}_shard_timeline.txt

@@ -55,6 +55,8 @@ const OptEntry k_options[] = {
         {"shard_geometry", "ASR_SHARD_GEOMETRY", &AsrOptions::shard_geometry},
         {"early_sort", "ASR_EARLY_SORT", &AsrOptions::early_sort},
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
+        {"sconv_split_rows", "ASR_SCONV_SPLIT_ROWS", &AsrOptions::sconv_split_rows},
+        {"sconv_split_min_rows", "ASR_SCONV_SPLIT_MIN_ROWS", &AsrOptions::sconv_split_min_rows},
 };
 
 // asr::GetPrintCallbackFunction (cpp/lib/asr.cpp:34-37): one callback per verbosity level, process wide
@@ -168,6 +170,7 @@ static void release_members(asr_hip_context* ctx) {
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_absmax) (void)hipFree(ctx->d_absmax);
+    if (ctx->split_part) (void)hipFree(ctx->split_part);
     if (ctx->ev_ok)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
 }

@@ -116,6 +116,12 @@ struct AsrOptions {
     i64 search_half = 1;          // aggregation search: 4^3 half-size cells per voxel (0: 3^3 full-size cells)
     i64 early_cells = 1;            // ... and its cell table, on the search thread
     i64 early_sort = 1;           // overlapped search: its point sort starts on the auxiliary stream beside the octree build
+    // 16-bit sparse conv, 55-slot lists whose INPUT grid has between these many rows (the coarse levels: a handful of
+    // tiles, the longest of which runs its 30 slots x cin / 32 steps alone on its CU): the slots are cut into five fixed
+    // ranges, every (tile, range) is a block of its own, a second kernel adds the partial sums in range order.  The
+    // choice depends on the input grid's size only, so that one rank of a sharded cloud makes the same one.
+    i64 sconv_split_min_rows = 2048;
+    i64 sconv_split_rows = 32768;  // 0: never
 };
 
 // Row-group plan of a neighbour list for the plan-driven 16-bit sparse conv (asr_conv16.hip): per 16
@@ -209,6 +215,8 @@ struct asr_hip_context {
     bool ev_ok = false;
     int* d_flags = nullptr;  // small device scratch for counters (persistent)
     float* d_zeros = nullptr;  // 4 KB of zeros: target of masked-out loads
+    float* split_part = nullptr;   // partial sums of the slot-range split of the 16-bit sparse conv (grown on demand)
+    size_t split_part_bytes = 0;
     unsigned* d_absmax = nullptr;  // f16x2: running maxima of the network's activation buffers; [255]: one-off inputs
     void* radius_state = nullptr;  // RadiusState of asr_geom.hip (between _count and _fill)
     void* mesh_state = nullptr;    // MeshState of asr_mesh.hip (between _count and _fill)

@@ -269,19 +269,27 @@ __global__ __launch_bounds__(1024, 8) void k_cconv(const float* __restrict__ fil
 }
 
 // ------------------------------------------------------------------------------------------
-// a10 with the contraction on the matrix cores (whole-path layout: Morton-ordered 32-byte records, cin = 4,
-// cout <= 32).  A wave owns GROUPS of 16 consecutive voxels: it accumulates B[cell][4] of each voxel as above
-// (lane = filter cell), parks the 16 x 256 matrix in LDS, and contracts it with the 256 x cout filter matrix in
-// 128 v_mfma_f32_16x16x4_f32 (exact f32): out[16 voxels][cout] -- instead of 64 ds_read_b128 + 64 v_pk_fma per
-// voxel on the VALU / LDS pipes.  The filter fragments (128 floats per lane) stay in registers for the whole
-// (persistent) kernel.  k order: MFMA step (j, t) of k-lane g contracts k = 16 j + 4 g + t on both operands, so the
-// A fragment of four steps is one ds_read_b128; the LDS rows are 264 floats apart (conflict-free for that read).
-// With only two waves per SIMD the row_splits -> index -> record load chain of a voxel is software pipelined
-// over the 16 voxels of a group: indices of voxel u+2 and records of voxel u+1 are in flight while voxel u is
-// accumulated.
+// a10 with pair loop and contraction on the matrix cores (whole-path layout: Morton-ordered 32-byte records, cin = 4,
+// cout <= 32).
+//   * A wave owns SUPER-GROUPS of 64 consecutive voxels (lane u holds the row bounds / centre / extent of voxel u) and
+//     streams their pairs in CHUNKS of at most 64 pairs: a chunk is a run of whole voxels (the mean row has 18 pairs, so
+//     3-4 voxels share one batch of 64 lanes: one index load, one record load, one coordinate transform and one LDS
+//     store per chunk instead of per voxel); a row of more than 64 pairs gets chunks of its own, cut at multiples of 64
+//     from the row start.  The index loads of chunk c+2 and the record loads of chunk c+1 are in flight while chunk c
+//     is accumulated (the row_splits -> index -> record chain is the latency that bounds a wave; with the group matrix
+//     below only two waves per SIMD fit, so the depth has to come from the pipeline).
+//   * Per voxel the 64 cells x 4 features are ONE 16 x 16 accumulator tile D[i = cy + 4 cz][j = c + 4 cx], four pairs
+//     per v_mfma_f32_16x16x4_f32, quads counted from the ROW start (a lane whose pair lies beyond the row end feeds a
+//     zero B operand): a row's result does not depend on which rows share its chunk.
+//   * Every 16 voxels the 16 x 256 matrix parked in LDS is contracted with the 256 x cout filter matrix in 128
+//     v_mfma_f32_16x16x4_f32 (exact f32; the filter fragments, 128 floats per lane, stay in registers for the whole
+//     persistent kernel).  k order: MFMA step (j, t) of k-lane g contracts k = 16 j + 4 g + t on both operands, so the
+//     A fragment of four steps is one ds_read_b128; the LDS rows are 264 floats apart (conflict-free for that read).
 // ------------------------------------------------------------------------------------------
-constexpr int CCG = 16;        // voxels per group
+constexpr int CCG = 16;        // voxels per contraction group
 constexpr int CCG_LD = 264;    // floats per LDS row of the group matrix
+constexpr int CCS = 64;        // voxels per super-group (one per lane)
+constexpr int CC_PAIR_LD = 160;  // float4 per wave: 64 pairs x 2 + 16 zero pairs (quads are read four at a time, up to 15 beyond a batch)
 // SORTED: neighbours are positions into the 32-byte records `rec`; else `rec` is unused and positions / features
 // come from the AoS arrays inp_pos [N,3] / inp_feat [N,4] at original indices (the generic operator boundary):
 // same arithmetic, so both layouts give identical bits.
@@ -295,15 +303,14 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
     // basis_out != null ("next" row f4, filter gradient): only the per-voxel matrices B[v][256] and the importance sums
     // are written; the contraction happens in the caller (dW = B^T g)
     __shared__ __attribute__((aligned(16))) float s_bt[8][CCG][CCG_LD];
-    __shared__ __attribute__((aligned(16))) float4 s_pair[8][128];
+    __shared__ __attribute__((aligned(16))) float4 s_pair[8][CC_PAIR_LD];
     __shared__ float s_norm[8][CCG];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 15, g = lane >> 4;
-    // pair loop on the matrix cores: the 64 x 4 cell sums of a voxel are ONE 16 x 16 accumulator tile,
-    // D[i = cy + 4 cz][j = c + 4 cx] = sum over pairs of (hy hz)[i] * (hx w f_c)[j], i.e. k = 16 i + j of the group matrix;
-    // a v_mfma_f32_16x16x4_f32 takes four pairs: lane (i = n, pair g) supplies A = hy(cy) hz(cz), lane (j = n, pair g)
-    // B = hx(cx) f_c -- three hat functions and two products per lane for four pairs, where the VALU loop spent 15
-    // instructions per pair.
+    // pair loop on the matrix cores: D[i = cy + 4 cz][j = c + 4 cx] = sum over pairs of (hy hz)[i] * (hx w f_c)[j], i.e.
+    // k = 16 i + j of the group matrix; lane (i = n, pair g) supplies A = hy(cy) hz(cz), lane (j = n, pair g)
+    // B = hx(cx) f_c -- three hat functions and two products per lane for four pairs.
     const float a_cy = (float)(n & 3), a_cz = (float)(n >> 2);  // A operand: row i = n
     const float b_cx = (float)(n >> 2);                         // B operand: column j = n -> cx = j / 4, channel j % 4
     const int b_c = n & 3;
@@ -321,34 +328,95 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
     float bias_o[2];
 #pragma unroll
     for (int T = 0; T < 2; ++T) bias_o[T] = (bias && 16 * T + n < cout) ? bias[16 * T + n] : 0.f;
+    if (lane < CC_PAIR_LD - 128) s_pair[wib][128 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // never written again
 
-    const i64 groups = (num_out + CCG - 1) / CCG;
-    const i64 wave0 = (blockIdx.x * (i64)blockDim.x + threadIdx.x) >> 6;
-    const i64 nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
-    for (i64 grp = wave0; grp < groups; grp += nwaves) {
-        const i64 q0 = grp * CCG;
-        // row bounds / centre / extent of the group's voxels: lane u holds voxel u
-        int mb = 0, mcnt = 0;  // first pair (relative to the group's first pair) and pair count
+    float4* const sp4 = &s_pair[wib][0];
+    const float* const sp = reinterpret_cast<const float*>(sp4);
+    const i64 sgroups = (num_out + CCS - 1) / CCS;
+    const i64 wave0 = (i64)blockIdx.x * (blockDim.x >> 6) + wib;
+    const i64 nwaves = (i64)gridDim.x * (blockDim.x >> 6);
+    for (i64 sg = wave0; sg < sgroups; sg += nwaves) {
+        const i64 q0 = sg * CCS;
+        const int nvox = (int)(num_out - q0 < CCS ? num_out - q0 : CCS);
+        // lane u: voxel u of the super-group.  mcnt = pairs this kernel accumulates (0 for a row of k_cconv_heavy)
+        int mb = 0, mcnt = 0, mall = 0;
         float mox = 0.f, moy = 0.f, moz = 0.f, msc = 0.f;
         const i64 pbase = rs[q0];
-        if (lane < CCG && q0 + lane < num_out) {
+        if (lane < nvox) {
             const i64 b = rs[q0 + lane], e = rs[q0 + lane + 1];
             mb = (int)(b - pbase);
-            mcnt = (int)(e - b);
+            mall = (int)(e - b < 0x7fffffff ? e - b : 0x7fffffff);
+            mcnt = (e - b) > heavy_rows ? 0 : mall;
             mox = out_pos[3 * (q0 + lane)];
             moy = out_pos[3 * (q0 + lane) + 1];
             moz = out_pos[3 * (q0 + lane) + 2];
             msc = 2.f * (1.f / extents[q0 + lane]);
         }
-        // pipeline stages: first batch (<= 64 pairs) of a voxel
-        auto load1 = [&](int u, int& idx, float& w) __attribute__((always_inline)) {
-            const int b = __builtin_amdgcn_readlane(mb, u), cnt = __builtin_amdgcn_readlane(mcnt, u);
-            const bool on = lane < cnt && cnt <= heavy_rows;
-            const i64 p = pbase + b + lane;
-            idx = on ? nidx[p] : 0;
-            w = on ? (nimp ? nimp[p] : 1.f) : 0.f;
+        // ---- chunk sequence (scalar state): next pair to hand out is pair `cso` of voxel `cu` ----
+        int cu = 0, cso = 0;
+        struct Chunk {
+            int u0, so, u1, total;  // voxels [u0, u1), `so` pairs of u0 consumed by earlier chunks, pairs in the chunk (-1: none)
         };
-        auto load2 = [&](int idx, float4& P, float4& F) __attribute__((always_inline)) {
+        auto next_chunk = [&]() __attribute__((always_inline)) -> Chunk {
+            Chunk c = {0, 0, 0, -1};
+            if (cu >= nvox) return c;
+            c.u0 = cu;
+            c.so = cso;
+            const int left = __builtin_amdgcn_readlane(mcnt, cu) - cso;
+            if (left > 64) {  // the row goes on in the next chunk
+                c.u1 = cu + 1;
+                c.total = 64;
+                cso += 64;
+                return c;
+            }
+            // whole rows while their quads fit: every row starts on a quad boundary of the LDS batch (zero filled
+            // up to it), so that the quad loop needs no end-of-row test
+            int total = left, padded = (left + 3) & ~3;
+            ++cu;
+            cso = 0;
+            while (cu < nvox) {
+                const int c2 = __builtin_amdgcn_readlane(mcnt, cu);
+                if (padded + c2 > 64) break;
+                total += c2;
+                padded = (padded + c2 + 3) & ~3;
+                ++cu;
+            }
+            c.u1 = cu;
+            c.total = total;
+            return c;
+        };
+        // stage A: which voxel a lane's pair belongs to, its index and importance
+        // (lpos: where the pair goes in the LDS batch = the lane moved up by the zero fill in front of its row)
+        auto stage_a = [&](const Chunk& c, int& vox, int& lpos, int& idx, float& w) __attribute__((always_inline)) {
+            vox = c.u0;
+            lpos = lane;
+            idx = 0;
+            w = 0.f;
+            if (c.total < 0) return;
+            int vb = __builtin_amdgcn_readlane(mb, c.u0) + c.so, voff = 0, fill = 0;
+            int off = __builtin_amdgcn_readlane(mcnt, c.u0) - c.so;
+            off = off > 64 ? 64 : off;
+            int poff = (off + 3) & ~3;
+            for (int u = c.u0 + 1; u < c.u1; ++u) {
+                const int cn = __builtin_amdgcn_readlane(mcnt, u), bu = __builtin_amdgcn_readlane(mb, u);
+                if (lane >= off) {
+                    vox = u;
+                    vb = bu;
+                    voff = off;
+                    fill = poff - off;
+                }
+                off += cn;
+                poff = (poff + cn + 3) & ~3;
+            }
+            lpos = lane + fill;
+            if (lane < c.total) {
+                const i64 p = pbase + vb + (lane - voff);
+                idx = nidx[p];
+                w = nimp ? nimp[p] : 1.f;
+            }
+        };
+        // stage B: position + features of the pair
+        auto stage_b = [&](int idx, float4& P, float4& F) __attribute__((always_inline)) {
             if (SORTED) {
                 P = rec[2 * (i64)idx];
                 F = rec[2 * (i64)idx + 1];
@@ -358,105 +426,138 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
                                 inp_feat[4 * (i64)idx + 3]);
             }
         };
-        int i1 = 0;
-        float w1 = 0.f;
-        float4 P2, F2;
-        float w2;
-        load1(0, i1, w1);
-        load2(i1, P2, F2);
-        w2 = w1;
-        load1(1, i1, w1);
-#pragma unroll 1
-        for (int u = 0; u < CCG; ++u) {
-            const float4 Pc = P2, Fc = F2;
-            const float wc = w2;
-            if (u + 1 < CCG) {  // records of voxel u+1, indices of voxel u+2: in flight during this voxel
-                load2(i1, P2, F2);
-                w2 = w1;
-            }
-            if (u + 2 < CCG) load1(u + 2, i1, w1);
-            const int cnt_all = __builtin_amdgcn_readlane(mcnt, u);
-            const bool heavy = cnt_all > heavy_rows;
-            const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mox), u));
-            const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(moy), u));
-            const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(moz), u));
-            const float sc2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(msc), u));
-            f32x4 D = {0.f, 0.f, 0.f, 0.f};
-            float norm_lane = 0.f;
-            if (!heavy && cnt_all > 0) {
-                const int b = __builtin_amdgcn_readlane(mb, u);
-                for (int p0 = 0; p0 < cnt_all; p0 += 64) {
-                    const int cnt = cnt_all - p0 < 64 ? cnt_all - p0 : 64;
-                    float4 P = Pc, F = Fc;
-                    float w = wc;
-                    if (p0 > 0) {  // rows of more than 64 pairs: further batches are loaded on the spot
-                        const bool on = lane < cnt;
-                        const i64 p = pbase + b + p0 + lane;
-                        const int idx = on ? nidx[p] : 0;
-                        w = on ? (nimp ? nimp[p] : 1.f) : 0.f;
-                        load2(idx, P, F);
-                    }
-                    float ux, uy, uz;
-                    cconv_pair_coords((P.x - ox) * sc2, (P.y - oy) * sc2, (P.z - oz) * sc2, ux, uy, uz);
-                    norm_lane += w;
-                    __builtin_amdgcn_wave_barrier();
-                    // lanes beyond cnt park zero features: their products vanish
-                    s_pair[wib][2 * lane] = make_float4(ux, uy, uz, 0.f);
-                    s_pair[wib][2 * lane + 1] = make_float4(w * F.x, w * F.y, w * F.z, w * F.w);
-                    __builtin_amdgcn_wave_barrier();
-                    const float* sp = reinterpret_cast<const float*>(&s_pair[wib][0]);
-                    for (int j = 0; j < cnt; j += 4) {
-                        const float4 a = s_pair[wib][2 * (j + g)];
-                        const float fc = sp[8 * (j + g) + 4 + b_c];
-                        const float wx = fminf(fmaxf(1.f - fabsf(a.x - b_cx), 0.f), 1.f);
-                        const float wy = fminf(fmaxf(1.f - fabsf(a.y - a_cy), 0.f), 1.f);
-                        const float wz = fminf(fmaxf(1.f - fabsf(a.z - a_cz), 0.f), 1.f);
-                        D = __builtin_amdgcn_mfma_f32_16x16x4f32(wy * wz, wx * fc, D, 0, 0, 0);
-                    }
+        f32x4 D = {0.f, 0.f, 0.f, 0.f};  // the voxel being accumulated (carried over chunks for rows of more than 64 pairs)
+        float nl = 0.f;                  // its importance, summed per lane over the row's batches
+        // contraction of the 16 voxels q0 + 16 k .. parked in s_bt
+        auto contract = [&](int k) __attribute__((always_inline)) {
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float4 a4 = *reinterpret_cast<const float4*>(&s_bt[wib][n][16 * j + 4 * g]);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wreg[0][j][t], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wreg[1][j][t], acc1, 0, 0, 0);
                 }
             }
-            // D[r] = cell sums k = 16 (4 g + r) + n
+            // acc[r] = out[voxel 4 g + r][o = 16 T + n]
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_bt[wib][u][16 * (4 * g + r) + n] = D[r];
-            const float norm = wave_sum_dpp(norm_lane);
-            if (lane == 0) s_norm[wib][u] = heavy ? -1.f : norm;  // -1: written by k_cconv_heavy
-            if (basis_out && q0 + u < num_out) {
+            for (int r = 0; r < 4; ++r) {
+                const int vx = 4 * g + r;
+                const i64 q = q0 + 16 * k + vx;
+                const float norm = s_norm[wib][vx];
+                if (q >= num_out || norm < 0.f) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) basis_out[(q0 + u) * 256 + 16 * (4 * g + r) + n] = D[r];
-                if (lane == 0) norm_out[q0 + u] = norm;
+                for (int T = 0; T < 2; ++T) {
+                    const int o = 16 * T + n;
+                    float v = T == 0 ? acc0[r] : acc1[r];
+                    if (normalize && norm != 0.f) v = v / norm;
+                    v += bias_o[T];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (o < cout) out[q * cout + o] = v;
+                }
             }
-        }
-        if (basis_out) continue;
-        __builtin_amdgcn_wave_barrier();
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 a4 = *reinterpret_cast<const float4*>(&s_bt[wib][n][16 * j + 4 * g]);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wreg[0][j][t], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], wreg[1][j][t], acc1, 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();  // the group matrix is re-used by the next group
+        };
+        // stage C: coordinates of the chunk's pairs into LDS, then voxel by voxel through the matrix cores
+        auto stage_c = [&](const Chunk& c, int vox, int lpos, float w, const float4& P, const float4& F) __attribute__((always_inline)) {
+            const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * vox, __float_as_int(mox)));
+            const float oy = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * vox, __float_as_int(moy)));
+            const float oz = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * vox, __float_as_int(moz)));
+            const float sc2 = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * vox, __float_as_int(msc)));
+            float ux, uy, uz;
+            cconv_pair_coords((P.x - ox) * sc2, (P.y - oy) * sc2, (P.z - oz) * sc2, ux, uy, uz);
+            __builtin_amdgcn_wave_barrier();
+            // zero fill first (LDS operations of a wave complete in order), then the pairs at their rows' positions
+            sp4[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            sp4[64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < c.total) {
+                sp4[2 * lpos] = make_float4(ux, uy, uz, w);
+                sp4[2 * lpos + 1] = make_float4(w * F.x, w * F.y, w * F.z, w * F.w);
             }
-        }
-        // acc[r] = out[voxel 4 g + r][o = 16 T + n]
+            __builtin_amdgcn_wave_barrier();
+            int off = 0;
+            for (int u = c.u0; u < c.u1; ++u) {
+                const int full = __builtin_amdgcn_readlane(mcnt, u);
+                const int so = u == c.u0 ? c.so : 0;
+                int cn = full - so;
+                cn = cn > 64 ? 64 : cn;
+                if (so == 0) {
+                    D = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    nl = 0.f;
+                }
+                if (cn > 0) {
+                    // sixteen pairs per round: the eight LDS reads of four quads are issued together (one exposed LDS
+                    // latency per round instead of one per quad; reads beyond the batch hit the zero pad)
+                    for (int j = 0; j < cn; j += 16) {
+                        float4 a[4];
+                        float fc[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int vx = 4 * g + r;
-            const i64 q = q0 + vx;
-            const float norm = s_norm[wib][vx];
-            if (q >= num_out || norm < 0.f) continue;
+                        for (int t = 0; t < 4; ++t) {
+                            a[t] = sp4[2 * (off + j + 4 * t + g)];
+                            fc[t] = sp[8 * (off + j + 4 * t + g) + 4 + b_c];
+                        }
+                        // (pins the eight reads here, before the wave-uniform branches below: the compiler would sink every
+                        // read into the branch that consumes it, which puts one LDS round trip in front of every MFMA)
 #pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                const int o = 16 * T + n;
-                float v = T == 0 ? acc0[r] : acc1[r];
-                if (normalize && norm != 0.f) v = v / norm;
-                v += bias_o[T];
-                if (relu) v = fmaxf(v, 0.f);
-                if (o < cout) out[q * cout + o] = v;
+                        for (int t = 0; t < 4; ++t)
+                            asm volatile("" : "+v"(a[t].x), "+v"(a[t].y), "+v"(a[t].z), "+v"(fc[t]));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            if (t > 0 && j + 4 * t >= cn) break;  // wave uniform (the last quad's tail is zero fill)
+                            const float wx = fminf(fmaxf(1.f - fabsf(a[t].x - b_cx), 0.f), 1.f);
+                            const float wy = fminf(fmaxf(1.f - fabsf(a[t].y - a_cy), 0.f), 1.f);
+                            const float wz = fminf(fmaxf(1.f - fabsf(a[t].z - a_cz), 0.f), 1.f);
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(wy * wz, wx * fc[t], D, 0, 0, 0);
+                        }
+                    }
+                    if (lane < cn) nl += sp[8 * (off + lane) + 3];
+                }
+                off += (cn + 3) & ~3;
+                if (so + cn < full) continue;  // the row goes on in the next chunk (it is the chunk's only voxel)
+                // D[r] = cell sums k = 16 (4 g + r) + n
+                const int vx = u & (CCG - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_bt[wib][vx][16 * (4 * g + r) + n] = D[r];
+                const float norm = wave_sum_dpp(nl);
+                const bool heavy = __builtin_amdgcn_readlane(mall, u) > full;  // written by k_cconv_heavy
+                if (lane == 0) s_norm[wib][vx] = heavy ? -1.f : norm;
+                if (basis_out) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) basis_out[(q0 + u) * 256 + 16 * (4 * g + r) + n] = D[r];
+                    if (lane == 0) norm_out[q0 + u] = norm;
+                } else if (vx == CCG - 1 || u == nvox - 1) {
+                    contract(u / CCG);
+                }
             }
+        };
+
+        // ---- the pipeline: chunk c in stage C, c+1 in stage B (records in flight), c+2 in stage A (indices in flight) ----
+        Chunk c0 = next_chunk(), c1 = next_chunk();
+        int vox0, idx0, lpos0, vox1, idx1, lpos1;
+        float w0, w1;
+        float4 P0, F0;
+        stage_a(c0, vox0, lpos0, idx0, w0);
+        stage_b(idx0, P0, F0);
+        stage_a(c1, vox1, lpos1, idx1, w1);
+#pragma unroll 1
+        while (c0.total >= 0) {
+            const float4 Pc = P0, Fc = F0;
+            const float wc = w0;
+            const int voxc = vox0, lposc = lpos0;
+            const Chunk cc = c0;
+            // records of the next chunk, indices of the one after it
+            c0 = c1;
+            vox0 = vox1;
+            lpos0 = lpos1;
+            w0 = w1;
+            if (c0.total >= 0) stage_b(idx1, P0, F0);
+            c1 = next_chunk();
+            stage_a(c1, vox1, lpos1, idx1, w1);
+            stage_c(cc, voxc, lposc, wc, Pc, Fc);
         }
-        __builtin_amdgcn_wave_barrier();  // the group matrix is re-used by the next group
     }
 }
 

@@ -652,6 +652,29 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
 // ------------------------------------------------------------------------------------------
 
 // ------------------------------------------------------------------------------------------
+// Slot-range split of the 55-slot lists (coarse grids).  A tile's slot steps run one after the other inside one block;
+// on the coarse grids a launch has fewer tiles than the chip has CUs and ends with its longest tile (up to 31 slots x
+// cin / 32 steps by ONE wave per SIMD, whose dependent MFMAs nothing overlaps).  With SPLIT the slots are cut into
+// SPLIT_RANGES FIXED ranges -- the 7 same-level slots, then the 48 cross-level slots in four blocks of 12 -- and every
+// (tile, range) is a block of its own (blockIdx.y = range).  A tile whose slots all lie in one range is finished by
+// that block as usual; otherwise each block stores its partial sums part[range][row position][column] and
+// k_sconv_split_reduce adds them IN RANGE ORDER and applies bias / ReLU / residual.  A row's result is
+// ((P0 + P1) + P2) + ... over the ranges its tile has, a range the row itself has no slot in contributes exact zeros:
+// the result does not depend on which rows share the tile (one rank of a sharded cloud computes the same bits).
+// ------------------------------------------------------------------------------------------
+constexpr int SPLIT_RANGES = 5;
+__host__ __device__ inline unsigned long long split_range_mask(int s) {
+    const int lo = s == 0 ? 0 : 7 + 12 * (s - 1), hi = s == 0 ? 7 : 19 + 12 * (s - 1);
+    return ((1ull << hi) - 1) ^ ((1ull << lo) - 1);
+}
+// blockIdx.y -> range: the ranges with the longest chains (twelve cross-level slots) are dispatched first
+__device__ inline int split_range_of_y(int y) { return y == 0 ? 1 : (y == 1 ? 2 : (y == 2 ? 0 : y)); }
+struct asr_split_args {
+    float* part;   // [SPLIT_RANGES][tiles * TM][ctot_pad] f32 partial sums (already unscaled)
+    i64 stride;    // elements per range
+};
+
+// ------------------------------------------------------------------------------------------
 // The plan-driven kernel: same tiles, panels, arithmetic and epilogue as k_sconv_mfma16, but
 //   * no neighbour table in LDS and no CSR parsing per block: a wave reads its group header with scalar loads
 //     and the 16 indices of a slot with one 64-byte load, prefetched one slot ahead;
@@ -660,10 +683,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
 //   * LDS holds only the two panel buffers, so three 8-wave blocks fit a CU.
 // Row weights (conv1b: importance of the neighbour) are read per (row, slot) through the plan as well.
 // ------------------------------------------------------------------------------------------
-template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
+template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4) void k_sconv_plan16(
         asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
-        const float* __restrict__ zeros) {
+        const float* __restrict__ zeros, asr_split_args sp) {
     constexpr int TM = WAVES * 16;
     constexpr int NCOL = NT * 16;
     constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : (MODE == ASR_CONV16_F16X2 ? 2 : 1);
@@ -708,17 +731,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     const i64 grp = tile * WAVES + wave;
     uint4 h = make_uint4(0, 0, 0, 0);
     if (grp < plan.groups) h = plan.hdr[grp];
-    const unsigned long long wmask =
+    // wmask_all: the group's slots (the pool holds one block per slot, in ascending order); wmask: those this block convolves
+    const unsigned long long wmask_all =
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.x) |
              ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.y) << 32)) & ((1ull << K) - 1);
     const unsigned woff = (unsigned)__builtin_amdgcn_readfirstlane((int)h.z);
-    if (lane == 0) s_wm[wave] = wmask;
+    if (lane == 0) s_wm[wave] = wmask_all;
     __syncthreads();
     unsigned long long bmask = 0;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) bmask |= s_wm[w];
     bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
+    unsigned long long wmask = wmask_all;
+    bool partial = false;  // SPLIT: the tile has slots in several ranges, this block stores partial sums
+    if constexpr (SPLIT) {
+        const unsigned long long rm = split_range_mask(split_range_of_y((int)blockIdx.y));
+        if ((bmask & rm) == 0) return;  // (block uniform)
+        partial = (bmask & ~rm) != 0;
+        wmask &= rm;
+        bmask &= rm;
+    }
 
     f32x4 acc[NT];
     f32x4 tacc[IMP ? NT : 1];
@@ -782,7 +815,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     auto has_slot = [&](const int k) __attribute__((always_inline)) -> bool { return k >= 0 && ((wmask >> k) & 1); };
     auto pool_off = [&](const int k) __attribute__((always_inline)) -> unsigned {
         const int kk = k < 0 ? 0 : k;
-        return (woff + (unsigned)__popcll(wmask & ((1ull << kk) - 1))) * 64u;
+        return (woff + (unsigned)__popcll(wmask_all & ((1ull << kk) - 1))) * 64u;
     };
     auto load_idx = [&](const int k) __attribute__((always_inline)) -> int {
         return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, has_slot(k) ? r * 4 : (int)OOB_OFF, (int)pool_off(k), 0);
@@ -938,11 +971,104 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         const i64 lr = row0 + wave * 16 + 4 * g + i;
         q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
     }
+    if constexpr (SPLIT) {
+        if (partial) {  // part[range][row position][column], unscaled (powers of two: exact)
+            float* pr = sp.part + (i64)split_range_of_y((int)blockIdx.y) * sp.stride;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i64 lr = row0 + wave * 16 + 4 * g + i;
+#pragma unroll
+                for (int nb = 0; nb < NT; ++nb)
+                    pr[lr * ctot_pad + n0 + nb * 16 + ncol] = acc[nb][i] * unscale[0] * unscale[1];
+            }
+            return;
+        }
+    }
     sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, q4, norm4, n0, ncol, ca, cout, has_b, out_f16, zeros, unscale);
     if (ROWW && a.out_importance && ncol == 0 && (DUAL ? has_b : ychunk == 0)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (q4[i] >= 0) a.out_importance[q4[i]] = norm4[i];
+    }
+}
+
+// Second pass of the slot-range split: one 256-thread block per 16-row group of a tile (a tile's rows are 16 x ctot_pad / 4
+// float4 pieces per group).  Tiles with a single range were finished by the first pass.
+template <int WAVES>
+__global__ __launch_bounds__(256) void k_sconv_split_reduce(asr_sparse_conv_args a, asr_conv_plan_view plan, asr_split_args sp,
+                                                            int ctot_pad, const float* __restrict__ zeros) {
+    constexpr int TM = WAVES * 16;
+    const i64 tile = blockIdx.x / WAVES;
+    const int grp_in_tile = (int)(blockIdx.x % WAVES);
+    unsigned long long bmask = 0;
+    for (int w = 0; w < WAVES; ++w) {  // (uniform loads)
+        const i64 grp = tile * WAVES + w;
+        if (grp < plan.groups) {
+            const uint4 h = plan.hdr[grp];
+            bmask |= (unsigned long long)h.x | ((unsigned long long)h.y << 32);
+        }
+    }
+    bmask &= (1ull << a.kernel_size) - 1;
+    int ranges = 0;
+#pragma unroll
+    for (int s = 0; s < SPLIT_RANGES; ++s) ranges += (bmask & split_range_mask(s)) != 0;
+    if (ranges < 2) return;
+    const int c4n = ctot_pad / 4;
+    unsigned amax = 0;
+    const bool res_v4 = a.residual && a.residual_ld % 4 == 0 && ((uintptr_t)a.residual & 15) == 0;
+    const bool out_v4 = a.out_ld % 4 == 0 && ((uintptr_t)a.out & 15) == 0;
+    for (int e = threadIdx.x; e < 16 * c4n; e += blockDim.x) {
+        const int r = e / c4n, c = 4 * (e % c4n);
+        const i64 lr = tile * TM + grp_in_tile * 16 + r;
+        if (lr >= a.num_out) break;
+        const i64 q = a.row_perm ? a.row_perm[lr] : lr;
+        float4 pv[SPLIT_RANGES];
+#pragma unroll
+        for (int s = 0; s < SPLIT_RANGES; ++s)  // all loads first (wave-uniform predicates)
+            if (bmask & split_range_mask(s)) pv[s] = *reinterpret_cast<const float4*>(sp.part + s * sp.stride + lr * ctot_pad + c);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool first = true;
+#pragma unroll
+        for (int s = 0; s < SPLIT_RANGES; ++s) {
+            if (!(bmask & split_range_mask(s))) continue;
+            if (first) {
+                v = pv[s];
+                first = false;
+            } else {
+                v.x += pv[s].x;
+                v.y += pv[s].y;
+                v.z += pv[s].z;
+                v.w += pv[s].w;
+            }
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+        float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool full4 = c + 3 < a.cout;
+        if (res_v4 && full4) res = *reinterpret_cast<const float4*>(a.residual + q * a.residual_ld + c);
+        const float rr[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = c + i;
+            if (col >= a.cout) continue;
+            float x = o[i] + (a.bias ? a.bias[col] : 0.f);
+            if (a.relu) x = fmaxf(x, 0.f);
+            if (a.residual) x += (res_v4 && full4) ? rr[i] : a.residual[q * a.residual_ld + col];
+            o[i] = x;
+            amax = max(amax, __float_as_uint(x) & 0x7fffffffu);
+        }
+        if (full4 && out_v4) {
+            *reinterpret_cast<float4*>(a.out + q * a.out_ld + c) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c + i < a.cout) a.out[q * a.out_ld + c + i] = o[i];
+        }
+    }
+    if (a.out_absmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+        if ((threadIdx.x & 63) == 0 && amax > __hip_atomic_load(a.out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.out_absmax, amax);
     }
 }
 
@@ -1066,6 +1192,30 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
             ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: the plan was built for another list");
         pv = plan->view();
     }
+    // slot-range split (see split_range_mask): plain 55-slot convolutions over a coarse grid.  Decided from the INPUT grid's
+    // row count, which a rank of a sharded cloud shares with the one-GPU run.
+    const bool split = use_plan && !dual && !imp && mode != ASR_CONV16_F16 && a.kernel_size == 55 && !a.force_nt &&
+                       !a.force_waves && ctot_pad % 64 == 0 && ctx->opt.sconv_split_rows > 0 &&
+                       a.num_inp <= ctx->opt.sconv_split_rows && a.num_inp >= ctx->opt.sconv_split_min_rows;
+    asr_split_args spa = {nullptr, 0};
+    if (split) {
+        nt = ctot_pad % 128 == 0 ? 8 : 4;
+        wide = true;
+        const i64 tiles = (a.num_out + 127) / 128;
+        spa.stride = tiles * 128 * ctot_pad;
+        const size_t need = (size_t)SPLIT_RANGES * spa.stride * sizeof(float);
+        if (need > ctx->split_part_bytes) {  // grown on demand, kept for the context's life
+            if (ctx->split_part) {
+                ASR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                (void)hipFree(ctx->split_part);
+                ctx->split_part = nullptr;
+                ctx->split_part_bytes = 0;
+            }
+            ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->split_part, need + need / 4));
+            ctx->split_part_bytes = need + need / 4;
+        }
+        spa.part = ctx->split_part;
+    }
 #define ASR_L16(NT_, KC_, W_, M_, I_, D_)                                                                        \
     {                                                                                                            \
         const i64 tiles_ = (a.num_out + W_ * 16 - 1) / (W_ * 16);                                                \
@@ -1073,7 +1223,7 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
         dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));                                  \
         if (use_plan)                                                                                            \
             k_sconv_plan16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                   \
-                    a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                               \
+                    a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros, spa);                          \
         else                                                                                                     \
             k_sconv_mfma16<NT_, KC_, W_, M_, I_, D_><<<grid, dim3(W_ * 64), 0, ctx->stream>>>(                   \
                     a, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros);                                   \
@@ -1097,7 +1247,29 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
         case 2: ASR_L16_W(2, KC_, M_) break; \
         default: ASR_L16_W(1, KC_, M_) break; \
     }
-    if (mode == ASR_CONV16_F16) {
+#define ASR_L16_SPLIT(NT_, M_)                                                                                   \
+    {                                                                                                            \
+        const i64 tiles_ = (a.num_out + 127) / 128;                                                              \
+        const i64 ny_ = ctot_pad / (NT_ * 16);                                                                   \
+        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_), SPLIT_RANGES);                    \
+        k_sconv_plan16<NT_, 32, 8, M_, false, false, true><<<grid, dim3(512), 0, ctx->stream>>>(                 \
+                a, pv, (const u16*)packed, cin_pad, ctot_pad, out_f16, zeros, spa);                              \
+        ASR_CHECK_LAUNCH(ctx);                                                                                   \
+        k_sconv_split_reduce<8><<<dim3((unsigned)(tiles_ * 8)), dim3(256), 0, ctx->stream>>>(a, pv, spa, ctot_pad, zeros); \
+    }
+    if (split) {
+        if (mode == ASR_CONV16_F16X2) {
+            if (nt == 8)
+                ASR_L16_SPLIT(8, ASR_CONV16_F16X2)
+            else
+                ASR_L16_SPLIT(4, ASR_CONV16_F16X2)
+        } else {
+            if (nt == 8)
+                ASR_L16_SPLIT(8, ASR_CONV16_BF16X3)
+            else
+                ASR_L16_SPLIT(4, ASR_CONV16_BF16X3)
+        }
+    } else if (mode == ASR_CONV16_F16) {
         if (kc64)
             ASR_L16_NT(64, ASR_CONV16_F16)
         else
@@ -1107,15 +1279,16 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
     } else {
         ASR_L16_NT(32, ASR_CONV16_BF16X3)
     }
+#undef ASR_L16_SPLIT
 #undef ASR_L16_NT
 #undef ASR_L16_W
 #undef ASR_L16_ID
 #undef ASR_L16
     ASR_CHECK_LAUNCH(ctx);
     {
-        char key[64];  // NT,KC,IMP,WAVES,DUAL,MODE,PLAN (k_sconv_mfma16 / k_sconv_plan16 instance)
-        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
-                 dual ? 1 : 0, mode, use_plan ? 1 : 0);
+        char key[64];  // NT,KC,IMP,WAVES,DUAL,MODE,PLAN[,1 = slot-range split] (k_sconv_mfma16 / k_sconv_plan16 instance)
+        snprintf(key, sizeof(key), "%d,%d,%d,%d,%d,%d,%d%s", nt, kc64 ? 64 : 32, imp && !dual ? 1 : 0, wide ? 8 : 4,
+                 dual ? 1 : 0, mode, use_plan ? 1 : 0, split ? ",1" : "");
         ++ctx->sconv_launches[key];
     }
     return ASR_HIP_OK;

@@ -9,7 +9,9 @@ def load(path):
     out = []
     for line in open(path).read().splitlines()[1:]:
         f = line.rsplit(",", 5)
-        if "sconv" in f[0]:
+        if "split_reduce" in f[0] and out:  # second pass of a slot-range split: part of the layer before it
+            out[-1] = (out[-1][0], out[-1][1] + float(f[3]))
+        elif "sconv" in f[0]:
             out.append((f[0], float(f[3])))
     return out
 

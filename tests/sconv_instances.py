@@ -20,14 +20,17 @@ BENCH_INSTANCES = {
 # order is <NT, KC, WAVES, MODE, IMP, DUAL>; MODE 2 = bf16x3, 3 = f16x2; PLAN 1 = k_sconv_plan16, 0 = k_sconv_mfma16)
 BENCH_SHAPES16 = {
     (4, 32, 0, 8, 1), (4, 32, 0, 8, 0), (8, 32, 0, 8, 1), (8, 32, 0, 8, 0),
-    (8, 32, 0, 4, 1), (8, 32, 0, 4, 0), (2, 32, 0, 4, 1), (2, 32, 0, 4, 0),
+    (8, 32, 0, 4, 1), (8, 32, 0, 4, 0), (2, 32, 0, 4, 1),
     (2, 32, 0, 8, 0),
 }
+# ... and the slot-range split (round 4: plain 55-slot layers of a grid of 2 048 .. 32 768 rows, level 4 at 10 M points;
+# an eighth field, 1, in the launch counters; template argument SPLIT = true in the trace)
+BENCH_SPLIT16 = {(8, 32, 0, 8, 0)}
 MODE_ID = {"bf16x3": 2, "f16x2": 3}
 
 
 def bench_instances16(mode):
-    return {s + (MODE_ID[mode], 1) for s in BENCH_SHAPES16}
+    return {s + (MODE_ID[mode], 1) for s in BENCH_SHAPES16} | {s + (MODE_ID[mode], 1, 1) for s in BENCH_SPLIT16}
 
 
 BENCH_INSTANCES16 = bench_instances16("f16x2")  # what `python bench.py` launches
@@ -37,10 +40,11 @@ def instances16_in_trace(path):
     out = set()
     with open(path) as f:
         for line in f:
-            m = re.match(r"k_sconv_(mfma|plan)16<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, \d+)?>", line)
+            m = re.match(r"k_sconv_(mfma|plan)16<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false))?>", line)
             if m:
-                out.add((int(m.group(2)), int(m.group(3)), int(m.group(6) == "true"), int(m.group(4)),
-                         int(m.group(7) == "true"), int(m.group(5)), int(m.group(1) == "plan")))
+                key = (int(m.group(2)), int(m.group(3)), int(m.group(6) == "true"), int(m.group(4)),
+                       int(m.group(7) == "true"), int(m.group(5)), int(m.group(1) == "plan"))
+                out.add(key + (1,) if m.group(8) == "true" else key)
     return out
 
 

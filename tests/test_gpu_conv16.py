@@ -186,7 +186,8 @@ def test_whole_path_precisions(gpu, precision, tol):
     pipe.ctx.sconv_variant_counts(reset=True)
     values = pipe.forward(_t(pts, gpu), _t(nrm, gpu), _t(rad, gpu), bb[0], bb[1])
     counts = pipe.ctx.sconv_variant_counts()
-    assert sum(counts.values()) == 44 and all(len(k) == 7 and k[5] == {"f16": 1, "bf16x3": 2, "f16x2": 3}[precision] and k[6] == 1 for k in counts)
+    # (an eighth field, 1, marks the slot-range split of the coarse grids' plain 55-slot layers)
+    assert sum(counts.values()) == 44 and all(len(k) in (7, 8) and k[5] == {"f16": 1, "bf16x3": 2, "f16x2": 3}[precision] and k[6] == 1 for k in counts)
     assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), ref["voxel_keys0"])
     for name, got in (("code", pipe.get("code")), ("values", values)):
         scale = max(1.0, float(np.abs(ref[name]).max()))
@@ -255,6 +256,66 @@ def test_conv_plan_reuse_and_row_lists(geo, gpu, mode):
     # a plan of another list is refused
     with pytest.raises(Exception):
         ops.sparse_conv16(mode, pa, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=lplan)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_slot_range_split_of_the_coarse_grids(geo, gpu, mode):
+    """Plain 55-slot convolutions over a grid of sconv_split_min_rows .. sconv_split_rows rows run as one block per (tile,
+    slot range) + a second pass that adds the partial sums in range order (asr_conv16.hip, split_range_mask): against the
+    oracle, against the unsplit kernel, and -- what a sharded forward relies on -- bit-identical whatever rows share a tile."""
+    from asr_hip import ops
+    level = 0
+    idx, kidx, rs, num_inp = _csr(geo, "nb", level)
+    v = len(rs) - 1
+    ctx = ops.context(gpu)
+    assert ctx.get_option("sconv_split_min_rows") <= v <= ctx.get_option("sconv_split_rows"), v
+    rng = np.random.default_rng(77)
+    K, cin, ca = 55, 64, 128
+    f = rng.standard_normal((num_inp, cin)).astype(np.float32)
+    W = (rng.standard_normal((K, cin, ca)) * np.sqrt(2.0 / (8 * cin))).astype(np.float32)
+    b = (rng.standard_normal(ca) * 0.1).astype(np.float32)
+    res = rng.standard_normal((v, ca)).astype(np.float32)
+    d_idx, d_k, d_rs = _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu)
+    pk = ops.pack_filters(_t(W, gpu), mode)
+    with O.precise():
+        ref = np.maximum(O.sparse_conv(W, f, idx, kidx, None, rs, False) + b, 0) + res
+    outs = {}
+    orders = {"regrouped": ops.row_groups(d_k, d_rs),
+              "shuffled": torch.from_numpy(rng.permutation(v).astype(np.int32)).to(gpu),
+              "natural": torch.arange(v, dtype=torch.int32, device=gpu)}
+    for name, perm in orders.items():
+        plan = ops.ConvPlan(K, d_idx, d_k, d_rs, row_perm=perm)
+        ctx.sconv_variant_counts(reset=True)
+        out = ops.sparse_conv16(mode, pk, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=perm, plan=plan,
+                                bias=_t(b, gpu), relu=True, residual=_t(res, gpu))
+        keys = list(ctx.sconv_variant_counts())
+        assert len(keys) == 1 and len(keys[0]) == 8 and keys[0][7] == 1, keys  # the split ran
+        outs[name] = out.cpu().numpy()
+        _close(outs[name], ref)
+        del plan
+    assert np.array_equal(outs["regrouped"], outs["shuffled"]) and np.array_equal(outs["regrouped"], outs["natural"])
+    # a row list (a rank's owned rows): the same bits for those rows, the others untouched
+    n_rows = v // 3
+    lplan = ops.ConvPlan(K, d_idx, d_k, d_rs, row_perm=orders["shuffled"], num_rows=n_rows)
+    part = torch.full((v, ca), 7.0, dtype=torch.float32, device=gpu)
+    ops.sparse_conv16(mode, pk, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=orders["shuffled"], num_rows=n_rows,
+                      plan=lplan, out=part, bias=_t(b, gpu), relu=True, residual=_t(res, gpu))
+    rows = orders["shuffled"][:n_rows].long().cpu().numpy()
+    got = part.cpu().numpy()
+    assert np.array_equal(got[rows], outs["regrouped"][rows])
+    assert np.all(got[np.setdiff1d(np.arange(v), rows)] == 7.0)
+    # the unsplit kernel: another summation order, the same tolerance
+    ctx.set_option("sconv_split_rows", 0)
+    try:
+        plan = ops.ConvPlan(K, d_idx, d_k, d_rs, row_perm=orders["regrouped"])
+        ctx.sconv_variant_counts(reset=True)
+        whole = ops.sparse_conv16(mode, pk, K, cin, ca, _t(f, gpu), d_idx, d_k, d_rs, row_perm=orders["regrouped"],
+                                  plan=plan, bias=_t(b, gpu), relu=True, residual=_t(res, gpu)).cpu().numpy()
+        assert all(len(k) == 7 for k in ctx.sconv_variant_counts())
+    finally:
+        ctx.set_option("sconv_split_rows", 32768)
+    _close(whole, ref)
+    _close(whole, outs["regrouped"])
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])

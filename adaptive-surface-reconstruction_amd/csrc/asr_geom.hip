@@ -1188,10 +1188,14 @@ __device__ __forceinline__ void radius_row_out(i64 q, i64 found, bool heavy, int
         mypos[u] = lane + 64 * u < h ? s_pos[lane + 64 * u] : 0;
         rank[u] = 0;
     }
-    for (int j = 0; j < h; ++j) {  // LDS broadcast reads
-        const u64 kj = s_keys[j];
+    if (h <= 64) {  // (wave uniform; 19 of 20 rows)
+        for (int j = 0; j < h; ++j) rank[0] += s_keys[j] < mine[0];  // LDS broadcast reads
+    } else {
+        for (int j = 0; j < h; ++j) {
+            const u64 kj = s_keys[j];
 #pragma unroll
-        for (int u = 0; u < RADIUS_LIGHT / 64; ++u) rank[u] += kj < mine[u];
+            for (int u = 0; u < RADIUS_LIGHT / 64; ++u) rank[u] += kj < mine[u];
+        }
     }
 #pragma unroll
     for (int u = 0; u < RADIUS_LIGHT / 64; ++u)
@@ -2001,10 +2005,10 @@ __global__ void k_rg_apply(RowGroupBatch b, const int32_t* sorted_ids, const int
 // Ranked keys (round 4): a hierarchy has a few thousand DISTINCT slot masks, so the 54 mask bits of the sort key are replaced
 // by the mask's rank among the distinct masks (same order, same permutation): (job, segment, rank) is 22 bits -- three digit
 // passes over all 13 lists in one sort instead of three passes over the 9-slot lists plus eight over the 55-slot ones.
-// Distinct masks: a small hash set (k_rg_mask_insert: all but the first insertion of a mask are read-only probes), sorted by
-// ONE workgroup in LDS (k_rg_mask_ranks, bitonic), rank written back as the set's value.  More than RG_MAX_MASKS distinct
-// masks: the caller falls back to the full-mask keys.
-constexpr int RG_MAX_MASKS = 16384;  // 128 KB of LDS for the one sorting workgroup (C3: ~1 500 distinct masks, mixed-density C5: more than 4 096)
+// Distinct masks: a small hash set (k_rg_masks: all but the first insertion of a mask are read-only probes), collected into a
+// dense list (k_rg_mask_collect) and ranked by counting (k_rg_mask_ranks), rank written back as the set's value.  More than
+// RG_MAX_MASKS distinct masks: the caller falls back to the full-mask keys.
+constexpr int RG_MAX_MASKS = 16384;  // (C3: ~1 500 distinct masks, mixed-density C5: more than 4 096)
 constexpr int RG_MASK_TAB = 65536;
 __global__ void k_rg_masks(RowGroupBatch b, u64* masks, HashTab t, int* cnt) {
     const i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x;
@@ -2020,46 +2024,35 @@ __global__ void k_rg_masks(RowGroupBatch b, u64* masks, HashTab t, int* cnt) {
     }
     masks[e] = m;
 }
-__global__ __launch_bounds__(1024) void k_rg_mask_ranks(HashTab t, int* cnt) {
-    __shared__ u64 s_key[RG_MAX_MASKS];
-    __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    for (u64 i = threadIdx.x; i <= t.mask; i += blockDim.x) {
-        const u64 k = t.keys[i];
-        if (k) {
-            const int o = atomicAdd(&s_n, 1);
-            if (o < RG_MAX_MASKS) s_key[o] = k;
-        }
+// the set's keys as a dense list (any order) with their slots; cnt[2] = how many
+__global__ void k_rg_mask_collect(HashTab t, u64* list, int32_t* slot_of, int* cnt) {
+    const u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x;
+    const u64 k = i <= t.mask ? t.keys[i] : 0;
+    const int o = block_append(k != 0, cnt + 2);
+    if (k && o < RG_MAX_MASKS) {
+        list[o] = k;
+        slot_of[o] = (int32_t)i;
     }
-    __syncthreads();
-    const int n = s_n;
-    if (threadIdx.x == 0) cnt[2] = n;
+}
+// rank of every distinct mask = number of smaller ones (the masks are distinct): one thread per mask, the list read through
+// LDS tiles.  (Round 4: this was a bitonic sort by ONE workgroup, 0.5 ms alone and 1.3 ms beside the search's query kernel,
+// whose waves share that CU's issue slots -- on the critical chain of the build.)
+__global__ __launch_bounds__(256) void k_rg_mask_ranks(HashTab t, const u64* list, const int32_t* slot_of, const int* cnt) {
+    __shared__ u64 s_key[2048];
+    const int n = cnt[2];
     if (n > RG_MAX_MASKS) return;
-    int m = 2;  // bitonic sort over the next power of two (a hierarchy has ~1500 distinct masks)
-    while (m < n) m <<= 1;
-    for (int i = n + threadIdx.x; i < m; i += blockDim.x) s_key[i] = ~u64(0);
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < m; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const u64 a = s_key[i], c = s_key[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) {
-                        s_key[i] = c;
-                        s_key[l] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n) return;
+    const u64 mine = i < n ? list[i] : 0;
+    int rank = 0;
+    for (int base = 0; base < n; base += 2048) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2048; e += blockDim.x) s_key[e] = base + e < n ? list[base + e] : ~u64(0);
+        __syncthreads();
+        const int m = min(2048, n - base);
+        for (int e = 0; e < m; ++e) rank += s_key[e] < mine;  // (LDS broadcast reads)
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const i64 slot = tab_find_slot(t, s_key[i]);
-        if (slot >= 0) t.vals[slot] = i;
-    }
+    if (i < n) t.vals[slot_of[i]] = rank;
 }
 // key = (job, segment, rank of the slot mask) in 4 + 6 + rank_bits bits
 __global__ void k_rg_keys_ranked(RowGroupBatch b, i64 seg, const u64* masks, HashTab t, unsigned* keys, int32_t* ids,
@@ -2675,7 +2668,12 @@ static int rg_batch_run_ranked(asr_hip_context* ctx, const asr_row_group_job* jo
     ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
     k_rg_masks<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, masks, t, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
-    k_rg_mask_ranks<<<1, 1024, 0, ctx->stream>>>(t, ctx->d_flags);
+    u64* mlist = arena_alloc<u64>(ctx->scratch, RG_MAX_MASKS);
+    int32_t* mslot = arena_alloc<int32_t>(ctx->scratch, RG_MAX_MASKS);
+    if (!mlist || !mslot) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    k_rg_mask_collect<<<grid_for((i64)t.mask + 1, BLK), BLK, 0, ctx->stream>>>(t, mlist, mslot, ctx->d_flags);
+    ASR_CHECK_LAUNCH(ctx);
+    k_rg_mask_ranks<<<RG_MAX_MASKS / 256, 256, 0, ctx->stream>>>(t, mlist, mslot, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     int host[16];
     ASR_TRY(read_flags(ctx, host));
@@ -3293,7 +3291,9 @@ int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* ra
             ASR_CHECK_LAUNCH(ctx);
         }
     }
-    // light rows: already sorted in their fixed slots, copy them to the CSR positions
+    // light rows: already sorted in their fixed slots, copy them to the CSR positions.  (Round 4: on a side stream beside the
+    // heavy rows' fill / sort / unpack below -- measured, no gain: the build's two chains already fill the GPU, what one
+    // kernel gains the ones beside it lose.)
     k_radius_place<<<grid_for(v * 16, BLK), BLK, 0, ctx->stream>>>(st.tmp, rs, st.is_heavy, v, sizes, st.ids, srad, idx,
                                                                    spos, dist, compat);
     ASR_CHECK_LAUNCH(ctx);

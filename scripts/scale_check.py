@@ -29,8 +29,9 @@ for prec in ("f32", "bf16x3", "f16x2"):
     print(prec, "%.1f ms/step, %.3g points/s" % (dt * 1e3, n / dt), "voxels", list(pipe.sizes.num_voxels)[:5],
           "reserved GB %.1f" % (pipe.ctx.reserved_bytes() / 2**30), flush=True)
     if prec != "f32":
-        print("  launches plan/table:", sum(c for k, c in counts.items() if len(k) == 7 and k[6] == 1) // 2,
-              sum(c for k, c in counts.items() if len(k) == 7 and k[6] == 0) // 2, flush=True)
+        print("  launches plan/table/slot-range split:", sum(c for k, c in counts.items() if len(k) >= 7 and k[6] == 1) // 2,
+              sum(c for k, c in counts.items() if len(k) >= 7 and k[6] == 0) // 2,
+              sum(c for k, c in counts.items() if len(k) == 8) // 2, flush=True)
     del pipe
     torch.cuda.empty_cache()
 a = out["f32"]

@@ -167,7 +167,7 @@ static void release_members(asr_hip_context* ctx) {
     ctx->persist.release();
     ctx->scratch.release();
     ctx->plan_arena.release();
-    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_flags_base) (void)hipFree(ctx->d_flags_base);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_absmax) (void)hipFree(ctx->d_absmax);
     if (ctx->split_part) (void)hipFree(ctx->split_part);

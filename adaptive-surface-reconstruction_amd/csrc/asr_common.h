@@ -213,7 +213,9 @@ struct asr_hip_context {
     float stage_ms[6] = {0, 0, 0, 0, 0, 0};
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
-    int* d_flags = nullptr;  // small device scratch for counters (persistent)
+    int* d_flags = nullptr;  // the CURRENT block of 64 device counters: a window into d_flags_base (asr_prim.h fresh_flags)
+    int* d_flags_base = nullptr;  // pool of zeroed counter blocks, re-zeroed with ONE memset when it is used up
+    int flags_next = 0;
     float* d_zeros = nullptr;  // 4 KB of zeros: target of masked-out loads
     float* split_part = nullptr;   // partial sums of the slot-range split of the 16-bit sparse conv (grown on demand)
     size_t split_part_bytes = 0;

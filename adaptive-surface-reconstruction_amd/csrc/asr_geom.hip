@@ -2193,7 +2193,7 @@ static int grow_keys(asr_hip_context* ctx, Arena& arena, const asr_octree_frame*
         const int lcap = (int)std::min<u64>(cap / 2, u64(1) << 30);
         u64* list = arena_alloc<u64>(arena, (size_t)lcap + 8);
         if (!list) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        ASR_TRY(fresh_flags(ctx));
         k_grow_init<<<grid_for(n, BLK), BLK, 0, ctx->stream>>>(*frame, pts, radii, n, radius_scale, max_depth, t,
                                                              ctx->d_flags, list, lcap);
         ASR_CHECK_LAUNCH(ctx);
@@ -2260,7 +2260,7 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
         u64* list = arena_alloc<u64>(ctx->scratch, (size_t)lcap + 8);
         uint8_t* flag = arena_alloc<uint8_t>(ctx->scratch, (size_t)lcap / 8 + 8);
         if (!list || !flag) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        ASR_TRY(fresh_flags(ctx));
         if (grown) {
             if (num_grown > 0)
                 k_octree_insert_keys<<<grid_for(num_grown, BLK), BLK, 0, ctx->stream>>>(grown, num_grown, t, ctx->d_flags,
@@ -2352,7 +2352,7 @@ static int build_key_map(asr_hip_context* ctx, const u64* keys, i64 v, HashTab& 
     ASR_TRY(ensure_flags(ctx));
     u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * v)) << grow;
     ASR_TRY(make_table(ctx, ctx->scratch, cap, true, t));
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     k_map_build<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, t, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
@@ -2517,7 +2517,7 @@ int asr_geom_neighbors_build_batch(asr_hip_context* ctx, Arena& out_arena, asr_n
             off += caps[j];
         }
         ASR_HIP_CHECK(ctx, hipMemsetAsync(tkeys, 0, cap_sum * sizeof(u64), ctx->stream));
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        ASR_TRY(fresh_flags(ctx));
         ASR_HIP_CHECK(ctx, hipMemsetAsync(counts + total, 0, sizeof(i64), ctx->stream));
         k_map_build_batch<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, ctx->d_flags);
         ASR_CHECK_LAUNCH(ctx);
@@ -2665,7 +2665,7 @@ static int rg_batch_run_ranked(asr_hip_context* ctx, const asr_row_group_job* jo
         ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     HashTab t;
     ASR_TRY(make_table(ctx, ctx->scratch, RG_MASK_TAB, true, t));
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     k_rg_masks<<<grid_for(total, BLK), BLK, 0, ctx->stream>>>(b, masks, t, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     u64* mlist = arena_alloc<u64>(ctx->scratch, RG_MAX_MASKS);
@@ -2743,7 +2743,7 @@ int asr_geom_coarsen_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* v_
         return ASR_HIP_OK;
     }
     int host[16];
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     k_coarsen_count<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY(read_flags(ctx, host));
@@ -2759,7 +2759,7 @@ int asr_geom_coarsen_fill(asr_hip_context* ctx, const u64* keys, i64 v, u64* out
     int32_t* s_u = arena_alloc<int32_t>(ctx->scratch, v_out);
     int32_t* s_s = arena_alloc<int32_t>(ctx->scratch, v_out);
     if (!k_u || !s_u || !s_s) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     k_coarsen_emit<<<grid_for(v, BLK), BLK, 0, ctx->stream>>>(keys, v, k_u, s_u, ctx->d_flags);
     ASR_CHECK_LAUNCH(ctx);
     ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, k_u, out_keys, s_u, s_s, v_out, 64)));
@@ -2929,7 +2929,7 @@ static int build_cell_table(asr_hip_context* ctx, i64 n, int lmin, int lmax, Rad
 static int build_point_index(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
                              i64 n, int lmin, int lmax, RadiusState& st, Arena* keep = nullptr,
                              bool want_rank = false, bool hash_all = true, const float* radii = nullptr) {
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     ASR_TRY(sort_points(ctx, frame, pts, n, lmax, st, keep, want_rank, radii));
     return build_cell_table(ctx, n, lmin, lmax, st, hash_all);
 }
@@ -3009,7 +3009,7 @@ int asr_geom_precells(asr_hip_context* ctx, Arena& keep) {
     st.codes = st.codes_w = pi.codes;
     st.n = pi.n;
     st.cell_grow = rstate(ctx).cell_grow;
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     ASR_TRY(build_cell_table(ctx, pi.n, 1, pi.lsort, st, false, &keep));
     int host[16];
     ASR_TRY(read_flags(ctx, host));
@@ -3028,7 +3028,7 @@ int asr_geom_precells(asr_hip_context* ctx, Arena& keep) {
 static int query_level_range(asr_hip_context* ctx, const asr_octree_frame* frame, const float* sizes,
                              i64 v, int* lmin, int* lmax) {
     int host[16];
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     int init[2] = {ASR_MAX_LEVEL, 0};
     ASR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_flags + 6, init, 2 * sizeof(int),
                                       hipMemcpyHostToDevice, ctx->stream));
@@ -3093,7 +3093,7 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
         st.codes_u = nullptr;
         st.ids_u = nullptr;
         st.ids_w = pre->ids;
-        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+        ASR_TRY(fresh_flags(ctx));
         if (pre->tab_keys && pre->tab_grow == st.cell_grow && pre->tab_lmin <= lmin && pre->tab_lmax >= std::max(lmax, ltab)) {
             st.tab = HashTab{pre->tab_keys, nullptr, pre->tab_mask};  // built beside the octree (asr_geom_precells)
             st.start = pre->tab_start;
@@ -3364,7 +3364,7 @@ int asr_geom_dual_count(asr_hip_context* ctx, const u64* nodes, i64 nn, const u6
     u64 cap = next_pow2((u64)std::max<i64>(1024, 2 * nn));
     ASR_TRY(make_table(ctx, ctx->scratch, cap, true, t));
     ASR_HIP_CHECK(ctx, hipMemsetAsync(t.vals, 0xFF, cap * sizeof(int32_t), ctx->stream));  // -1 = inner
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), ctx->stream));
+    ASR_TRY(fresh_flags(ctx));
     int32_t* keep = t.vals;
     t.vals = arena_alloc<int32_t>(ctx->scratch, cap);  // throw-away values for the node pass
     if (!t.vals) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");

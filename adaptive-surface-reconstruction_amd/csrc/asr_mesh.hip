@@ -460,7 +460,7 @@ int asr_mesh_contour_count(asr_hip_context* ctx, const float* values, i64 num_va
     ASR_TRY(ensure_flags(ctx));
     ctx->scratch.reset();
     hipStream_t s = ctx->stream;
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), s));
+    ASR_TRY(fresh_flags(ctx));
     MESH_ALLOC(flag, i64, num_duals + 1);
     MESH_ALLOC(npairs, i64, num_duals + 1);
     MESH_ALLOC(voff, i64, num_duals + 1);
@@ -556,7 +556,7 @@ int asr_mesh_components_count(asr_hip_context* ctx, const float* vertices, i64 n
     ASR_TRY(ensure_flags(ctx));
     ctx->scratch.reset();
     hipStream_t s = ctx->stream;
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags, 0, 16 * sizeof(int), s));
+    ASR_TRY(fresh_flags(ctx));
     MESH_ALLOC(parent, int, nv);
     MESH_ALLOC(is_root, i64, nv + 1);
     MESH_ALLOC(label, i64, nv + 1);

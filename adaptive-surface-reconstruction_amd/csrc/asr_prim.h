@@ -7,10 +7,27 @@
 
 namespace asr_prim {
 
+// Device counters come in blocks of 64 ints out of a pool that is zeroed once: a pass that needs fresh counters takes the
+// next block (fresh_flags) instead of clearing the one block there used to be -- twenty fill launches per geometry build,
+// each a dependent launch in one of its two chains.  The pool is cleared again, on the context's stream, when it is used up.
+constexpr int FLAG_BLOCK = 64, FLAG_BLOCKS = 512;
 static inline int ensure_flags(asr_hip_context* ctx) {
-    if (!ctx->d_flags) {
-        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_flags, 256 * sizeof(int)));
+    if (!ctx->d_flags_base) {
+        ASR_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_flags_base, (size_t)FLAG_BLOCK * FLAG_BLOCKS * sizeof(int)));
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags_base, 0, (size_t)FLAG_BLOCK * FLAG_BLOCKS * sizeof(int), ctx->stream));
+        ctx->d_flags = ctx->d_flags_base;
+        ctx->flags_next = 1;
     }
+    return ASR_HIP_OK;
+}
+// ctx->d_flags = a block of zeroed counters (what hipMemsetAsync(ctx->d_flags, 0, ...) used to give)
+static inline int fresh_flags(asr_hip_context* ctx) {
+    ASR_TRY(ensure_flags(ctx));
+    if (ctx->flags_next >= FLAG_BLOCKS) {
+        ASR_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_flags_base, 0, (size_t)FLAG_BLOCK * FLAG_BLOCKS * sizeof(int), ctx->stream));
+        ctx->flags_next = 0;
+    }
+    ctx->d_flags = ctx->d_flags_base + (size_t)FLAG_BLOCK * ctx->flags_next++;
     return ASR_HIP_OK;
 }
 static inline int read_flags(asr_hip_context* ctx, int* host) {

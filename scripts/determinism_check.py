@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 pts, nrm = synth.scan_cloud(n, seed=1000, device=dev)
 radii = synth.knn_radii_gpu(pts, 24)
 bb = synth.bounding_box(pts, 0.1)
-for prec in ("bf16x3", "f16"):
+for prec in ("f16x2", "bf16x3", "f16"):
     pipe = ImplicitPipeline(synth.make_weights(1, seed=0), device=dev, precision=prec)
     ref = pipe.forward(pts, nrm, radii, bb[0], bb[1]).clone()
     code = pipe.get("code").clone()

@@ -1116,6 +1116,89 @@ __global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, 
     out[2 * q + 1] = o1;
 }
 
+// The same decoder for the widths of the released model (c = h1 = h2 = 32) on the f32 matrix cores: a wave owns groups of 16
+// voxels, every layer is out[16 voxels][32] = act[16][32] . W^T as 2 x 8 v_mfma_f32_16x16x4_f32 (exact f32 products, f32
+// accumulate), the third layer one tile of which two columns are real.  The thread-per-voxel kernel above issues one LDS
+// broadcast read per FMA (2 112 of each per voxel: 0.36 ms at 10 M points); here the weights stay in registers as B fragments
+// and a layer's result goes through a 2 KB LDS tile per wave from the accumulator layout to the A layout.  k order: MFMA step s of
+// k-lane kk contracts k = 8 kk + s on both operands, so that a lane's eight A values are 32 contiguous bytes.
+__global__ __launch_bounds__(256) void k_decode_mfma(const float* __restrict__ code, i64 v, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, const float* __restrict__ w3,
+                                                     const float* __restrict__ sizes, float* __restrict__ out) {
+    constexpr int C = 32, LD = 36;
+    __shared__ __attribute__((aligned(16))) float s_t[4][16][LD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n = lane & 15, kk = lane >> 4;
+    float B1[8][2], B2[8][2], B3[8], bias1[2], bias2[2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            B1[s][T] = w1[(i64)(16 * T + n) * (3 + C) + 3 + 8 * kk + s];  // (the three shift columns are zero inputs)
+            B2[s][T] = w2[(i64)(16 * T + n) * C + 8 * kk + s];
+        }
+        B3[s] = n < 2 ? w3[n * C + 8 * kk + s] : 0.f;
+    }
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        bias1[T] = b1[16 * T + n];
+        bias2[T] = b2[16 * T + n];
+    }
+    const i64 groups = (v + 15) / 16;
+    const i64 wave0 = (i64)blockIdx.x * 4 + wave, nwaves = (i64)gridDim.x * 4;
+    float (*st)[LD] = s_t[wave];
+    auto load_rows = [&](i64 grp, float4& t0, float4& t1) __attribute__((always_inline)) {
+        const i64 q = grp * 16 + n;
+        t0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        t1 = t0;
+        if (grp < groups && q < v) {
+            t0 = *reinterpret_cast<const float4*>(code + q * C + 8 * kk);
+            t1 = *reinterpret_cast<const float4*>(code + q * C + 8 * kk + 4);
+        }
+    };
+    float4 n0, n1;  // the next group's rows, in flight while this group runs through the layers
+    load_rows(wave0, n0, n1);
+    for (i64 grp = wave0; grp < groups; grp += nwaves) {
+        float x[8];
+        x[0] = n0.x; x[1] = n0.y; x[2] = n0.z; x[3] = n0.w;
+        x[4] = n1.x; x[5] = n1.y; x[6] = n1.z; x[7] = n1.w;
+        load_rows(grp + nwaves, n0, n1);
+#pragma unroll
+        for (int layer = 0; layer < 2; ++layer) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], layer == 0 ? B1[s][0] : B2[s][0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], layer == 0 ? B1[s][1] : B2[s][1], a1, 0, 0, 0);
+            }
+            // a_T[i] = act[voxel 4 kk + i][column 16 T + n]: bias, ReLU, then through LDS into the A layout
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st[4 * kk + i][n] = fmaxf(a0[i] + (layer == 0 ? bias1[0] : bias2[0]), 0.f);
+                st[4 * kk + i][16 + n] = fmaxf(a1[i] + (layer == 0 ? bias1[1] : bias2[1]), 0.f);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float4 t0 = *reinterpret_cast<const float4*>(&st[n][8 * kk]);
+            const float4 t1 = *reinterpret_cast<const float4*>(&st[n][8 * kk + 4]);
+            x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w;
+            x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+        }
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) o = __builtin_amdgcn_mfma_f32_16x16x4f32(x[s], B3[s], o, 0, 0, 0);
+        if (n < 2) {  // o[i] = out[voxel 4 kk + i][n]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i64 vox = grp * 16 + 4 * kk + i;
+                if (vox < v) out[2 * vox + n] = (n == 0 && sizes) ? o[i] * sizes[vox] : o[i];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1330,8 +1413,7 @@ int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "decode_mlp: layer widths must be 1..64");
     size_t lds = sizeof(float) * (size_t)(h1 * c + h1 + h2 * h1 + h2 + 2 * h2);
     if (c == 32 && h1 == 32 && h2 == 32 && ((uintptr_t)code % 16 == 0))
-        k_decode<32, 32, 32><<<grid_for(v, 256), 256, lds, ctx->stream>>>(code, v, c, w1, b1, h1, w2, b2, h2,
-                                                                          w3, sizes, out);
+        k_decode_mfma<<<(unsigned)std::min<i64>((v + 63) / 64, 2048), 256, 0, ctx->stream>>>(code, v, w1, b1, w2, b2, w3, sizes, out);
     else
         k_decode<0, 0, 0><<<grid_for(v, 256), 256, lds, ctx->stream>>>(code, v, c, w1, b1, h1, w2, b2, h2, w3,
                                                                        sizes, out);

@@ -1337,7 +1337,10 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
 }
 
 // aggregate (net_definitions_torch.py:640-653, 72-120): feats1 [V0, C0] and the per-pair importance of the last build
-int implicit_aggregate(asr_hip_context* ctx, const float* points, const float* normals, i64 n, Net& net) {
+// feats_amax (f16x2 network): zeroed device scalar that receives the f32 bits of the largest |feats1| (kept by the continuous
+// conv's kernels instead of a pass over its 330 MB output)
+int implicit_aggregate(asr_hip_context* ctx, const float* points, const float* normals, i64 n, Net& net,
+                       unsigned* feats_amax = nullptr) {
     (void)points;
     if (n != ctx->sizes.num_points || ctx->sizes.num_voxels[0] == 0)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: no matching implicit_build");
@@ -1372,13 +1375,13 @@ int implicit_aggregate(asr_hip_context* ctx, const float* points, const float* n
         float* part = arena_alloc<float>(ctx->scratch, (size_t)ctx->agg_nq * C0);
         if (!part) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_conv_cconv(ctx, ck->data, ctx->agg_qcenters, ctx->agg_qsizes, feats, feats, ctx->agg_spos, imp_pairs,
-                               ctx->agg_rs, ctx->agg_nq, 4, C0, 1, cb->data, 1, part, 1));
+                               ctx->agg_rs, ctx->agg_nq, 4, C0, 1, cb->data, 1, part, 1, feats_amax));
         ASR_HIP_CHECK(ctx, hipMemsetAsync(feats1, 0, sizeof(float) * (size_t)V0 * C0, ctx->stream));
         k_scatter_rows<<<grid_for(ctx->agg_nq * C0, 256), 256, 0, ctx->stream>>>(part, ctx->agg_rows, ctx->agg_nq, C0, feats1);
         ASR_CHECK_LAUNCH(ctx);
     } else {
         ASR_TRY(asr_conv_cconv(ctx, ck->data, g[0].centers, g[0].sizes, feats, feats,
-                               ctx->agg_spos, imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1, 1));
+                               ctx->agg_spos, imp_pairs, ctx->agg_rs, V0, 4, C0, 1, cb->data, 1, feats1, 1, feats_amax));
     }
     ctx->feats1 = feats1;
     ctx->importance = imp_pairs;
@@ -1395,7 +1398,11 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     ASR_TRY(ensure_events(ctx));
     Net net{ctx, {weights, num_weights}};
     net.precision = prm->precision;
-    ASR_TRY(implicit_aggregate(ctx, points, normals, n, net));
+    // f16x2: every activation buffer has a running maximum, kept by the kernels that write it (a concat buffer by both of its
+    // producers) and read by the ones that consume it -- feats1's by the continuous conv
+    ASR_TRY(net.begin_amax());
+    unsigned* feats_amax = net.new_amax();
+    ASR_TRY(implicit_aggregate(ctx, points, normals, n, net, feats_amax));
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
     const i64 P = ctx->sizes.num_agg_pairs;
@@ -1447,9 +1454,6 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     float* f10 = buf(g[4].v, c_enc[4]);
     if (!f2 || !f10) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
 
-    // f16x2: every activation buffer has a running maximum, kept by the convolutions that write it (a concat buffer
-    // by both of its producers) and read by the ones that consume it; feats1 comes from the continuous conv: one pass
-    ASR_TRY(net.begin_amax());
     unsigned* cat_amax[4] = {nullptr, net.new_amax(), net.new_amax(), net.new_amax()};
     Feat enc_out[5];
     enc_out[0] = Feat{f2, c_enc[0], c_enc[0], net.new_amax()};
@@ -1463,8 +1467,7 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
         if (!feats1_in) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         ASR_TRY(asr_conv16_convert(ctx, feats1, V0 * (i64)C0, feats1_in, 1));
     }
-    Feat f_in{feats1_in, C0, C0, net.new_amax()};
-    if (f_in.amax) ASR_TRY(asr_conv16_absmax(ctx, feats1_in, V0, C0, C0, f_in.amax));
+    Feat f_in{feats1_in, C0, C0, feats_amax};
     ASR_TRY(net.block("sparseconv_encblock0", f_in, g[0], imp_pairs, true, enc_out[0], &imp));
     for (int i = 1; i <= 4; ++i) {
         std::string dn = "sparseconv_down" + std::to_string(i < 4 ? i : 3);

@@ -452,7 +452,8 @@ int asr_conv_agg_importance(asr_hip_context* ctx, const float* compat, const flo
 int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_pos,
                    const float* extents, const float* inp_pos, const float* inp_feat,
                    const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
-                   int cout, int normalize, const float* bias, int relu, float* out, int sorted4 = 0);
+                   int cout, int normalize, const float* bias, int relu, float* out, int sorted4 = 0,
+                   unsigned* out_absmax = nullptr);  // != null: max(its value, f32 bits of the largest |out|), kept by the kernels
 int asr_conv_cconv_basis(asr_hip_context* ctx, const float* out_pos, const float* extents, const float* inp_pos,
                          const float* inp_feat, const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out,
                          float* basis_out, float* norm_out);

@@ -299,9 +299,12 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
         const float4* __restrict__ rec, const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
         const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
         const i64* __restrict__ rs, i64 num_out, int cout, int normalize, const float* __restrict__ bias, int relu,
-        float* __restrict__ out, i64 heavy_rows, float* __restrict__ basis_out, float* __restrict__ norm_out) {
+        float* __restrict__ out, i64 heavy_rows, float* __restrict__ basis_out, float* __restrict__ norm_out,
+        unsigned* __restrict__ out_absmax) {
     // basis_out != null ("next" row f4, filter gradient): only the per-voxel matrices B[v][256] and the importance sums
     // are written; the contraction happens in the caller (dW = B^T g)
+    // out_absmax != null: the running maximum of |out| for the f16x2 sparse conv that reads it (one atomic per wave)
+    unsigned amax = 0;
     __shared__ __attribute__((aligned(16))) float s_bt[8][CCG][CCG_LD];
     __shared__ __attribute__((aligned(16))) float4 s_pair[8][CC_PAIR_LD];
     __shared__ float s_norm[8][CCG];
@@ -456,7 +459,10 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
                     if (normalize && norm != 0.f) v = v / norm;
                     v += bias_o[T];
                     if (relu) v = fmaxf(v, 0.f);
-                    if (o < cout) out[q * cout + o] = v;
+                    if (o < cout) {
+                        out[q * cout + o] = v;
+                        amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();  // the group matrix is re-used by the next group
@@ -559,6 +565,11 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
             stage_c(cc, voxc, lposc, wc, Pc, Fc);
         }
     }
+    if (out_absmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+        if (lane == 0 && amax > __hip_atomic_load(out_absmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_absmax, amax);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -568,6 +579,14 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
 // combined through LDS in wave order (deterministic), wave 0 does the contraction.
 // ------------------------------------------------------------------------------------------
 constexpr i64 CCONV_HEAVY = 256;
+__global__ void k_cconv_absmax(const float* __restrict__ x, i64 n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (i64 e = blockIdx.x * (i64)blockDim.x + threadIdx.x; e < n; e += (i64)gridDim.x * blockDim.x)
+        m = max(m, __float_as_uint(x[e]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 __global__ void k_cconv_heavy_list(const i64* rs, i64 num_out, i64 thr, int32_t* list, int* count) {
     i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (q >= num_out) return;
@@ -581,7 +600,8 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
         const float* __restrict__ inp_feat, const int32_t* __restrict__ nidx,
         const float* __restrict__ nimp, const i64* __restrict__ rs, const int32_t* __restrict__ list,
         const int* __restrict__ list_count, int cin, int cout, int normalize, const float* __restrict__ bias,
-        int relu, float* __restrict__ out) {
+        int relu, float* __restrict__ out, unsigned* __restrict__ out_absmax) {
+    unsigned amax = 0;  // (wave 0 writes the rows)
     __shared__ float s_part[16][64][4];
     __shared__ float s_norm[16];
     __shared__ __attribute__((aligned(16))) float4 s_pair[16][128];
@@ -666,7 +686,13 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
             if (bias) r += bias[lane];
             if (relu) r = fmaxf(r, 0.f);
             out[q * cout + lane] = r;
+            amax = max(amax, __float_as_uint(r) & 0x7fffffffu);
         }
+    }
+    if (out_absmax && wave == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+        if (lane == 0 && amax) atomicMax(out_absmax, amax);
     }
 }
 
@@ -1213,7 +1239,7 @@ int asr_conv_agg_importance(asr_hip_context* ctx, const float* compat, const flo
 int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_pos,
                    const float* extents, const float* inp_pos, const float* inp_feat,
                    const int32_t* nidx, const float* nimp, const i64* rs, i64 num_out, int cin,
-                   int cout, int normalize, const float* bias, int relu, float* out, int sorted4) {
+                   int cout, int normalize, const float* bias, int relu, float* out, int sorted4, unsigned* out_absmax) {
     if (num_out <= 0) return ASR_HIP_OK;
     if (sorted4 && cin != 4) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: the Morton-ordered layout needs cin == 4");
     if (cout < 1 || cout > 64) ASR_FAIL(ctx, ASR_HIP_EINVAL, "continuous_conv: cout must be 1..64");
@@ -1222,6 +1248,7 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     // dependent row_splits -> index -> position load chain of every voxel
     unsigned blocks = grid_for(num_out * 64, 1024);
     if (blocks > 256 * 2) blocks = 256 * 2;  // persistent: the filter slice is staged once per block
+    const bool mfma_path = cin == 4 && cout <= 32 && !ctx->opt.cconv_valu;  // (these kernels keep out_absmax themselves)
     // long rows: collect, then one 1024-thread block per row
     int32_t* heavy = arena_alloc<int32_t>(ctx->scratch, (size_t)num_out);
     int* d_count = arena_alloc<int>(ctx->scratch, 4);
@@ -1242,22 +1269,22 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
 #define ASR_LAUNCH_CCONV_HEAVY_S(C_, S_)                                                                  \
     k_cconv_heavy<C_, S_><<<512, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, \
                                                          nimp, rs, heavy, d_count, cin, cout, normalize,   \
-                                                         bias, relu, out);
+                                                         bias, relu, out, mfma_path ? out_absmax : nullptr);
 #define ASR_LAUNCH_CCONV_HEAVY(C_)        \
     if (sorted4)                          \
         ASR_LAUNCH_CCONV_HEAVY_S(C_, true) \
     else                                  \
         ASR_LAUNCH_CCONV_HEAVY_S(C_, false)
-    if (cin == 4 && cout <= 32 && !ctx->opt.cconv_valu) {
+    if (mfma_path) {
         // contraction on the matrix cores: one persistent 8-wave block per CU (152 KB of LDS)
         if (sorted4)
             k_cconv_mfma<true><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, (const float4*)inp_pos, nullptr,
                                                              nullptr, nidx, nimp, rs, num_out, cout, normalize, bias,
-                                                             relu, out, CCONV_HEAVY, nullptr, nullptr);
+                                                             relu, out, CCONV_HEAVY, nullptr, nullptr, out_absmax);
         else
             k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, nullptr, inp_pos, inp_feat,
                                                               nidx, nimp, rs, num_out, cout, normalize, bias, relu,
-                                                              out, CCONV_HEAVY, nullptr, nullptr);
+                                                              out, CCONV_HEAVY, nullptr, nullptr, out_absmax);
     } else if (cout <= 8)
         ASR_LAUNCH_CCONV(8)
     else if (cout <= 32)
@@ -1276,6 +1303,11 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
 #undef ASR_LAUNCH_CCONV_S
 #undef ASR_LAUNCH_CCONV_HEAVY_S
     ASR_CHECK_LAUNCH(ctx);
+    if (out_absmax && !mfma_path) {  // the general kernels do not keep it: one pass over the output
+        k_cconv_absmax<<<(unsigned)std::min<i64>((num_out * cout + 255) / 256, 8192), 256, 0, ctx->stream>>>(out, num_out * (i64)cout,
+                                                                                                           out_absmax);
+        ASR_CHECK_LAUNCH(ctx);
+    }
     return ASR_HIP_OK;
 }
 
@@ -1289,7 +1321,7 @@ int asr_conv_cconv_basis(asr_hip_context* ctx, const float* out_pos, const float
     ASR_TRY(asr_ctx_zeros(ctx, &zeros));  // stands in for the (unused) filter matrix
     k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(zeros, out_pos, extents, nullptr, inp_pos, inp_feat, nidx, nimp,
                                                       rs, num_out, 0, 0, nullptr, 0, nullptr,
-                                                      (i64)0x7fffffff, basis_out, norm_out);
+                                                      (i64)0x7fffffff, basis_out, norm_out, nullptr);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }

@@ -697,6 +697,211 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
 }
 
 // ------------------------------------------------------------------------------------------
+// Long rows of the whole-path layout (cin == 4), cut into segments.  At 10 M points 135 rows are long and 60 of them hold
+// 35 000 pairs on average (a coarse voxel beside the surface): one block per ROW walked such a row for 0.18 ms on an otherwise
+// idle chip.  Here a work item is (row, segment of CCH_SEG pairs); its block leaves the 64 x 4 cell sums + the importance sum of
+// the segment in a partial slot and k_cconv_heavy4_finish adds a row's segments IN ORDER and contracts; a row of one segment
+// is finished by its block.  k_cconv_heavy4_items lays the items out on the device (the number of long rows never reaches
+// the host): item_first[li] = first item of long row li, part_first[li] = its first partial slot, or -1 for a row of one
+// item -- also rows whose segments would not fit the CCH_CAP slots, which then stay one item.
+// ------------------------------------------------------------------------------------------
+constexpr int CCH_SEG = 4096;
+constexpr int CCH_CAP = 16384;  // partial slots of 260 floats
+constexpr int CCH_LD = 260;
+
+__global__ __launch_bounds__(1024) void k_cconv_heavy4_items(const i64* __restrict__ rs, const int32_t* __restrict__ list,
+                                                             int* __restrict__ cnt, int* __restrict__ item_first,
+                                                             int* __restrict__ part_first) {
+    __shared__ int s_a[1024], s_b[1024];
+    __shared__ int s_carry[2];
+    const int n = cnt[0], t = threadIdx.x;
+    if (t == 0) s_carry[0] = s_carry[1] = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int li = base + t;
+        int seg = 0;
+        if (li < n) {
+            const i64 q = list[li];
+            seg = (int)((rs[q + 1] - rs[q] + CCH_SEG - 1) / CCH_SEG);
+        }
+        const int multi = seg > 1 ? seg : 0;
+        // inclusive scans of the partial slots, then (with the rows that do not fit kept whole) of the items
+        s_a[t] = multi;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int x = t >= o ? s_a[t - o] : 0;
+            __syncthreads();
+            s_a[t] += x;
+            __syncthreads();
+        }
+        const int pf = s_carry[0] + s_a[t] - multi;
+        const bool cut = multi && pf + multi <= CCH_CAP;
+        const int items = li < n ? (cut ? seg : 1) : 0;
+        s_b[t] = items;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int x = t >= o ? s_b[t - o] : 0;
+            __syncthreads();
+            s_b[t] += x;
+            __syncthreads();
+        }
+        if (li < n) {
+            item_first[li] = s_carry[1] + s_b[t] - items;
+            part_first[li] = cut ? pf : -1;
+        }
+        __syncthreads();
+        if (t == 1023) {
+            s_carry[0] += s_a[1023];
+            s_carry[1] += s_b[1023];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        item_first[n] = s_carry[1];
+        cnt[1] = s_carry[1];
+    }
+}
+
+// contraction of one row's cell sums (lane = cell: B0..B3 its four channels) with the filter, epilogue, store; every lane of the
+// wave takes part.  Returns the f32 bits of the largest |value| written (for out_absmax).
+template <int COUT_MAX>
+__device__ inline unsigned cconv_heavy4_finish_row(const float* __restrict__ filters, float B0, float B1, float B2, float B3,
+                                                   float norm_total, int cout, int normalize, const float* __restrict__ bias,
+                                                   int relu, float* __restrict__ orow, int lane) {
+    const float* wrow = filters + (i64)lane * 4 * cout;
+    float mine = 0.f;
+#pragma unroll
+    for (int o = 0; o < COUT_MAX; ++o) {
+        if (o < cout) {
+            float a = wrow[o] * B0;
+            a += wrow[cout + o] * B1;
+            a += wrow[2 * cout + o] * B2;
+            a += wrow[3 * cout + o] * B3;
+            const float t = wave_reduce_sum(a);
+            if (lane == o) mine = t;
+        }
+    }
+    unsigned amax = 0;
+    if (lane < cout) {
+        float r = mine;
+        if (normalize && norm_total != 0.f) r = r / norm_total;
+        if (bias) r += bias[lane];
+        if (relu) r = fmaxf(r, 0.f);
+        orow[lane] = r;
+        amax = __float_as_uint(r) & 0x7fffffffu;
+    }
+    return amax;
+}
+
+template <int COUT_MAX, bool SORTED>
+__global__ __launch_bounds__(1024) void k_cconv_heavy4(
+        const float* __restrict__ filters, const float* __restrict__ out_pos, const float* __restrict__ extents,
+        const float* __restrict__ inp_pos, const float* __restrict__ inp_feat, const int32_t* __restrict__ nidx,
+        const float* __restrict__ nimp, const i64* __restrict__ rs, const int32_t* __restrict__ list,
+        const int* __restrict__ cnt, const int* __restrict__ item_first, const int* __restrict__ part_first, int cout,
+        int normalize, const float* __restrict__ bias, int relu, float* __restrict__ out, float* __restrict__ part,
+        unsigned* __restrict__ out_absmax) {
+    __shared__ float s_part[16][64][4];
+    __shared__ float s_norm[16];
+    __shared__ __attribute__((aligned(16))) float4 s_pair[16][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_list = cnt[0], n_items = cnt[1];
+    unsigned amax = 0;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        __syncthreads();  // the previous item's LDS partials are consumed
+        int lo = 0, hi = n_list;  // long row li with item_first[li] <= item < item_first[li + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (item_first[mid] <= item)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int li = lo, seg = item - item_first[li], pf = part_first[li];
+        const i64 q = list[li];
+        i64 b = rs[q], e = rs[q + 1];
+        if (pf >= 0) {
+            b += (i64)seg * CCH_SEG;
+            e = e < b + CCH_SEG ? e : b + CCH_SEG;
+        }
+        const float ox = out_pos[3 * q], oy = out_pos[3 * q + 1], oz = out_pos[3 * q + 2];
+        const float sc2 = 2.f * (1.f / extents[q]);
+        f32x4 D = {0.f, 0.f, 0.f, 0.f};
+        float norm_lane = 0.f;
+        for (i64 p0 = b + 64 * (i64)wave; p0 < e; p0 += 64 * 16) {
+            const int c = (int)((e - p0) < 64 ? (e - p0) : 64);
+            cconv_batch_mma<SORTED>(inp_pos, inp_feat, nidx, nimp, p0, c, lane, ox, oy, oz, sc2, D, norm_lane, s_pair[wave]);
+        }
+        const float norm = wave_sum_dpp(norm_lane);
+        {  // D[r] = basis element k = 16 (4 g + r) + n = 4 cell + channel
+            float* flat = &s_part[wave][0][0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) flat[16 * (4 * (lane >> 4) + r) + (lane & 15)] = D[r];
+        }
+        if (lane == 0) s_norm[wave] = norm;
+        __syncthreads();
+        if (wave != 0) continue;
+        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, nt = 0.f;
+        for (int w2 = 0; w2 < 16; ++w2) {  // wave order: deterministic
+            B0 += s_part[w2][lane][0];
+            B1 += s_part[w2][lane][1];
+            B2 += s_part[w2][lane][2];
+            B3 += s_part[w2][lane][3];
+            nt += s_norm[w2];
+        }
+        if (pf >= 0) {  // one segment of several: the partial slot
+            float* ps = part + (i64)(pf + seg) * CCH_LD;
+            *reinterpret_cast<float4*>(ps + 4 * lane) = make_float4(B0, B1, B2, B3);
+            if (lane == 0) ps[256] = nt;
+        } else {
+            amax = max(amax, cconv_heavy4_finish_row<COUT_MAX>(filters, B0, B1, B2, B3, nt, cout, normalize, bias, relu,
+                                                               out + q * cout, lane));
+        }
+    }
+    if (out_absmax && wave == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+        if (lane == 0 && amax) atomicMax(out_absmax, amax);
+    }
+}
+
+// the rows of several segments: one wave per long row, segments added in order
+template <int COUT_MAX>
+__global__ __launch_bounds__(256) void k_cconv_heavy4_finish(const float* __restrict__ filters, const i64* __restrict__ rs,
+                                                             const int32_t* __restrict__ list, const int* __restrict__ cnt,
+                                                             const int* __restrict__ item_first,
+                                                             const int* __restrict__ part_first, int cout, int normalize,
+                                                             const float* __restrict__ bias, int relu, float* __restrict__ out,
+                                                             const float* __restrict__ part, unsigned* __restrict__ out_absmax) {
+    const int lane = threadIdx.x & 63;
+    const int n_list = cnt[0];
+    unsigned amax = 0;
+    for (int li = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); li < n_list; li += (int)((gridDim.x * blockDim.x) >> 6)) {
+        const int pf = part_first[li];
+        if (pf < 0) continue;  // (wave uniform) finished by its one block
+        const int nseg = item_first[li + 1] - item_first[li];
+        float B0 = 0.f, B1 = 0.f, B2 = 0.f, B3 = 0.f, nt = 0.f;
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            const float* ps = part + (i64)(pf + sgm) * CCH_LD;
+            const float4 v = *reinterpret_cast<const float4*>(ps + 4 * lane);
+            B0 += v.x;
+            B1 += v.y;
+            B2 += v.z;
+            B3 += v.w;
+            nt += ps[256];
+        }
+        const i64 q = list[li];
+        amax = max(amax, cconv_heavy4_finish_row<COUT_MAX>(filters, B0, B1, B2, B3, nt, cout, normalize, bias, relu,
+                                                           out + q * cout, lane));
+    }
+    if (out_absmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+        if (lane == 0 && amax) atomicMax(out_absmax, amax);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // a12 scalar reference kernel: one thread per (row, out channel).  Any cin / cout / strides.
 // Used for shapes the MFMA kernel does not take and as an in-library cross-check (algo=1).
 // ------------------------------------------------------------------------------------------
@@ -1292,7 +1497,25 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     else
         ASR_LAUNCH_CCONV(64)
     ASR_CHECK_LAUNCH(ctx);
-    if (cout <= 8)
+    if (mfma_path) {  // long rows cut into segments (k_cconv_heavy4)
+        int* item_first = arena_alloc<int>(ctx->scratch, (size_t)num_out + 2);
+        int* part_first = arena_alloc<int>(ctx->scratch, (size_t)num_out + 2);
+        float* part = arena_alloc<float>(ctx->scratch, (size_t)CCH_CAP * CCH_LD);
+        if (!item_first || !part_first || !part) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+        k_cconv_heavy4_items<<<1, 1024, 0, ctx->stream>>>(rs, heavy, d_count, item_first, part_first);
+        ASR_CHECK_LAUNCH(ctx);
+        if (sorted4)
+            k_cconv_heavy4<32, true><<<1024, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs,
+                                                                    heavy, d_count, item_first, part_first, cout, normalize,
+                                                                    bias, relu, out, part, out_absmax);
+        else
+            k_cconv_heavy4<32, false><<<1024, 1024, 0, ctx->stream>>>(filters, out_pos, extents, inp_pos, inp_feat, nidx, nimp, rs,
+                                                                     heavy, d_count, item_first, part_first, cout, normalize,
+                                                                     bias, relu, out, part, out_absmax);
+        ASR_CHECK_LAUNCH(ctx);
+        k_cconv_heavy4_finish<32><<<64, 256, 0, ctx->stream>>>(filters, rs, heavy, d_count, item_first, part_first, cout, normalize,
+                                                               bias, relu, out, part, out_absmax);
+    } else if (cout <= 8)
         ASR_LAUNCH_CCONV_HEAVY(8)
     else if (cout <= 32)
         ASR_LAUNCH_CCONV_HEAVY(32)

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
         const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
         const i64* __restrict__ rs, i64 num_out, int cout, int normalize, const float* __restrict__ bias, int relu,
         float* __restrict__ out, i64 heavy_rows, float* __restrict__ basis_out, float* __restrict__ norm_out,
-        unsigned* __restrict__ out_absmax) {
+        unsigned* __restrict__ out_absmax, int* __restrict__ sg_counter) {
     // basis_out != null ("next" row f4, filter gradient): only the per-voxel matrices B[v][256] and the importance sums
     // are written; the contraction happens in the caller (dW = B^T g)
     // out_absmax != null: the running maximum of |out| for the f16x2 sparse conv that reads it (one atomic per wave)
@@ -335,10 +335,20 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
 
     float4* const sp4 = &s_pair[wib][0];
     const float* const sp = reinterpret_cast<const float*>(sp4);
+    // Super-groups are handed out by an atomic counter (zeroed by the launcher): with the static round robin the slowest of the
+    // 2 048 waves carried 1.13-1.27 x the mean number of pairs (scripts/cconv_balance.py) and set the kernel's time.  The
+    // next ticket is drawn while the current super-group is processed.
     const i64 sgroups = (num_out + CCS - 1) / CCS;
-    const i64 wave0 = (i64)blockIdx.x * (blockDim.x >> 6) + wib;
-    const i64 nwaves = (i64)gridDim.x * (blockDim.x >> 6);
-    for (i64 sg = wave0; sg < sgroups; sg += nwaves) {
+    auto draw = [&]() __attribute__((always_inline)) -> int {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(sg_counter, 1);
+        return t;
+    };
+    int ticket = draw();
+    for (;;) {
+        const i64 sg = __builtin_amdgcn_readfirstlane(ticket);
+        if (sg >= sgroups) break;
+        ticket = draw();
         const i64 q0 = sg * CCS;
         const int nvox = (int)(num_out - q0 < CCS ? num_out - q0 : CCS);
         // lane u: voxel u of the super-group.  mcnt = pairs this kernel accumulates (0 for a row of k_cconv_heavy)
@@ -1458,7 +1468,7 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     int32_t* heavy = arena_alloc<int32_t>(ctx->scratch, (size_t)num_out);
     int* d_count = arena_alloc<int>(ctx->scratch, 4);
     if (!heavy || !d_count) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
-    ASR_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(d_count, 0, 4 * sizeof(int), ctx->stream));  // [0] long rows, [1] their items, [2] tickets
     k_cconv_heavy_list<<<grid_for(num_out, 256), 256, 0, ctx->stream>>>(rs, num_out, CCONV_HEAVY, heavy,
                                                                       d_count);
     ASR_CHECK_LAUNCH(ctx);
@@ -1485,11 +1495,11 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
         if (sorted4)
             k_cconv_mfma<true><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, (const float4*)inp_pos, nullptr,
                                                              nullptr, nidx, nimp, rs, num_out, cout, normalize, bias,
-                                                             relu, out, CCONV_HEAVY, nullptr, nullptr, out_absmax);
+                                                             relu, out, CCONV_HEAVY, nullptr, nullptr, out_absmax, d_count + 2);
         else
             k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, nullptr, inp_pos, inp_feat,
                                                               nidx, nimp, rs, num_out, cout, normalize, bias, relu,
-                                                              out, CCONV_HEAVY, nullptr, nullptr, out_absmax);
+                                                              out, CCONV_HEAVY, nullptr, nullptr, out_absmax, d_count + 2);
     } else if (cout <= 8)
         ASR_LAUNCH_CCONV(8)
     else if (cout <= 32)
@@ -1542,9 +1552,12 @@ int asr_conv_cconv_basis(asr_hip_context* ctx, const float* out_pos, const float
     if (num_out <= 0) return ASR_HIP_OK;
     const float* zeros = nullptr;
     ASR_TRY(asr_ctx_zeros(ctx, &zeros));  // stands in for the (unused) filter matrix
+    int* tickets = arena_alloc<int>(ctx->scratch, 4);
+    if (!tickets) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
+    ASR_HIP_CHECK(ctx, hipMemsetAsync(tickets, 0, 4 * sizeof(int), ctx->stream));
     k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(zeros, out_pos, extents, nullptr, inp_pos, inp_feat, nidx, nimp,
                                                       rs, num_out, 0, 0, nullptr, 0, nullptr,
-                                                      (i64)0x7fffffff, basis_out, norm_out, nullptr);
+                                                      (i64)0x7fffffff, basis_out, norm_out, nullptr, tickets);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }

@@ -1142,7 +1142,8 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         ASR_HIP_CHECK(ctx, hipEventRecord(ctx->aux_t0, sc->stream));  // the search is timed on ITS stream
         // The search's point sort needs nothing from the octree (it sorts deep enough for any realistic leaf level,
         // PRESORT_LEVEL): enqueued on the auxiliary stream now, it runs beside the octree construction.
-        if (ctx->opt.early_sort) ASR_TRY(asr_geom_presort(sc, sc->persist, &ctx->frame, points, radii, n));
+        // (the sort itself is enqueued by the search thread below: it reads one number back first -- the finest level a point
+        // can be inserted on, which sets the depth of the sort -- and this thread goes on to the octree meanwhile)
     }
     // The search thread starts here: first the cell table of the sorted points (host round trips of its own, beside
     // the octree construction on this thread), then it waits for the level-0 voxels.
@@ -1177,7 +1178,10 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
                 return;
             }
             int rc = ASR_HIP_OK;
-            if (ctx->opt.early_sort && ctx->opt.early_cells && sc->pindex.valid) rc = asr_geom_precells(sc, sc->persist);
+            if (ctx->opt.early_sort)
+                rc = asr_geom_presort(sc, sc->persist, &ctx->frame, points, radii, n, prm->point_radius_scale, prm->octree_max_depth);
+            if (rc == ASR_HIP_OK && ctx->opt.early_sort && ctx->opt.early_cells && sc->pindex.valid)
+                rc = asr_geom_precells(sc, sc->persist);
             const bool go = level0_future.get();
             if (rc != ASR_HIP_OK || !go) {
                 search_rc = rc;

@@ -367,7 +367,7 @@ int asr_geom_octree_build(asr_hip_context* ctx, const asr_octree_frame* frame, c
 int asr_geom_precells(asr_hip_context* ctx, Arena& keep);
 // Morton order of the points (+ radii) into ctx->pindex, arrays in `keep`
 int asr_geom_presort(asr_hip_context* ctx, Arena& keep, const asr_octree_frame* frame, const float* pts,
-                     const float* radii, i64 n);
+                     const float* radii, i64 n, float radius_scale = 0.f, int max_depth = 21);
 int asr_geom_neighbors_count(asr_hip_context* ctx, const u64* keys, i64 v, i64* rs, i64* num_pairs);
 int asr_geom_neighbors_fill(asr_hip_context* ctx, const u64* keys, i64 v, const i64* rs,
                             int32_t* idx, uint8_t* kidx);

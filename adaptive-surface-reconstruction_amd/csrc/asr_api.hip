@@ -1036,6 +1036,7 @@ int build_begin(asr_hip_context* ctx, i64 n, const asr_implicit_params* prm) {
     ctx->agg_nq = 0;
     ctx->agg_qcenters = ctx->agg_qsizes = nullptr;
     ctx->has_search = false;
+    ctx->build_sharded = false;
     ctx->build_mark_ok = false;
     ctx->conv_plans.clear();
     memset(&ctx->sizes, 0, sizeof(ctx->sizes));
@@ -1337,6 +1338,7 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
         *st_out = st;
         shard_guard.keep = true;
     }
+    ctx->build_sharded = st && asr_shard_world(st) > 1;
     return ASR_HIP_OK;
 }
 
@@ -1560,6 +1562,9 @@ int asr_hip_implicit_network(asr_hip_context* ctx, const float* points, const fl
     CTX_GUARD(ctx);
     if (!points || !normals || n <= 0 || !weights || !prm)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: null argument");
+    if (ctx->build_sharded)  // (the sharded forward calls the internal function with ctx->shard set)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_network: the last build was one rank's build of a sharded cloud (partial neighbour "
+                                      "lists, plans and aggregation rows): run asr_hip_implicit_build again");
     return implicit_network(ctx, points, normals, n, weights, num_weights, prm, values_out);
 }
 int asr_hip_implicit_aggregate(asr_hip_context* ctx, const float* points, const float* normals, int64_t n,
@@ -1567,6 +1572,9 @@ int asr_hip_implicit_aggregate(asr_hip_context* ctx, const float* points, const 
     CTX_GUARD(ctx);
     if (!points || !normals || n <= 0 || !weights || !prm)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_aggregate: null argument");
+    if (ctx->build_sharded)
+        ASR_FAIL(ctx, ASR_HIP_EINVAL, "implicit_aggregate: the last build was one rank's build of a sharded cloud (the "
+                                      "aggregation rows of the owned voxels only): run asr_hip_implicit_build again");
     ASR_TRY(ensure_events(ctx));
     Net net{ctx, {weights, num_weights}};
     net.precision = prm->precision;

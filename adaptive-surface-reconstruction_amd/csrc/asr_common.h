@@ -196,6 +196,9 @@ struct asr_hip_context {
     int32_t* agg_spos = nullptr;         // neighbour of each aggregation pair as a position in Morton order
     const float4* agg_sorted = nullptr;  // points in Morton order (x, y, z, original index bits)
     bool has_search = false;             // the last implicit_build ran the aggregation search
+    // the last implicit_build was ONE RANK's build of a sharded cloud (asr_hip_implicit_forward_sharded, option shard_geometry):
+    // 55-slot lists, plans and the aggregation CSR hold the owned rows only -- the stand-alone network entry points refuse it
+    bool build_sharded = false;
     // sharded geometry: the search covered agg_nq (> 0) rows of grid 0 only -- agg_rows lists them, the CSR above and
     // the query centres / sizes below are compact over that list
     const int32_t* agg_rows = nullptr;

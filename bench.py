@@ -447,8 +447,10 @@ def pipelined_rate(pipe, weights, dev, inputs, n, steps, depth=2):
 def one_scan_line(args, world, n, dt, sharded, extra):
     """bench line of the one-scan mode: ONE cloud over all ranks, total work fixed ("strong")"""
     steps = max(args.steps, 1)
-    how = ("inside the library (asr_hip_implicit_forward_sharded): geometry + aggregation replicated, 53 sparse convs on owned "
-           "rows with one packed RCCL send/recv group per convolution on the library's stream, decoder, values all-gathered"
+    how = ("inside the library (asr_hip_implicit_forward_sharded, option shard_geometry = default): octree, voxel keys and "
+           "up / down lists of the whole cloud on every rank; 55-slot neighbour lists, plans, aggregation search, continuous "
+           "conv, 53 sparse convs and decoder on the owned rows only, one packed RCCL send/recv group per convolution on the "
+           "library's stream, values all-gathered"
            if sharded.native else
            "Python reference driver (asr_hip/sharding.py): octree + grids replicated (from 4 ranks on: neighbour lists, "
            "tiling orders and aggregation for the owned voxels only), 53 sparse convs + decoder on owned rows, halo exchange "

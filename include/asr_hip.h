@@ -459,8 +459,14 @@ int asr_hip_implicit_forward(asr_hip_context* ctx, const float* points_dev,
  * stencil of its operators: one face ring per 55-slot convolution on the same / child / parent level
  * (cpp/lib/grid.cpp:99-170) and parent <-> children for the transitions (cpp/lib/grid.cpp:206-242).
  *
- * asr_hip_implicit_forward_sharded: every rank holds the whole cloud and builds the geometry + the aggregation stage of
- * the whole cloud (replicated); the 53 sparse convolutions and the decoder run on the rows the rank OWNS (grid-0 voxels
+ * asr_hip_implicit_forward_sharded: every rank holds the whole cloud.  Option "shard_geometry" (default -1 = 1 whenever
+ * world > 1): 1 = octree, voxel keys and the one-entry-per-voxel up / down lists of the whole cloud on every rank (the
+ * integer work ownership is derived from), 55-slot neighbour lists, row-group plans, aggregation search and continuous
+ * conv for the voxels the rank owns only; 0 = geometry + aggregation of the whole cloud on every rank (replicated).
+ * After a forward with per-rank geometry the context holds a PARTIAL build ("neighbors_*", "aggregation_*" of
+ * asr_hip_implicit_get list the owned rows, sizes.num_pairs / num_agg_pairs are the rank's): asr_hip_implicit_network
+ * and asr_hip_implicit_aggregate refuse it (ASR_HIP_EINVAL) until the next asr_hip_implicit_build.
+ * The 53 sparse convolutions and the decoder run on the rows the rank OWNS (grid-0 voxels
  * cut into `world` contiguous ranges of their level-21 Morton order with equal pair counts, a coarser voxel belongs to
  * the owner of its first child), with one point-to-point exchange of the boundary rows of the input buffer (+ the
  * importance of those rows) before each convolution -- grouped with the MAX all-reduce of the f16x2 running maximum of that

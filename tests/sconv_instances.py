@@ -15,8 +15,8 @@ BENCH_INSTANCES = {
 }
 
 
-# 16-bit kernel instances of the default bench (f16x2 arithmetic since round 3; bf16x3 before -- the launcher picks the
-# same tiles for both): (NT, KC, IMP, WAVES, DUAL, MODE, PLAN) as the library's launch counters report them (template
+# 16-bit kernel instances of the default bench (bf16x3 arithmetic since round 5; f16x2 in rounds 3-4 and as a sub-record
+# now -- the launcher picks the same tiles for both): (NT, KC, IMP, WAVES, DUAL, MODE, PLAN) as the library's launch counters report them (template
 # order is <NT, KC, WAVES, MODE, IMP, DUAL>; MODE 2 = bf16x3, 3 = f16x2; PLAN 1 = k_sconv_plan16, 0 = k_sconv_mfma16)
 BENCH_SHAPES16 = {
     (4, 32, 0, 8, 1), (4, 32, 0, 8, 0), (8, 32, 0, 8, 1), (8, 32, 0, 8, 0),
@@ -33,7 +33,7 @@ def bench_instances16(mode):
     return {s + (MODE_ID[mode], 1) for s in BENCH_SHAPES16} | {s + (MODE_ID[mode], 1, 1) for s in BENCH_SPLIT16}
 
 
-BENCH_INSTANCES16 = bench_instances16("f16x2")  # what `python bench.py` launches
+BENCH_INSTANCES16 = bench_instances16("bf16x3")  # what `python bench.py` launches
 
 
 def instances16_in_trace(path):

@@ -232,3 +232,38 @@ def test_library_sharded_forward_world_one_over_rccl(gpu, precision):
     assert torch.equal(full, single)
     assert pipe.shard_stats["exchanges"] == 0 and pipe.shard_stats["owned_rows"][0] == single.shape[0]
     comm.close()
+
+
+def test_partial_build_of_a_sharded_forward_is_refused_by_the_standalone_entry_points(gpu):
+    """After a sharded forward with per-rank geometry the context holds ONE RANK's neighbour lists, plans and aggregation
+    rows; asr_hip_implicit_network / asr_hip_implicit_aggregate on that context would silently compute wrong values --
+    they must fail until the next asr_hip_implicit_build (round-4 advisor finding).  One process plays rank 0 of a
+    world of two with a transport that moves nothing (the halo rows keep stale values: only the refusal is checked)."""
+    import ctypes
+    sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd")]
+    from asr_hip import _lib, synth
+    from asr_hip._lib import AsrHipError
+    from asr_hip.pipeline import ImplicitPipeline
+    dev = torch.device("cuda:0")
+    pts, nrm = synth.scan_cloud(6000, seed=5, device=dev)
+    rad = synth.knn_radii_gpu(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    pipe = ImplicitPipeline(synth.make_weights(4, seed=1), device=dev, precision="bf16x3")
+    ex = _lib.SHARD_EXCHANGE_FN(lambda *a: 0)
+    ar = _lib.SHARD_ALLREDUCE_FN(lambda *a: 0)
+    comm = _lib.ShardComm(None, 0, 2, ex, ar, _lib.SHARD_EXCHANGE_MAX_FN())
+
+    class C:
+        def handle(self):
+            return ctypes.byref(comm)
+
+    pipe.forward_sharded(C(), pts, nrm, rad, bb[0], bb[1])
+    with pytest.raises(AsrHipError, match="sharded"):
+        pipe.network(pts, nrm, bb[0], bb[1])
+    with pytest.raises(AsrHipError, match="sharded"):
+        pipe.aggregate(pts, nrm, bb[0], bb[1])
+    # a fresh build clears the flag
+    pipe.build(pts, rad, bb[0], bb[1])
+    v = pipe.network(pts, nrm, bb[0], bb[1])
+    ref = ImplicitPipeline(synth.make_weights(4, seed=1), device=dev, precision="bf16x3").forward(pts, nrm, rad, bb[0], bb[1])
+    assert torch.equal(v, ref)

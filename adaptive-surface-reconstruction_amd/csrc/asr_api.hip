@@ -57,6 +57,8 @@ const OptEntry k_options[] = {
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
         {"sconv_split_rows", "ASR_SCONV_SPLIT_ROWS", &AsrOptions::sconv_split_rows},
         {"sconv_split_min_rows", "ASR_SCONV_SPLIT_MIN_ROWS", &AsrOptions::sconv_split_min_rows},
+        {"sconv_ring", "ASR_SCONV_RING", &AsrOptions::sconv_ring},
+        {"sconv_ring_min_rows", "ASR_SCONV_RING_MIN_ROWS", &AsrOptions::sconv_ring_min_rows},
 };
 
 // asr::GetPrintCallbackFunction (cpp/lib/asr.cpp:34-37): one callback per verbosity level, process wide

@@ -120,6 +120,11 @@ struct AsrOptions {
     // tiles, the longest of which runs its 30 slots x cin / 32 steps alone on its CU): the slots are cut into five fixed
     // ranges, every (tile, range) is a block of its own, a second kernel adds the partial sums in range order.  The
     // choice depends on the input grid's size only, so that one rank of a sharded cloud makes the same one.
+    i64 sconv_ring = 0;            // 16-bit sparse conv: 1 = decoupled-wave kernel (k_sconv_ring16) for the plain 128-column-tile layers
+                                   // of grids with at least sconv_ring_min_rows output rows.  Off: measured 1.3 x SLOWER than
+                                   // k_sconv_plan16 on those layers at 10 M points; kept for its tests and as a
+                                   // record of the experiment
+    i64 sconv_ring_min_rows = 100000;
     i64 sconv_split_min_rows = 2048;
     i64 sconv_split_rows = 32768;  // 0: never
 };

@@ -44,6 +44,47 @@ __global__ __launch_bounds__(512) void k_gather(const float* __restrict__ feat, 
     if (acc == 0x12345678u) out[0] = acc;
 }
 
+// MAP 3: the same 16 rows x 128 B per pair of wave instructions, but global -> LDS by DMA (buffer_load ... lds): lane l moves
+// piece l & 7 of row l >> 3 (eight adjacent lanes = one 128-byte line) into LDS slot l; READ: the wave then reads its two
+// 16-byte operand pieces (row l & 15, pieces 2 (l >> 4), + 1) back with ds_read_b128
+template <int DEPTH, bool READ>
+__global__ __launch_bounds__(512) void k_gather_lds(const float* __restrict__ feat, unsigned bytes, const int* __restrict__ idx,
+                                                    int n_idx, int iters, int ld_bytes, unsigned* out) {
+    __shared__ __attribute__((aligned(16))) u32x4 s_a[8 * DEPTH * 128];  // per wave and slot: 16 rows x 8 pieces
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)bytes, 0x00020000);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r8 = lane >> 3, g8 = lane & 7;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    unsigned acc = 0;
+    int pos = (wave_global * 16 + r8) % n_idx;
+    u32x4* base = s_a + wave * DEPTH * 128;
+    auto issue = [&](int d) __attribute__((always_inline)) {
+        const unsigned off = (unsigned)idx[pos] * (unsigned)ld_bytes + 16u * g8;
+        const unsigned off2 = (unsigned)idx[(pos + 8) % n_idx] * (unsigned)ld_bytes + 16u * g8;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)&base[d * 128], 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)&base[d * 128 + 64], 16, (int)off2, 0, 0, 0);
+        pos = (pos + 7919) % n_idx;
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d);
+    const int rr = lane & 15, gg = lane >> 4;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DEPTH - 1)) : "memory");
+            if (READ) {
+                const u32x4 a = base[d * 128 + rr * 8 + ((2 * gg) ^ (rr & 7))];
+                const u32x4 b = base[d * 128 + rr * 8 + ((2 * gg + 1) ^ (rr & 7))];
+                acc += a[0] ^ b[3];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            issue(d);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
     const int ld = 256;  // 64 channels f32
     const size_t rows_max = 2500000;
@@ -64,7 +105,7 @@ int main() {
         srand(1);
         for (int i = 0; i < n_idx; ++i) h[i] = (int)(((size_t)rand() * 32768 + rand()) % rows);
         hipMemcpy(d_idx, h.data(), n_idx * 4, hipMemcpyHostToDevice);
-        for (int map : {0, 1, 2})
+        for (int map : {0, 1, 2, 3, 4})
         for (int blocks_per_cu : {2}) {
             for (int depth : {2}) {
                 const int iters = 2000 / depth;
@@ -73,6 +114,8 @@ int main() {
                     if (map == 0) k_gather<2, 0><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
                     if (map == 1) k_gather<2, 1><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
                     if (map == 2) k_gather<2, 2><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
+                    if (map == 3) k_gather_lds<2, false><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
+                    if (map == 4) k_gather_lds<2, true><<<grid, 512>>>(feat, (unsigned)(rows * ld), d_idx, n_idx, iters, ld, out);
                 };
                 launch();
                 hipDeviceSynchronize();

@@ -30,7 +30,9 @@ pts, nrm = synth.scan_cloud(n, seed=1000, device=dev)
 radii = synth.knn_radii_gpu(pts, 24)
 bb = synth.bounding_box(pts, 0.1)
 w = synth.make_weights(1, seed=0, init="reference")
-pipe = ImplicitPipeline(w, device=dev, precision="f16x2")
+PREC = os.environ.get("ASR_DRY_PRECISION", "bf16x3")
+pipe = ImplicitPipeline(w, device=dev, precision=PREC)
+print("precision", PREC, flush=True)
 
 
 def run(name, f, reps=6):

@@ -77,7 +77,9 @@ int asr_hip_context_weights_changed(asr_hip_context* ctx);
  * on the tuning options; "sconv_dry" is the exception: it skips work and produces garbage, for timing only.
  * "search_half" (1): the aggregation search of asr_hip_implicit_build covers a voxel's ball with 4^3 half-size
  * cells for the rows with many candidates (2: for every voxel, 0: 3^3 full-size cells throughout).  get_option also answers the read-only "last_search_margin_pairs": pairs the last
- * such search found in the rounding margin of the half-size cells. */
+ * such search found in the rounding margin of the half-size cells.
+ * "sconv_ring" (0), "sconv_ring_min_rows" (100000): 1 sends the plain 128-column-tile layers of the 16-bit sparse convs on
+ * grids of at least that many rows to the decoupled-wave kernel (k_sconv_ring16: same bits, measured slower -- DESIGN.md 7.4). */
 int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value);
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value);
 

@@ -12,9 +12,10 @@ BASELINE.json / SURVEY 8(d)) that is already resident in HBM.
 N = 1: the monolithic C++ driver (asr_hip_implicit_forward).
 N > 1 (default --shard auto): BASELINE's metric is "10M-pt cloud, 1/2/4/8 GPU", so the headline is ONE 10 M-point
 scan sharded over the N GPUs by Morton range with halo exchange per convolution over RCCL ("scaling": "strong",
-asr_hip/sharding.py); value = points of that one scan / max-over-ranks time.  The replica mode (one scan per GPU,
-no collective, "weak") is measured in the same run and reported as config.replicas; --shard replicas makes it the
-headline.  Should the sharded path fail on a node, the line falls back to the replica measurement and says so.
+asr_hip_implicit_forward_sharded).  The replica mode (one scan per GPU, no collective, "weak") is measured FIRST in the
+same run and reported as config.replicas; --shard replicas makes it the headline.  The sharded path then runs under a
+watchdog ($ASR_BENCH_ONE_SCAN_TIMEOUT, 420 s): should it fail or not finish on a node, the line falls back to the
+replica measurement and says so.
 """
 import argparse
 import json
@@ -627,33 +628,16 @@ def main():
     if args.precision == "f16" and mode == "one-scan":
         mode = "replicas"  # the sharded network runs the f32-class kernels only
 
-    # ---- ONE scan over all ranks (the headline at N > 1) ------------------------------------------
-    one_scan_out, one_scan_error = None, None
-    if mode == "one-scan":
-        try:
-            one_scan_out = run_one_scan(args, world, rank, dev, weights, n, barrier, synth)
-        except Exception as e:  # the bench must still print a line: fall back to the replica measurement below
-            one_scan_error = "%s: %s" % (type(e).__name__, e)
-            if args.shard == "one-scan":
-                raise
-        if args.shard == "one-scan":
-            if rank == 0:
-                print(json.dumps(one_scan_out))
-            if world > 1:
-                dist.barrier()
-                dist.destroy_process_group()
-            return
-
-    # ---- config C4 (8 GPUs: eight fused scans, 80 M points, sharded): informational sub-record ------
-    c4_out = None
-    if mode == "one-scan" and one_scan_error is None and (world == 8 or os.environ.get("ASR_BENCH_C4")):
-        try:
-            import copy
-            a4 = copy.copy(args)
-            a4.steps, a4.warmup = 1, 1
-            c4_out = run_one_scan(a4, world, rank, dev, weights, n, barrier, synth, fused=world)
-        except Exception as e:
-            c4_out = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- --shard one-scan: the sharded path alone (also at 1 GPU) ----------------------------------
+    one_scan_out, one_scan_error, c4_out = None, None, None
+    if args.shard == "one-scan" and mode == "one-scan":
+        one_scan_out = run_one_scan(args, world, rank, dev, weights, n, barrier, synth)
+        if rank == 0:
+            print(json.dumps(one_scan_out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- one scan per rank: inputs (untimed), radii = exact 24-NN distance ------------------------
     pts, nrm = synth.scan_cloud(n, seed=rank_seed(rank), device=dev, density_variance=args.density_variance)
@@ -805,6 +789,45 @@ def main():
                                     "note": "algorithmic bytes of octree + 5 grids + aggregation search (SURVEY 8(d) "
                                             "formulas, bench.geometry_bytes) over stage_ms.geometry_wall; the stage is a "
                                             "chain of latency-bound integer kernels, not a streaming pass"}
+    else:
+        out = None
+
+    # ---- ONE scan over all ranks (the headline at N > 1), AFTER the replica line exists: the sharded path has never run on
+    # more than one physical GPU here, so it runs under a watchdog -- if it has not finished in time (a hang inside a
+    # collective cannot be recovered in-process) rank 0 prints the replica line with a note and every rank leaves.
+    if mode == "one-scan":
+        import threading
+        limit = float(os.environ.get("ASR_BENCH_ONE_SCAN_TIMEOUT", 420))
+
+        def give_up():
+            if rank == 0:
+                out["config"]["one_scan_error"] = "the sharded one-scan path did not finish within %.0f s" % limit
+                out["config"]["note"] = "replica measurement (one scan per GPU, weak scaling) reported instead"
+                print(json.dumps(out), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        del pipe
+        torch.cuda.empty_cache()
+        try:
+            one_scan_out = run_one_scan(args, world, rank, dev, weights, n, barrier, synth)
+        except Exception as e:  # the bench must still print a line: the replica measurement above
+            one_scan_error = "%s: %s" % (type(e).__name__, e)
+        # config C4 (8 GPUs: eight fused scans, 80 M points, sharded): informational sub-record
+        if one_scan_error is None and (world == 8 or os.environ.get("ASR_BENCH_C4")):
+            try:
+                import copy
+                a4 = copy.copy(args)
+                a4.steps, a4.warmup = 1, 1
+                c4_out = run_one_scan(a4, world, rank, dev, weights, n, barrier, synth, fused=world)
+            except Exception as e:
+                c4_out = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+
+    if rank == 0:
         if one_scan_out is not None:
             # N > 1: the one-scan strong-scaling measurement is the headline, the replicas ride along
             head = one_scan_out

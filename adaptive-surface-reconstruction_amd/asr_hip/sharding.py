@@ -533,11 +533,12 @@ class HipBackend:
         if key not in self._plans:
             perm = rows.to(torch.int32).contiguous()
             ctx = ops.context(self.device)
-            ctx.set_option("plan_arena", 1)  # this plan only: other users of the context keep plans of their own
+            before = ctx.get_option("plan_arena")
+            ctx.set_option("plan_arena", 1)  # this plan only: other users of the context keep their own setting
             try:
                 plan = ops.ConvPlan(K, idx, kidx, rs, row_perm=perm, num_rows=rows.numel())
             finally:
-                ctx.set_option("plan_arena", 0)
+                ctx.set_option("plan_arena", before)
             self._plans[key] = (perm, plan, rows)
         return self._plans[key][:2]
 

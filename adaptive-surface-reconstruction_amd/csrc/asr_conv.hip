@@ -713,7 +713,7 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy(
 // the segment in a partial slot and k_cconv_heavy4_finish adds a row's segments IN ORDER and contracts; a row of one segment
 // is finished by its block.  k_cconv_heavy4_items lays the items out on the device (the number of long rows never reaches
 // the host): item_first[li] = first item of long row li, part_first[li] = its first partial slot, or -1 for a row of one
-// item -- also rows whose segments would not fit the CCH_CAP slots, which then stay one item.
+// item -- also EVERY row when the segments of all long rows together would not fit the CCH_CAP slots (one decision per list).
 // ------------------------------------------------------------------------------------------
 constexpr int CCH_SEG = 4096;
 constexpr int CCH_CAP = 16384;  // partial slots of 260 floats
@@ -725,8 +725,26 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy4_items(const i64* __restri
     __shared__ int s_a[1024], s_b[1024];
     __shared__ int s_carry[2];
     const int n = cnt[0], t = threadIdx.x;
-    if (t == 0) s_carry[0] = s_carry[1] = 0;
+    // The list comes out of atomics in no particular order, so whether a row is cut must not depend on its position in it
+    // (a cut row is summed segment by segment: other bits than the same row kept whole): ALL rows of more than one segment are
+    // cut when their slots fit together, none otherwise -- one decision per list, the same on every run and on every rank.
+    __shared__ long long s_total;
+    if (t == 0) {
+        s_carry[0] = s_carry[1] = 0;
+        s_total = 0;
+    }
     __syncthreads();
+    {
+        long long mine = 0;
+        for (int li = t; li < n; li += 1024) {
+            const i64 q = list[li];
+            const i64 seg = (rs[q + 1] - rs[q] + CCH_SEG - 1) / CCH_SEG;
+            if (seg > 1) mine += seg;
+        }
+        if (mine) atomicAdd((unsigned long long*)&s_total, (unsigned long long)mine);
+    }
+    __syncthreads();
+    const bool cut_all = s_total <= CCH_CAP;
     for (int base = 0; base < n; base += 1024) {
         const int li = base + t;
         int seg = 0;
@@ -745,7 +763,7 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy4_items(const i64* __restri
             __syncthreads();
         }
         const int pf = s_carry[0] + s_a[t] - multi;
-        const bool cut = multi && pf + multi <= CCH_CAP;
+        const bool cut = multi && cut_all;
         const int items = li < n ? (cut ? seg : 1) : 0;
         s_b[t] = items;
         __syncthreads();

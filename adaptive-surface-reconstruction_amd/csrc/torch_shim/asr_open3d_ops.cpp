@@ -26,6 +26,8 @@ namespace {
 struct DeviceContext {
     std::mutex mu;
     asr_hip_context* ctx = nullptr;
+    hipStream_t last_stream = nullptr;  // stream of the previous op on this context
+    hipEvent_t switch_ev = nullptr;
 };
 struct Locked {
     std::unique_lock<std::mutex> lock;
@@ -48,6 +50,19 @@ Locked context_for(const at::Tensor& t) {
     if (!dc->ctx) {
         c10::DeviceGuard guard(t.device());
         TORCH_CHECK(asr_hip_context_create(&dc->ctx, stream) == ASR_HIP_OK, "asr_hip_context_create failed");
+    }
+    // Threads on different streams share the context's scratch arena and flag pool: when the stream changes, the new stream
+    // waits for everything the previous ops enqueued on the old one (ops are enqueued under the mutex, so an event recorded
+    // now is behind all of them).
+    if (dc->last_stream != stream) {
+        if (dc->switch_ev || hipEventCreateWithFlags(&dc->switch_ev, hipEventDisableTiming) == hipSuccess) {
+            c10::DeviceGuard guard(t.device());
+            {
+                TORCH_CHECK(hipEventRecord(dc->switch_ev, dc->last_stream) == hipSuccess, "hipEventRecord failed");
+                TORCH_CHECK(hipStreamWaitEvent(stream, dc->switch_ev, 0) == hipSuccess, "hipStreamWaitEvent failed");
+            }
+        }
+        dc->last_stream = stream;
     }
     asr_hip_context_set_stream(dc->ctx, stream);
     return Locked{std::move(lock), dc->ctx};

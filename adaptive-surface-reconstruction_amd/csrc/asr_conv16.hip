@@ -563,7 +563,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
         // The A fragments of this step are taken out of aq BEFORE the gather of step + 2 is issued into the
         // same registers (no register rotation, the gather stays two steps ahead).
         u32x4 fa[NJ][PLANES];
-        if (active) {
+        {  // (unconditional: a wave without the slot splits the zeros its gathers returned -- no branch, no merge copies)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if constexpr (MODE == ASR_CONV16_F16) {

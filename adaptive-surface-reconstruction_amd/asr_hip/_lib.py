@@ -136,7 +136,7 @@ class ShardStats(ctypes.Structure):
 EXPORTS = [
     "asr_hip_context_create", "asr_hip_context_destroy", "asr_hip_context_set_stream",
     "asr_hip_last_error", "asr_hip_version", "asr_hip_context_reserved_bytes", "asr_hip_set_print_callback", "asr_hip_print",
-    "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_weights_changed", "asr_hip_context_set_option", "asr_hip_context_get_option",
+    "asr_hip_struct_size", "asr_hip_context_device", "asr_hip_context_weights_changed", "asr_hip_context_set_option", "asr_hip_context_get_option", "asr_hip_option_info",
     "asr_hip_sparse_conv_variant_counts", "asr_hip_sparse_conv_packed_bytes", "asr_hip_sparse_conv_pack",
     "asr_hip_sparse_conv_f16", "asr_hip_sparse_conv_bf16x3", "asr_hip_sparse_conv_f16x2",
     "asr_hip_absmax_f32", "asr_hip_convert_f16",
@@ -250,6 +250,17 @@ class Context:
     def set_option(self, name, value):
         """per-context tunable (include/asr_hip.h asr_hip_context_set_option)"""
         self.call("asr_hip_context_set_option", name.encode(), ctypes.c_int64(int(value)))
+
+    def non_default_options(self):
+        """{name: value} of every tunable of this context that differs from its built-in default (asr_hip_option_info)"""
+        out, i = {}, 0
+        name, dflt = ctypes.c_char_p(), ctypes.c_int64()
+        while self.lib.asr_hip_option_info(i, ctypes.byref(name), ctypes.byref(dflt)) == 0:
+            v = self.get_option(name.value.decode())
+            if v != dflt.value:
+                out[name.value.decode()] = v
+            i += 1
+        return out
 
     def get_option(self, name):
         v = ctypes.c_int64(0)

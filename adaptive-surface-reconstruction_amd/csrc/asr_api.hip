@@ -36,7 +36,6 @@ struct OptEntry {
 const OptEntry k_options[] = {
         {"sconv_min_blocks", "ASR_SCONV_MIN_BLOCKS", &AsrOptions::sconv_min_blocks},
         {"sconv_wide_min", "ASR_SCONV_WIDE_MIN", &AsrOptions::sconv_wide_min},
-        {"sconv_dry", "ASR_SCONV_DRY", &AsrOptions::sconv_dry},
         {"row_segment", "ASR_ROW_SEGMENT", &AsrOptions::row_segment},
         {"row_lpt", "ASR_ROW_LPT", &AsrOptions::row_lpt},
         {"row_ranked", "ASR_ROW_RANKED", &AsrOptions::row_ranked},
@@ -57,8 +56,6 @@ const OptEntry k_options[] = {
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
         {"sconv_split_rows", "ASR_SCONV_SPLIT_ROWS", &AsrOptions::sconv_split_rows},
         {"sconv_split_min_rows", "ASR_SCONV_SPLIT_MIN_ROWS", &AsrOptions::sconv_split_min_rows},
-        {"sconv_ring", "ASR_SCONV_RING", &AsrOptions::sconv_ring},
-        {"sconv_ring_min_rows", "ASR_SCONV_RING_MIN_ROWS", &AsrOptions::sconv_ring_min_rows},
 };
 
 // asr::GetPrintCallbackFunction (cpp/lib/asr.cpp:34-37): one callback per verbosity level, process wide
@@ -72,7 +69,7 @@ PrintSlot g_print[4];
 
 extern "C" {
 
-const char* asr_hip_version(void) { return "0.2.0+mi355x.r3"; }
+const char* asr_hip_version(void) { return "0.2.0+mi355x.r6"; }
 
 int asr_hip_set_print_callback(asr_hip_print_callback callback, void* user, const int* levels, int num_levels) {
     if (num_levels < 0 || (num_levels > 0 && !levels)) return ASR_HIP_EINVAL;
@@ -127,6 +124,14 @@ int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t v
             return ASR_HIP_OK;
         }
     ASR_FAIL(ctx, ASR_HIP_EINVAL, "unknown option '%s'", name);
+}
+int asr_hip_option_info(int index, const char** name, int64_t* default_value) {
+    const int n = (int)(sizeof(k_options) / sizeof(k_options[0]));
+    if (index < 0 || index >= n || !name || !default_value) return ASR_HIP_EINVAL;
+    static const AsrOptions defaults;
+    *name = k_options[index].name;
+    *default_value = defaults.*(k_options[index].field);
+    return ASR_HIP_OK;
 }
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value) {
     if (!ctx || !name || !value) return ASR_HIP_EINVAL;

@@ -96,7 +96,6 @@ struct AsrOptions {
     i64 sconv16_min_blocks = 1024;  // the same for the 16-bit kernels (4 per CU: every column chunk of a tile gathers the
                                     // features again, and these kernels are bound by the load path on the small grids)
     i64 sconv_wide_min = 2048;    // 8-wave (128-row) blocks when they still give this many blocks
-    i64 sconv_dry = 0;            // measurement aid: 1 = prologue + epilogue, 2 = no wave-level slot skip, 3 = prologue
     i64 row_segment = 524288;     // rows are regrouped inside segments of this many consecutive rows
     i64 search_hash_level = -1;   // >= 0: finest level of the search's cell hash table (finer: binary search); tests
     i64 knn_deep = 1;             // kNN radius: finer start levels for the points of crowded cells (0: off)
@@ -120,11 +119,6 @@ struct AsrOptions {
     // tiles, the longest of which runs its 30 slots x cin / 32 steps alone on its CU): the slots are cut into five fixed
     // ranges, every (tile, range) is a block of its own, a second kernel adds the partial sums in range order.  The
     // choice depends on the input grid's size only, so that one rank of a sharded cloud makes the same one.
-    i64 sconv_ring = 0;            // 16-bit sparse conv: 1 = decoupled-wave kernel (k_sconv_ring16) for the plain 128-column-tile layers
-                                   // of grids with at least sconv_ring_min_rows output rows.  Off: measured 1.3 x SLOWER than
-                                   // k_sconv_plan16 on those layers at 10 M points; kept for its tests and as a
-                                   // record of the experiment
-    i64 sconv_ring_min_rows = 100000;
     i64 sconv_split_min_rows = 2048;
     i64 sconv_split_rows = 32768;  // 0: never
 };

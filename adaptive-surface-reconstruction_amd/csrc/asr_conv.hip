@@ -1082,9 +1082,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : (NT >= 16 ? 3 : 4)) vo
     bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
     bmask &= (1ull << K) - 1;  // K <= 56
-    if (a.algo == 9 || a.algo == 7) bmask = 0;  // measurement aid (ASR_SCONV_DRY=1): prologue + epilogue only
-    if (a.algo == 7) return;                    // (ASR_SCONV_DRY=3): prologue only
-    if (a.algo == 8) wmask = bmask;    // measurement aid (ASR_SCONV_DRY=2): no wave-level slot skip
 
     f32x4 acc[NT];
 #pragma unroll
@@ -1613,8 +1610,6 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
     const int ctot = a.cout + (dual ? a.cout_b : 0);
     if (dual && (!imp || a.cout % 16 != 8 || a.cout_b != 8 || a.residual || (uintptr_t)a.filters_b % 16 != 0))
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: second filter bank needs importance, cout %% 16 == 8, cout_b == 8");
-    const int dry = (int)ctx->opt.sconv_dry;
-    if (dry) a.algo = dry == 2 ? 8 : (dry == 3 ? 7 : 9);
     // widest column tile that fits cout, narrowed while the launch has too few blocks to fill
     // 256 CUs (coarse grids have only a few thousand rows; the gather is then repeated per
     // column chunk, which those levels can afford).  128-row blocks (8 waves) halve the weight

@@ -1073,406 +1073,6 @@ __global__ __launch_bounds__(256) void k_sconv_split_reduce(asr_sparse_conv_args
 }
 
 
-// ------------------------------------------------------------------------------------------
-// k_sconv_ring16 (round 5): the plain 55- / 9-slot layers of the large grids on DECOUPLED waves.
-//
-// k_sconv_plan16 ends every (slot, panel) step with a workgroup barrier, so a step lasts as long as the slowest of its
-// eight waves' memory round trips, and three workgroups per CU cannot cover that (matrix pipe 68 % busy on the 128- and
-// 256-wide layers, counters in profiles/r05_sq.csv).  Here a workgroup is ONE tile of 256 rows x 128 columns on a CU:
-//   * eight consumer waves, each with TWO 16-row groups (a B fragment read from LDS feeds two MFMA chains: half the
-//     panel traffic and LDS reads per product);
-//   * a ninth wave that only streams weight panels: global -> LDS by DMA into a ring of RB buffers, up to RB - 1 steps
-//     ahead of the slowest consumer; it publishes "panel s has landed" in an LDS word and re-uses a buffer when the LDS
-//     count of consumers that finished it is complete.  No s_barrier in the main loop;
-//   * the gathered rows go global -> LDS by DMA as well (global_load_lds_dwordx4: eight adjacent lanes move one 128-byte
-//     line -- twice the rate of a gather in the MFMA operand layout, scripts/micro/gather_bw.hip), two steps ahead into a
-//     private ring per wave (counted vmcnt waits, no cross-wave synchronisation), and are read back as operand
-//     fragments with conflict-free ds_read_b128 (XOR swizzle f(row) below, found by exhaustive search over the
-//     hardware's ds_read_b128 lane groups).
-// Same plan, packed weights, arithmetic (products of a row in the same order) and epilogue as k_sconv_plan16: results
-// are bit-identical to it (tests/test_gpu_conv16.py).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int ring_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
-// The flag words of the ring are read and written with inline DS instructions: in front of a DS access the compiler can see,
-// and cannot prove disjoint from a pending LDS DMA (an atomic access carries no alias information), it puts s_waitcnt
-// vmcnt(0) -- which would drain the row and panel prefetches of every step.
-__device__ __forceinline__ unsigned lds_addr_of(const unsigned* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
-__device__ __forceinline__ unsigned lds_flag_read(unsigned addr) {
-    unsigned v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_flag_write(unsigned addr, unsigned v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_flag_inc(unsigned addr) {
-    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(1u) : "memory");
-}
-
-template <int MODE>
-__device__ __forceinline__ void ring_split(const u32x4& q0, const u32x4& q1, float a_scale,
-                                           u32x4 (&fa)[MODE == ASR_CONV16_BF16X3 ? 3 : 2]) {
-    if constexpr (MODE == ASR_CONV16_F16X2) {
-        sconv16_split_f16x2(q0, q1, a_scale, fa[0], fa[1]);
-    } else {
-        unsigned p0[4], p1v[4], p2v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4& q = i < 2 ? q0 : q1;
-            const f32x2 v = {__uint_as_float(q[2 * (i & 1)]), __uint_as_float(q[2 * (i & 1) + 1])};
-            p0[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-            const f32x2 r1 = {v.x - __uint_as_float(p0[i] << 16), v.y - __uint_as_float(p0[i] & 0xffff0000u)};
-            p1v[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
-            const f32x2 r2 = {r1.x - __uint_as_float(p1v[i] << 16), r1.y - __uint_as_float(p1v[i] & 0xffff0000u)};
-            p2v[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
-        }
-        fa[0] = (u32x4){p0[0], p0[1], p0[2], p0[3]};
-        fa[1] = (u32x4){p1v[0], p1v[1], p1v[2], p1v[3]};
-        fa[2] = (u32x4){p2v[0], p2v[1], p2v[2], p2v[3]};
-    }
-}
-
-// products of one step of a wave's row group; the B fragments of two column tiles feed two independent MFMA chains, and
-// the fragments of the next pair are in flight while the current pair is multiplied.  Per row the same products in the same
-// order as sconv16_products.
-template <int MODE>
-__device__ __forceinline__ void ring_chain2(f32x4& c0, f32x4& c1, const u32x4* fa, const u32x4* bp0, const u32x4* bp1) {
-    if constexpr (MODE == ASR_CONV16_F16X2) {
-        const f16x8 x0 = __builtin_bit_cast(f16x8, fa[0]), x1 = __builtin_bit_cast(f16x8, fa[1]);
-        const f16x8 p0 = __builtin_bit_cast(f16x8, bp0[0]), p1 = __builtin_bit_cast(f16x8, bp0[1]);
-        const f16x8 q0 = __builtin_bit_cast(f16x8, bp1[0]), q1 = __builtin_bit_cast(f16x8, bp1[1]);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, p1, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, q1, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, p0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x1, q0, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, p0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x0, q0, c1, 0, 0, 0);
-    } else {
-        const bf16x8 x0 = __builtin_bit_cast(bf16x8, fa[0]), x1 = __builtin_bit_cast(bf16x8, fa[1]),
-                     x2 = __builtin_bit_cast(bf16x8, fa[2]);
-        const bf16x8 p0 = __builtin_bit_cast(bf16x8, bp0[0]), p1 = __builtin_bit_cast(bf16x8, bp0[1]),
-                     p2 = __builtin_bit_cast(bf16x8, bp0[2]);
-        const bf16x8 q0 = __builtin_bit_cast(bf16x8, bp1[0]), q1 = __builtin_bit_cast(bf16x8, bp1[1]),
-                     q2 = __builtin_bit_cast(bf16x8, bp1[2]);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, p2, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, q2, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, p1, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, q1, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, p1, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, q1, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, p0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, q0, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, p0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, q0, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, p0, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, q0, c1, 0, 0, 0);
-    }
-}
-template <int MODE, int PLANES>
-__device__ __forceinline__ void ring_products(const u32x4 (&fa)[PLANES], const u32x4* __restrict__ sb, f32x4 (&acc)[8], int ncol, int g) {
-    constexpr int PLANE_PIECES = 128 * 4;
-    auto load_b = [&](const int nb, u32x4 (&b)[PLANES]) __attribute__((always_inline)) {
-        const int col = nb * 16 + ncol;
-        const int piece = col * 4 + swz<32>(col, g);
-#pragma unroll
-        for (int pl = PLANES - 1; pl >= 0; --pl) b[pl] = sb[pl * PLANE_PIECES + piece];  // (the low planes are used first)
-    };
-    u32x4 b0[PLANES], b1[PLANES], b2[PLANES], b3[PLANES];
-    load_b(0, b0);
-    load_b(1, b1);
-#pragma unroll
-    for (int nb = 0; nb < 8; nb += 4) {
-        load_b(nb + 2, b2);
-        load_b(nb + 3, b3);
-        __builtin_amdgcn_sched_barrier(0);
-        ring_chain2<MODE>(acc[nb], acc[nb + 1], fa, b0, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (nb + 4 < 8) {
-            load_b(nb + 4, b0);
-            load_b(nb + 5, b1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        ring_chain2<MODE>(acc[nb + 2], acc[nb + 3], fa, b2, b3);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-#ifndef RING_STAGGER
-#define RING_STAGGER 12
-#endif
-constexpr int RING_RB = 3;     // weight panel buffers
-constexpr int RING_CW = 15;    // consumer waves, one 16-row group each (+ the panel wave = 16 waves, the largest workgroup)
-constexpr int RING_TM = RING_CW * 16;  // rows per tile
-
-template <int MODE>
-__global__ __launch_bounds__((RING_CW + 1) * 64, 1) void k_sconv_ring16(asr_sparse_conv_args a, asr_conv_plan_view plan,
-                                                                        const u16* __restrict__ packed, int cin_pad, int ctot_pad,
-                                                                        const float* __restrict__ zeros, int dry) {
-    // dry (measurement aid, option sconv_dry, only in builds with -DASR_RING_DRY): 1 = no MFMAs, 2 = no row DMA, 4 = no panel
-    // DMA (results are then wrong)
-#ifndef ASR_RING_DRY
-    dry = 0;
-#endif
-    constexpr int KC = 32, NCOL = 128;
-    constexpr int PLANES = MODE == ASR_CONV16_BF16X3 ? 3 : 2;
-    constexpr int PLANE_PIECES = NCOL * 4;
-    constexpr int PV = PLANES * PLANE_PIECES;  // 16-byte pieces per panel
-    constexpr int NCHUNK = PV / 64;            // 1 KB DMA pieces per panel
-    constexpr unsigned OOB_OFF = 0xFFFFE000u;
-    __shared__ __attribute__((aligned(16))) u32x4 s_B0[PV];
-    __shared__ __attribute__((aligned(16))) u32x4 s_B1[PV];
-    __shared__ __attribute__((aligned(16))) u32x4 s_B2[PV];
-    __shared__ __attribute__((aligned(16))) u32x4 s_A0[RING_CW * 128];  // per wave: 16 rows x 8 pieces of one panel
-    __shared__ __attribute__((aligned(16))) u32x4 s_A1[RING_CW * 128];
-    __shared__ unsigned s_ready[4];  // [b]: number of panels that have landed in buffer b so far
-    __shared__ unsigned s_done[4];   // [b]: number of (consumer wave, step) pairs that have finished reading buffer b
-    __shared__ unsigned long long s_wm[RING_CW];
-    __shared__ int s_slot[56];                 // the tile's slots in ascending order
-    __shared__ unsigned s_blk[RING_CW][56];    // [wave][slot rank]: byte offset of the group's pool block, OOB_OFF: not in the group
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int nY = ctot_pad / NCOL;
-    i64 tile = blockIdx.x;
-    int ychunk = 0;
-    if (nY > 1) {  // column chunks of one row tile on one XCD, consecutive dispatch slots (see k_sconv_mfma)
-        const i64 r8 = blockIdx.x >> 3;
-        ychunk = (int)(r8 % nY);
-        tile = (r8 / nY) * 8 + (blockIdx.x & 7);
-    }
-    const i64 row0 = tile * RING_TM;
-    if (row0 >= a.num_out) return;
-    const int n0 = ychunk * NCOL;
-    const int K = a.kernel_size;
-    const int cin = a.cin;
-    const int npanel = cin / KC;  // (the launcher sends cin % 32 != 0 elsewhere)
-    const i64 plane_stride = (i64)K * ctot_pad * cin_pad;
-
-    unsigned long long m = 0;
-    unsigned woff = 0;
-    if (wave < RING_CW) {
-        const i64 grp = tile * RING_CW + wave;
-        uint4 h = make_uint4(0, 0, 0, 0);
-        if (grp < plan.groups) h = plan.hdr[grp];
-        m = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.x) |
-             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)h.y) << 32)) & ((1ull << K) - 1);
-        woff = (unsigned)__builtin_amdgcn_readfirstlane((int)h.z);
-        if (lane == 0) s_wm[wave] = m;
-    }
-    if (tid < 4) {
-        s_ready[tid] = 0;
-        s_done[tid] = 0;
-    }
-    __syncthreads();
-    unsigned long long bmask = 0;
-#pragma unroll
-    for (int w = 0; w < RING_CW; ++w) bmask |= s_wm[w];
-    bmask = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bmask) |
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bmask >> 32)) << 32);
-    const int nslots = __popcll(bmask);
-    const int nsteps = nslots * npanel;
-    // slot tables: lane k of a wave files slot k under its rank among the tile's slots
-    if (lane < 56 && ((bmask >> lane) & 1)) {
-        const unsigned long long below = (1ull << lane) - 1;
-        const int rank = __popcll(bmask & below);
-        if (wave == RING_CW)
-            s_slot[rank] = lane;
-        else
-            s_blk[wave][rank] = ((m >> lane) & 1) ? (woff + (unsigned)__popcll(m & below)) * 64u : OOB_OFF;
-    }
-    __syncthreads();
-    if (nsteps == 0) return;
-    constexpr int RSRC_FLAGS = 0x00020000;
-
-    if (wave == RING_CW) {
-        // ---------------- the panel wave ----------------
-        __builtin_amdgcn_s_setprio(3);
-        const __amdgpu_buffer_rsrc_t rs_w =
-                __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, (int)(PLANES * plane_stride * 2), RSRC_FLAGS);
-        const int lane16 = lane * 16;
-        int j = 0, p = 0, k = s_slot[0];
-        for (int s = 0; s < nsteps; ++s) {
-            const int b = s % RING_RB;
-            if (s >= RING_RB) {  // the consumers of step s - RB have left the buffer
-                const unsigned need = (unsigned)(RING_CW * (s / RING_RB));
-                const unsigned da = lds_addr_of(&s_done[b]);
-                while (lds_flag_read(da) < need) __builtin_amdgcn_s_sleep(1);
-            }
-            u32x4* dst = b == 0 ? s_B0 : (b == 1 ? s_B1 : s_B2);
-            const int soff = ((k * npanel + p) * ctot_pad * KC) * 2;
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-                const int pl = c / (PLANE_PIECES / 64), ci = c % (PLANE_PIECES / 64);
-                if (!(dry & 4))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)&dst[c * 64], 16, lane16,
-                                                             soff + (int)((pl * plane_stride + (i64)n0 * KC) * 2 + ci * 1024), 0, 0);
-            }
-            if (s >= 1) {  // the panel of step s - 1 has landed once at most this step's NCHUNK pieces are in flight
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCHUNK) : "memory");
-                if (lane == 0) lds_flag_write(lds_addr_of(&s_ready[(s - 1) % RING_RB]), (unsigned)((s - 1) / RING_RB + 1));
-            }
-            if (++p == npanel) {
-                p = 0;
-                ++j;
-                k = j < nslots ? s_slot[j] : 0;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) lds_flag_write(lds_addr_of(&s_ready[(nsteps - 1) % RING_RB]), (unsigned)((nsteps - 1) / RING_RB + 1));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        return;
-    }
-
-    // ---------------- consumer waves ----------------
-    const int r = lane & 15, g = lane >> 4;
-    const int ncol = r;
-    f32x4 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
-    float a_scale = 1.f, unscale[2] = {1.f, 1.f};
-    if constexpr (MODE == ASR_CONV16_F16X2) {
-        const int sa = f16x2_scale_exp(*a.inp_absmax);
-        const int un = -(sa + *(const int*)(packed + PLANES * plane_stride));
-        a_scale = f16x2_pow2(sa);
-        unscale[0] = f16x2_pow2(un / 2);
-        unscale[1] = f16x2_pow2(un - un / 2);
-    }
-    const __amdgpu_buffer_rsrc_t rs_p =
-            __builtin_amdgcn_make_buffer_rsrc((void*)plan.pool, 0, (int)plan.pool_bytes, RSRC_FLAGS);
-    // rows by buffer addressing (the launcher sends matrices of 4 GB and more elsewhere): a lane beyond the buffer -- an absent
-    // neighbour -- writes ZEROS into its LDS piece (checked on gfx950).  global_load_lds would take 64-bit addresses, but the
-    // compiler cannot tell its LDS target from other LDS arrays and drains vmcnt in front of every DS read.
-    const unsigned row_bytes = (unsigned)a.inp_ld * 4u;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)a.inp_features, 0, (int)(unsigned)(a.num_inp > 0 ? ((a.num_inp - 1) * a.inp_ld + cin) * 4 : 0), RSRC_FLAGS);
-    // DMA lane mapping: chunk c (8 rows of the group's 16), lane l -> row 8 c + (l >> 3), LDS piece slot l & 7, which holds the
-    // row's 16-byte piece (l & 7) ^ ring_swz(row)
-    const int drow = lane >> 3;
-    unsigned dpiece[2], dentry[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        dpiece[c] = (unsigned)(((lane & 7) ^ ring_swz(8 * c + drow)) * 16);
-        dentry[c] = (unsigned)((8 * c + drow) * 4);
-    }
-    const unsigned* const my_blk = s_blk[wave];
-    // neighbour indices of the lane's two DMA rows for the slot of rank j (always issued, beyond the pool for a slot the group
-    // does not have or past the end: every step has the same sequence of memory instructions); x[2] = the block's offset
-    auto load_idx = [&](const int j, unsigned (&x)[3]) __attribute__((always_inline)) {
-        const unsigned blk = j < nslots ? my_blk[j] : OOB_OFF;
-        x[2] = blk;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) x[c] = __builtin_amdgcn_raw_buffer_load_b32(rs_p, (int)(blk + dentry[c]), 0, 0);
-    };
-    // the two DMA pieces of a step (panel p) into A buffer `dst` (this wave's 2 KB of it)
-    auto dma_a = [&](const int p, const unsigned (&x)[3], u32x4* dst) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const bool valid = x[2] != OOB_OFF && (int)x[c] >= 0;
-            const unsigned off = valid ? x[c] * row_bytes + dpiece[c] : OOB_OFF;
-            if (!(dry & 2))
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)&dst[wave * 128 + c * 64], 16,
-                                                         (int)off, p * (KC * 4), 0, 0);
-        }
-    };
-    const int a_base = wave * 128 + r * 8;
-    const int a_p0 = (2 * g) ^ ring_swz(r), a_p1 = (2 * g + 1) ^ ring_swz(r);
-
-    // step iterators (slot rank, panel): s (compute), s + 2 (row DMA), s + 4 (indices)
-    int j_c = 0, p_c = 0, j_d = 0, p_d = 0, j_i = 0, p_i = 0;
-#define ASR_RING_ADV(j, p) \
-    if (++(p) == npanel) { \
-        (p) = 0;           \
-        ++(j);             \
-    }
-    unsigned idx_s0[3], idx_s1[3], idx_s2[3];  // indices of step t live in set t % 3
-    load_idx(j_i, idx_s0);
-    ASR_RING_ADV(j_i, p_i)
-    load_idx(j_i, idx_s1);
-    ASR_RING_ADV(j_i, p_i)
-    dma_a(p_d, idx_s0, s_A0);
-    ASR_RING_ADV(j_d, p_d)
-    load_idx(j_i, idx_s2);
-    ASR_RING_ADV(j_i, p_i)
-    dma_a(p_d, idx_s1, s_A1);
-    ASR_RING_ADV(j_d, p_d)
-    load_idx(j_i, idx_s0);
-    ASR_RING_ADV(j_i, p_i)
-    int s = 0;
-    unsigned gen = 1;  // s / RB + 1
-    // The consumer waves run the same instruction stream from the same start: left alone they stay in phase -- all of them in
-    // the scalar / split part of a step at once, then all of them queueing on the matrix pipes.  A quarter of a step of delay
-    // between the waves of a SIMD (waves w, w + 4, w + 8, w + 12) lets the matrix phase of one cover the rest of another.
-    switch (wave >> 2) {
-        case 1: __builtin_amdgcn_s_sleep(RING_STAGGER); break;
-        case 2: __builtin_amdgcn_s_sleep(2 * RING_STAGGER); break;
-        case 3: __builtin_amdgcn_s_sleep(3 * RING_STAGGER); break;
-        default: break;
-    }
-
-    // one step.  AS: A buffer of step s (s % 2); BS: panel buffer (s % 3); idx_use: indices of step s + 2; idx_new: receives
-    // those of step s + 4
-    auto step = [&](auto asc, auto bsc, unsigned (&idx_use)[3], unsigned (&idx_new)[3]) __attribute__((always_inline)) {
-        constexpr int AS = decltype(asc)::value;
-        constexpr int BS = decltype(bsc)::value;
-        u32x4* const sa = AS ? s_A1 : s_A0;
-        const u32x4* const sb = BS == 0 ? s_B0 : (BS == 1 ? s_B1 : s_B2);
-        // rows of this step: in flight behind them are the 2 + 2 (rows, indices) of step s - 1's issue
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        u32x4 fa[PLANES];
-        {
-            const u32x4 q0 = sa[a_base + a_p0], q1 = sa[a_base + a_p1];
-            ring_split<MODE>(q0, q1, a_scale, fa);
-        }
-        // (the reads above have returned: their data went through the split) rows of step s + 2 into the same buffer
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        dma_a(p_d, idx_use, sa);
-        ASR_RING_ADV(j_d, p_d)
-        load_idx(j_i, idx_new);
-        ASR_RING_ADV(j_i, p_i)
-        {
-            const unsigned ra = lds_addr_of(&s_ready[BS]);
-            while (lds_flag_read(ra) < gen) __builtin_amdgcn_s_sleep(1);
-        }
-        asm volatile("" ::: "memory");
-        if (!(dry & 1)) ring_products<MODE, PLANES>(fa, sb, acc, ncol, g);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) lds_flag_inc(lds_addr_of(&s_done[BS]));
-        ++s;
-        if (BS == RING_RB - 1) ++gen;
-    };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    using C2 = std::integral_constant<int, 2>;
-    while (true) {  // s % 6 == 0 here
-        step(C0(), C0(), idx_s2, idx_s1);
-        if (s == nsteps) break;
-        step(C1(), C1(), idx_s0, idx_s2);
-        if (s == nsteps) break;
-        step(C0(), C2(), idx_s1, idx_s0);
-        if (s == nsteps) break;
-        step(C1(), C0(), idx_s2, idx_s1);
-        if (s == nsteps) break;
-        step(C0(), C1(), idx_s0, idx_s2);
-        if (s == nsteps) break;
-        step(C1(), C2(), idx_s1, idx_s0);
-        if (s == nsteps) break;
-    }
-#undef ASR_RING_ADV
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the dummy row pieces of the steps past the end)
-
-    const f32x4 none = {0.f, 0.f, 0.f, 0.f};
-    const float norm4[4] = {0.f, 0.f, 0.f, 0.f};
-    int q4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const i64 lr = row0 + wave * 16 + 4 * g + i;
-        q4[i] = lr < a.num_out ? (a.row_perm ? a.row_perm[lr] : (int)lr) : -1;
-    }
-    sconv16_epilogue<8, MODE, false>(a, acc, none, q4, norm4, n0, ncol, a.cout, a.cout, false, 0, zeros, unscale);
-}
-
 }  // namespace
 
 // ==========================================================================================
@@ -1592,14 +1192,9 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
             ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv16: the plan was built for another list");
         pv = plan->view();
     }
-    // decoupled-wave kernel (k_sconv_ring16): plain layers, 128-column tiles, grids large enough for whole rounds of
-    // one 256-row tile per CU
-    const bool ring = use_plan && !dual && !imp && (mode == ASR_CONV16_BF16X3 || mode == ASR_CONV16_F16X2) &&
-                      ctot_pad % 128 == 0 && !a.force_nt && !a.force_waves && !a.normalize && !a.out_importance &&
-                      ctx->opt.sconv_ring && a.num_out >= ctx->opt.sconv_ring_min_rows;
     // slot-range split (see split_range_mask): plain 55-slot convolutions over a coarse grid.  Decided from the INPUT grid's
     // row count, which a rank of a sharded cloud shares with the one-GPU run.
-    const bool split = use_plan && !ring && !dual && !imp && mode != ASR_CONV16_F16 && a.kernel_size == 55 && !a.force_nt &&
+    const bool split = use_plan && !dual && !imp && mode != ASR_CONV16_F16 && a.kernel_size == 55 && !a.force_nt &&
                        !a.force_waves && ctot_pad % 64 == 0 && ctx->opt.sconv_split_rows > 0 &&
                        a.num_inp <= ctx->opt.sconv_split_rows && a.num_inp >= ctx->opt.sconv_split_min_rows;
     asr_split_args spa = {nullptr, 0};
@@ -1620,22 +1215,6 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
             ctx->split_part_bytes = need + need / 4;
         }
         spa.part = ctx->split_part;
-    }
-    if (ring) {
-        const i64 tiles_ = (a.num_out + RING_TM - 1) / RING_TM;
-        const i64 ny_ = ctot_pad / 128;
-        dim3 grid((unsigned)(ny_ > 1 ? ((tiles_ + 7) / 8) * 8 * ny_ : tiles_));
-        if (mode == ASR_CONV16_BF16X3)
-            k_sconv_ring16<ASR_CONV16_BF16X3><<<grid, dim3((RING_CW + 1) * 64), 0, ctx->stream>>>(a, pv, (const u16*)packed, cin_pad,
-                                                                                                  ctot_pad, zeros, (int)ctx->opt.sconv_dry);
-        else
-            k_sconv_ring16<ASR_CONV16_F16X2><<<grid, dim3((RING_CW + 1) * 64), 0, ctx->stream>>>(a, pv, (const u16*)packed, cin_pad,
-                                                                                                 ctot_pad, zeros, (int)ctx->opt.sconv_dry);
-        ASR_CHECK_LAUNCH(ctx);
-        char key[64];  // reported as a 9-wave instance of the plan kernel's key format
-        snprintf(key, sizeof(key), "8,32,0,9,0,%d,1", mode);
-        ++ctx->sconv_launches[key];
-        return ASR_HIP_OK;
     }
 #define ASR_L16(NT_, KC_, W_, M_, I_, D_)                                                                        \
     {                                                                                                            \

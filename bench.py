@@ -647,6 +647,7 @@ def main():
     t_knn = time.perf_counter() - t_knn
     bb_min, bb_max = synth.bounding_box(pts, 0.1)
     pipe = ImplicitPipeline(weights, device=dev, precision=args.precision)
+    options_timed = pipe.ctx.non_default_options()
 
     def step():
         return pipe.forward(pts, nrm, radii, bb_min, bb_max)
@@ -732,6 +733,9 @@ def main():
                                       "variance preserving, synth.make_weights(1, seed=2)" if args.weights == "variance"
                                       else "reference initialisers"),
                        "precision": args.precision,
+                       # every tunable of the timed context that differs from its built-in default (environment seeds
+                       # included); none of the library's options skips work
+                       "non_default_options": options_timed,
                        "points_per_gpu": n,
                        "voxels": [int(v) for v in pipe.sizes.num_voxels],
                        "pairs": [int(v) for v in pipe.sizes.num_pairs],
@@ -774,7 +778,7 @@ def main():
                  "frac_counter_traffic": (tr[0] * launches / unet_s / 1e9 / HBM_PEAK_GBS) if tr and unet_s > 0 else None}
         head_r = dict(r_hbm if r_hbm["frac"] >= r_mfma["frac"] else r_mfma)
         head_r.update({"traffic": tr[0] if tr else None,
-                       "traffic_note": ("HBM-side bytes per launch ((2*FETCH_SIZE + WRITE_SIZE)*1024, Infinity-Cache hits "
+                       "traffic_from_profiles": ("HBM-side bytes per launch ((2*FETCH_SIZE + WRITE_SIZE)*1024, Infinity-Cache hits "
                                         "included), rocprofv3 PMC passes in profiles/%s" % tr[1]) if tr else None,
                        "kernel": "%s (%d launches/step, %.3f ms avg, %.1f algorithmic GFLOP and %.1f algorithmic / %.1f "
                                  "compulsory GB per step)" % (kname, launches, stage_ms["unet"] / launches, flops / 1e9,
@@ -792,32 +796,77 @@ def main():
     else:
         out = None
 
+    def final_line(head_scan, scan_error, c4):
+        """rank 0: the line that is printed -- the one-scan measurement as the headline when there is one (the replicas ride
+        along), else the replica line with the reason"""
+        line = out
+        if head_scan is not None:
+            line = head_scan
+            line["config"]["replicas"] = {k: out[k] for k in ("value", "ms_per_step", "scaling")}
+            line["config"]["replicas"]["stage_ms"] = out["config"]["stage_ms"]
+            line["config"]["replicas"]["note"] = "one %d-point scan per GPU, no collective (weak scaling), same run" % n
+            line["config"]["non_default_options"] = out["config"]["non_default_options"]
+            line["roofline"] = out["roofline"]
+            line["roofline"]["note"] = "dominant kernel measured in the replica run of this job (one scan per GPU)"
+            line["roofline_geometry"] = out["roofline_geometry"]
+            if c4 is not None:
+                line["config"]["c4_fused_scans"] = ({k: c4[k] for k in ("value", "ms_per_step", "scaling", "config")}
+                                                    if "value" in c4 else c4)
+        elif scan_error is not None:
+            line["config"]["one_scan_error"] = scan_error
+            line["config"]["note"] = "the sharded one-scan path failed on this node: replica measurement reported instead"
+        return line
+
     # ---- ONE scan over all ranks (the headline at N > 1), AFTER the replica line exists: the sharded path has never run on
-    # more than one physical GPU here, so it runs under a watchdog -- if it has not finished in time (a hang inside a
-    # collective cannot be recovered in-process) rank 0 prints the replica line with a note and every rank leaves.
+    # more than one physical GPU here, so each of its two runs has a watchdog of its own -- a hang inside a collective cannot
+    # be recovered in-process: rank 0 prints what is finished by then (the replica line with a note if the headline run hangs,
+    # the finished headline if only the C4 sub-record hangs) and every rank leaves.
     if mode == "one-scan":
         import threading
+        printed = threading.Lock()  # whoever takes it prints the job's ONE line
+
+        def watchdog_for(what, limit, head_scan):
+            def give_up():
+                if not printed.acquire(blocking=False):
+                    return
+                if rank == 0:
+                    msg = "%s did not finish within %.0f s" % (what, limit)
+                    if head_scan is None:
+                        line = final_line(None, msg, None)
+                    else:
+                        line = final_line(head_scan, None, {"error": msg})
+                    print(json.dumps(line), flush=True)
+                sys.stdout.flush()
+                os._exit(0)
+            t = threading.Timer(limit, give_up)
+            t.daemon = True
+            t.start()
+            return t
+
         limit = float(os.environ.get("ASR_BENCH_ONE_SCAN_TIMEOUT", 420))
-
-        def give_up():
-            if rank == 0:
-                out["config"]["one_scan_error"] = "the sharded one-scan path did not finish within %.0f s" % limit
-                out["config"]["note"] = "replica measurement (one scan per GPU, weak scaling) reported instead"
-                print(json.dumps(out), flush=True)
-            sys.stdout.flush()
-            os._exit(0)
-
-        watchdog = threading.Timer(limit, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+        watchdog = watchdog_for("the sharded one-scan path", limit, None)
         del pipe
         torch.cuda.empty_cache()
         try:
             one_scan_out = run_one_scan(args, world, rank, dev, weights, n, barrier, synth)
         except Exception as e:  # the bench must still print a line: the replica measurement above
             one_scan_error = "%s: %s" % (type(e).__name__, e)
-        # config C4 (8 GPUs: eight fused scans, 80 M points, sharded): informational sub-record
-        if one_scan_error is None and (world == 8 or os.environ.get("ASR_BENCH_C4")):
+        # every rank must take the same decision about the next collective run: agree on "somebody failed" (still under the
+        # first watchdog: a rank that died inside a collective leaves its peers waiting here)
+        failed = torch.tensor([1 if one_scan_error is not None else 0], device=dev, dtype=torch.int32)
+        if world > 1:
+            if args.backend == "gloo":
+                failed = failed.cpu()
+            dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        any_failed = bool(int(failed.item()))
+        watchdog.cancel()
+        if any_failed and one_scan_error is None:
+            one_scan_error = "the sharded one-scan path failed on another rank"
+            one_scan_out = None
+        # config C4 (8 GPUs: eight fused scans, 80 M points, sharded): informational sub-record, its own watchdog
+        if not any_failed and (world == 8 or os.environ.get("ASR_BENCH_C4")):
+            limit4 = float(os.environ.get("ASR_BENCH_C4_TIMEOUT", 300))
+            watchdog = watchdog_for("config C4 (fused scans, sharded)", limit4, one_scan_out)
             try:
                 import copy
                 a4 = copy.copy(args)
@@ -825,25 +874,13 @@ def main():
                 c4_out = run_one_scan(a4, world, rank, dev, weights, n, barrier, synth, fused=world)
             except Exception as e:
                 c4_out = {"error": "%s: %s" % (type(e).__name__, e)}
-        watchdog.cancel()
+            watchdog.cancel()
+        if not printed.acquire(blocking=False):  # a watchdog is printing: leave it to it
+            time.sleep(30)
+            os._exit(0)
 
     if rank == 0:
-        if one_scan_out is not None:
-            # N > 1: the one-scan strong-scaling measurement is the headline, the replicas ride along
-            head = one_scan_out
-            head["config"]["replicas"] = {k: out[k] for k in ("value", "ms_per_step", "scaling")}
-            head["config"]["replicas"]["stage_ms"] = out["config"]["stage_ms"]
-            head["config"]["replicas"]["note"] = "one %d-point scan per GPU, no collective (weak scaling), same run" % n
-            head["roofline"] = out["roofline"]
-            head["roofline"]["note"] = "dominant kernel measured in the replica run of this job (one scan per GPU)"
-            head["roofline_geometry"] = out["roofline_geometry"]
-            if c4_out is not None:
-                head["config"]["c4_fused_scans"] = ({k: c4_out[k] for k in ("value", "ms_per_step", "scaling", "config")}
-                                                    if "value" in c4_out else c4_out)
-            out = head
-        elif one_scan_error is not None:
-            out["config"]["one_scan_error"] = one_scan_error
-            out["config"]["note"] = "the sharded one-scan path failed on this node: replica measurement reported instead"
+        out = final_line(one_scan_out, one_scan_error, c4_out)
         if not args.no_cpu_baseline and world == 1:  # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1000)
         print(json.dumps(out))

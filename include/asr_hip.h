@@ -72,16 +72,18 @@ int asr_hip_context_weights_changed(asr_hip_context* ctx);
 /* Per-context tunables (no process-wide state).  Names: "sconv_min_blocks" (2816) and
  * "sconv_wide_min" (2048): launch-size thresholds that pick the sparse-conv tile shape;
  * "row_segment" (524288), "row_lpt" (1): MFMA row regrouping; "overlap" (1): aggregation search on a
- * second stream; "sconv_dry" (0): measurement aid; "build_search" (1): 0 makes asr_hip_implicit_build stop
+ * second stream; "build_search" (1): 0 makes asr_hip_implicit_build stop
  * after the grid hierarchy (a rank of a sharded run searches only the rows it owns).  Results never depend
- * on the tuning options; "sconv_dry" is the exception: it skips work and produces garbage, for timing only.
+ * on the tuning options: none of them skips work.
  * "search_half" (1): the aggregation search of asr_hip_implicit_build covers a voxel's ball with 4^3 half-size
  * cells for the rows with many candidates (2: for every voxel, 0: 3^3 full-size cells throughout).  get_option also answers the read-only "last_search_margin_pairs": pairs the last
- * such search found in the rounding margin of the half-size cells.
- * "sconv_ring" (0), "sconv_ring_min_rows" (100000): 1 sends the plain 128-column-tile layers of the 16-bit sparse convs on
- * grids of at least that many rows to the decoupled-wave kernel (k_sconv_ring16: same bits, measured slower -- DESIGN.md 7.4). */
+ * such search found in the rounding margin of the half-size cells. */
 int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t value);
 int asr_hip_context_get_option(asr_hip_context* ctx, const char* name, int64_t* value);
+/* The table of tunables: name and built-in default of option `index` (0, 1, ... until ASR_HIP_EINVAL).  A context's defaults can
+ * be seeded from the environment (ASR_<NAME>) when it is created; bench.py prints every option that differs from its built-in
+ * default into the line's `config` (the reference has no tunables: cpp/lib/asr.hpp:27-101). */
+int asr_hip_option_info(int index, const char** name, int64_t* default_value);
 
 /* ---- print callbacks: asr::SetPrintCallbackFunction (cpp/lib/asr.hpp:25-34, asr.cpp:34-47) ------------- */
 /* Process-wide like the reference's (a static table of four callbacks).  Levels: cpp/lib/asr.hpp:27.  The whole-path

@@ -104,6 +104,15 @@ def test_options_without_a_gpu():
     lib = _lib.load()
     assert lib.asr_hip_context_set_option(None, b"overlap", ctypes.c_int64(0)) == 1
     assert lib.asr_hip_context_device(None) == -1
+    # the option table (asr_hip_option_info): names + built-in defaults, no work-skipping mode among them
+    names, i = {}, 0
+    name, dflt = ctypes.c_char_p(), ctypes.c_int64()
+    while lib.asr_hip_option_info(i, ctypes.byref(name), ctypes.byref(dflt)) == 0:
+        names[name.value.decode()] = dflt.value
+        i += 1
+    assert names["overlap"] == 1 and names["sconv_split_rows"] == 32768 and len(names) >= 20
+    assert not any("dry" in k or "ring" in k for k in names)
+    assert lib.asr_hip_option_info(i, ctypes.byref(name), ctypes.byref(dflt)) == 1
 
 
 def test_model_pt_loader_reads_a_torchscript_archive(tmp_path):

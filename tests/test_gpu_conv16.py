@@ -466,53 +466,3 @@ def test_duplicate_slot_in_a_row_is_refused(gpu):
     kidx[11] = 1
     out = ops.sparse_conv16("bf16x3", packed, 3, c, c, _t(f, gpu), _t(idx, gpu), _t(kidx, gpu), _t(rs, gpu))
     _close(out.cpu().numpy(), O.sparse_conv(W, f, idx, kidx, None, rs, False))
-
-
-@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
-def test_ring_kernel_equals_plan_kernel_on_random_lists(gpu, mode):
-    """k_sconv_ring16 (decoupled waves: 256-row tiles, panel wave + LDS rings, rows by LDS DMA) runs the products of a row in
-    the same order as k_sconv_plan16: plain convolutions agree BIT FOR BIT on random neighbour lists -- empty rows, full
-    rows, absent neighbours (zero-filled by the DMA), row lists, padded strides, one and two 128-column chunks, bias /
-    ReLU / residual epilogues, row counts that do not fill the last tile."""
-    from asr_hip import ops
-    ctx = ops.context(gpu)
-    g = torch.Generator(device="cpu").manual_seed(123)
-    split_rows = ctx.get_option("sconv_split_rows")
-    ctx.set_option("sconv_split_rows", 0)  # (the slot-range split of the coarse grids adds a row's slots in another order)
-    try:
-        for case in range(20):
-            K = [55, 9, 27, 55][case % 4]
-            cin = [32, 64, 128, 256, 96][case % 5]
-            cout = [128, 256, 120, 248][case % 4]
-            v, num_inp = int(torch.randint(1, 5000, (1,), generator=g)), int(torch.randint(1, 6000, (1,), generator=g))
-            lens = torch.randint(0, min(K, 14) + 1, (v,), generator=g)
-            lens[torch.randint(0, v, (max(1, v // 50),), generator=g)] = K
-            slots = torch.cat([torch.randperm(K, generator=g)[:int(n)] for n in lens]) if int(lens.sum()) else torch.zeros(0, dtype=torch.int64)
-            rs = torch.zeros(v + 1, dtype=torch.int64)
-            rs[1:] = torch.cumsum(lens, 0)
-            idx = torch.randint(0, num_inp, (int(rs[-1]),), generator=g)
-            ld = cin + [0, 4, 32][case % 3]
-            f = torch.randn((num_inp, ld), generator=g).to(gpu)[:, :cin]
-            W = (torch.randn((K, cin, cout), generator=g) * 0.1).to(gpu)
-            bias = torch.randn(cout, generator=g).to(gpu) if case % 2 else None
-            res = torch.randn((v, cout), generator=g).to(gpu) if case % 3 == 0 else None
-            perm = torch.randperm(v, generator=g).to(torch.int32).to(gpu) if case % 3 else None
-            n_rows = max(1, v // 2) if (case % 4 == 3 and perm is not None) else None
-            kw = dict(bias=bias, relu=bool(case % 2), residual=res, row_perm=perm, num_rows=n_rows)
-            pk = ops.pack_filters(W, mode)
-            outs = []
-            for ring in (1, 0):
-                ctx.set_option("sconv_ring", ring)
-                ctx.set_option("sconv_ring_min_rows", 0)
-                ctx.sconv_variant_counts(reset=True)
-                out = torch.full((v, cout), -3.0, device=gpu)
-                ops.sparse_conv16(mode, pk, K, cin, cout, f, idx.to(torch.int32).to(gpu), slots.to(torch.uint8).to(gpu),
-                                  rs.to(gpu), out=out, **kw)
-                key = list(ctx.sconv_variant_counts())[0]
-                assert (key[3] == 9) == bool(ring), key
-                outs.append(out)
-            assert torch.equal(outs[0], outs[1]), (case, float((outs[0] - outs[1]).abs().max()))
-    finally:
-        ctx.set_option("sconv_ring", 0)
-        ctx.set_option("sconv_ring_min_rows", 100000)
-        ctx.set_option("sconv_split_rows", split_rows)

@@ -2,6 +2,8 @@
 the oracle and the network within tolerance (narrow model so the CPU oracle finishes in seconds).
 10 M points (C3): size-independent properties -- sortedness, CSR well-formedness, inversion round
 trip, slot uniqueness, symmetric neighbour relation, run-to-run bit reproducibility."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -138,8 +140,8 @@ def _close_or_cpu_class(got, exact, ref32, what):
 def test_ten_million_points_single_layers_vs_oracle(gpu):
     """C3 size: full-width layers of every grid level through the launcher's OWN tile choice at 10 M points, each
     compared with the oracle on the same CSR -- once on the exact f32 kernel (k_sconv_mfma) and once on the kernel
-    the default bench TIMES (k_sconv_plan16<f16x2> with the row-group plan of the list; and its six-product sibling
-    bf16x3).  The instances launched must be exactly the ones named in the committed trace of the bench
+    the default bench TIMES (k_sconv_plan16<bf16x3> with the row-group plan of the list; and its three-product sibling
+    f16x2, a sub-record of the bench).  The instances launched must be exactly the ones named in the committed trace of the bench
     (tests/sconv_instances.py)."""
     from asr_hip import ops
     from asr_hip.pipeline import ImplicitPipeline
@@ -213,7 +215,7 @@ def test_ten_million_points_single_layers_vs_oracle(gpu):
 
 def test_ten_million_points_split_arithmetic_whole_path_equals_the_exact_f32_kernel(gpu):
     """C3 size, full-width network (the widths of the bench), variance-preserving weights: the implicit values of
-    the arithmetic the bench times (f16x2; and bf16x3) against the bit-exact f32-input MFMA kernel on the same cloud,
+    the arithmetic the bench times (bf16x3; and the f16x2 sub-record) against the bit-exact f32-input MFMA kernel on the same cloud,
     bound 1e-5 of the range (north_star) -- measured 3e-6 for bf16x3."""
     from asr_hip.pipeline import ImplicitPipeline
     pts, nrm, radii, bb = _prep(10_000_000, 1000, gpu)
@@ -422,13 +424,22 @@ def test_ten_million_points_full_width_headline_arithmetic_vs_oracle(gpu):
         exact = parity.oracle_network(item, hp, hn, weights)
     ref32 = parity.oracle_network(item, hp, hn, weights)
     cpu_share = {k: parity.pass_fraction(ref32[k], exact[k]) for k in ("code", "values")}
-    for precision in ("bf16x3", "f16x2"):
+    record = {"what": "10 M-point C3 cloud, full width (channel_div 1), synth.make_weights(1, seed=2): distance of code / values "
+                      "from the oracle's double-accumulating evaluation (max |error| / range) and share of elements within "
+                      "1e-5 + 1e-5 |exact|", "points": int(pts.shape[0]), "arithmetic": {}}
+    for k in ("code", "values"):
+        scale = max(1.0, float(np.abs(exact[k]).max()))
+        cpu_err = float(np.abs(ref32[k].astype(np.float64) - exact[k]).max())
+        record["arithmetic"].setdefault("fp32 CPU oracle", {})[k] = {"max_err": cpu_err, "range": scale,
+                                                                     "err_over_range": cpu_err / scale, "share": cpu_share[k]}
+    for precision in ("bf16x3", "f16x2", "f32"):
         pipe = ImplicitPipeline(weights, device=gpu, precision=precision)
         pipe.ctx.sconv_variant_counts(reset=True)
         values = pipe.forward(pts, nrm, radii, bb[0], bb[1])
         counts = pipe.ctx.sconv_variant_counts()
-        from sconv_instances import bench_instances16
-        assert sum(counts.values()) == 44 and set(counts) == bench_instances16(precision), counts
+        if precision != "f32":
+            from sconv_instances import bench_instances16
+            assert sum(counts.values()) == 44 and set(counts) == bench_instances16(precision), counts
         assert np.array_equal(pipe.get("voxel_keys0").cpu().numpy().view(np.uint64), item["voxel_keys0"])
         assert np.array_equal(pipe.get("aggregation_neighbors_index").cpu().numpy(), item["aggregation_neighbors_index"])
         _close(pipe.get("feats1").cpu().numpy(), exact["feats1"])
@@ -436,15 +447,26 @@ def test_ten_million_points_full_width_headline_arithmetic_vs_oracle(gpu):
             g = got.cpu().numpy()
             scale = max(1.0, float(np.abs(exact[k]).max()))
             err = float(np.abs(g.astype(np.float64) - exact[k]).max())
+            rms = float(np.sqrt(np.mean((g.astype(np.float64) - exact[k]) ** 2)))
             cpu_err = float(np.abs(ref32[k].astype(np.float64) - exact[k]).max())
             share = parity.pass_fraction(g, exact[k])
+            record["arithmetic"].setdefault(precision, {})[k] = {"max_err": err, "rms_err": rms, "range": scale,
+                                                                 "err_over_range": err / scale, "share": share}
             print("10 M points, full width, %s, %s: max deviation from the exact result %.3e at a range of %.3g (%.2e of "
                   "it; fp32 CPU oracle %.2e of it); share within 1e-5 + 1e-5 |ref|: %.5f (fp32 CPU oracle %.5f)"
                   % (precision, k, err, scale, err / scale, cpu_err / scale, share, cpu_share[k]))
             assert err <= 1.5e-5 * scale, (precision, k, err, scale)
             if k == "values":
-                assert share >= min(0.999, cpu_share[k] - 0.005), (precision, share, cpu_share[k])
+                # measured on MI355X (profiles/r06_parity_10m.json); an explicit floor next to the relative one
+                assert share >= min(0.999, cpu_share[k] - 0.005) and share >= 0.98, (precision, share, cpu_share[k])
         del pipe
+    # the measured numbers are an artefact, not a print: gpurun_out/parity_10m.json -> profiles/r06_parity_10m.json
+    import json
+    path = os.environ.get("ASR_PARITY_JSON", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                          "gpurun_out", "parity_10m.json"))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(record, f, indent=1)
 
 
 def test_config_c5_ten_million_mixed_density_points_f16(gpu):

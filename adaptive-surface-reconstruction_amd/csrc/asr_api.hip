@@ -56,7 +56,15 @@ const OptEntry k_options[] = {
         {"early_cells", "ASR_EARLY_CELLS", &AsrOptions::early_cells},
         {"sconv_split_rows", "ASR_SCONV_SPLIT_ROWS", &AsrOptions::sconv_split_rows},
         {"sconv_split_min_rows", "ASR_SCONV_SPLIT_MIN_ROWS", &AsrOptions::sconv_split_min_rows},
+        {"arena_cap_mb", "ASR_ARENA_CAP_MB", &AsrOptions::arena_cap_mb},
+        {"inject_failure", "ASR_INJECT_FAILURE", &AsrOptions::inject_failure},
 };
+// option "arena_cap_mb" -> the arenas of the context and of its auxiliary (search) context
+void apply_arena_cap(asr_hip_context* ctx) {
+    const size_t cap = ctx->opt.arena_cap_mb > 0 ? (size_t)ctx->opt.arena_cap_mb << 20 : 0;
+    for (asr_hip_context* c : {ctx, ctx->aux})
+        if (c) c->persist.cap = c->scratch.cap = c->shard_mem.cap = cap;
+}
 
 // asr::GetPrintCallbackFunction (cpp/lib/asr.cpp:34-37): one callback per verbosity level, process wide
 struct PrintSlot {
@@ -112,6 +120,7 @@ int asr_hip_context_create(asr_hip_context** out, void* stream) {
     memset(&ctx->sizes, 0, sizeof(ctx->sizes));
     for (const OptEntry& o : k_options)  // experiment defaults from the environment, per context
         if (const char* e = getenv(o.env)) ctx->opt.*(o.field) = atoll(e);
+    apply_arena_cap(ctx);
     *out = ctx;
     return ASR_HIP_OK;
 }
@@ -121,6 +130,7 @@ int asr_hip_context_set_option(asr_hip_context* ctx, const char* name, int64_t v
         if (!strcmp(name, o.name)) {
             ctx->opt.*(o.field) = value;
             if (ctx->aux) ctx->aux->opt.*(o.field) = value;
+            apply_arena_cap(ctx);
             return ASR_HIP_OK;
         }
     ASR_FAIL(ctx, ASR_HIP_EINVAL, "unknown option '%s'", name);
@@ -177,6 +187,7 @@ static void release_members(asr_hip_context* ctx) {
     if (ctx->d_flags_base) (void)hipFree(ctx->d_flags_base);
     if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
     if (ctx->d_absmax) (void)hipFree(ctx->d_absmax);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->split_part) (void)hipFree(ctx->split_part);
     if (ctx->ev_ok)
         for (auto& e : ctx->ev) (void)hipEventDestroy(e);
@@ -947,6 +958,7 @@ int asr_ctx_ensure_aux(asr_hip_context* ctx) {
     ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t0));
     ASR_HIP_CHECK(ctx, hipEventCreate(&ctx->aux_t1));
     ctx->aux->opt = ctx->opt;
+    apply_arena_cap(ctx);
     return ASR_HIP_OK;
 }
 
@@ -1405,17 +1417,10 @@ int implicit_aggregate(asr_hip_context* ctx, const float* points, const float* n
     return ASR_HIP_OK;
 }
 
-int implicit_network(asr_hip_context* ctx, const float* points, const float* normals, i64 n,
-                     const asr_weight* weights, int num_weights, const asr_implicit_params* prm,
-                     float* values_out) {
-    ASR_TRY(ensure_events(ctx));
-    Net net{ctx, {weights, num_weights}};
-    net.precision = prm->precision;
-    // f16x2: every activation buffer has a running maximum, kept by the kernels that write it (a concat buffer by both of its
-    // producers) and read by the ones that consume it -- feats1's by the continuous conv
-    ASR_TRY(net.begin_amax());
-    unsigned* feats_amax = net.new_amax();
-    ASR_TRY(implicit_aggregate(ctx, points, normals, n, net, feats_amax));
+// U-Net + decoder over the feats1 / importance of implicit_aggregate (the part of the network that exchanges halos in a
+// sharded forward).  With ctx->dry_launch set this is the PREPARATION pass: every weight look-up and shape check, every
+// allocation (activations, packed weights, partial-sum and staging buffers) happens, no kernel is launched and nothing travels.
+int network_unet_decode(asr_hip_context* ctx, Net& net, const asr_implicit_params* prm, float* values_out, unsigned* feats_amax) {
     GridDev* g = ctx->grids;
     const i64 V0 = g[0].v;
     const i64 P = ctx->sizes.num_agg_pairs;
@@ -1550,6 +1555,47 @@ int implicit_network(asr_hip_context* ctx, const float* points, const float* nor
     return ASR_HIP_OK;
 }
 
+// comm != null (asr_hip_implicit_forward_sharded, ctx->shard set): the aggregation runs (it has no collective), then the
+// U-Net and the decoder go through their preparation pass, the ranks agree that nobody failed, and only then the pass
+// that launches and exchanges runs -- from the same arena marks, so that it repeats the allocations it has already made.
+int implicit_network(asr_hip_context* ctx, const float* points, const float* normals, i64 n,
+                     const asr_weight* weights, int num_weights, const asr_implicit_params* prm,
+                     float* values_out, const asr_shard_comm* comm = nullptr) {
+    ASR_TRY(ensure_events(ctx));
+    Net net{ctx, {weights, num_weights}};
+    net.precision = prm->precision;
+    // f16x2: every activation buffer has a running maximum, kept by the kernels that write it (a concat buffer by both of its
+    // producers) and read by the ones that consume it -- feats1's by the continuous conv
+    unsigned* feats_amax = nullptr;
+    int rc = net.begin_amax();
+    if (rc == ASR_HIP_OK) {
+        feats_amax = net.new_amax();
+        rc = implicit_aggregate(ctx, points, normals, n, net, feats_amax);
+    }
+    if (!comm || comm->world <= 1) {
+        ASR_TRY(rc);
+        return network_unet_decode(ctx, net, prm, values_out, feats_amax);
+    }
+    ArenaMark m_scratch, m_persist;
+    arena_mark(ctx->scratch, m_scratch);
+    arena_mark(ctx->persist, m_persist);
+    const int amax_mark = net.num_amax;
+    if (rc == ASR_HIP_OK) {
+        ctx->dry_launch = true;
+        rc = network_unet_decode(ctx, net, prm, values_out, feats_amax);
+        ctx->dry_launch = false;
+    }
+    if (rc == ASR_HIP_OK && ctx->opt.inject_failure == 2) {
+        ctx->err = "injected failure (option inject_failure = 2)";
+        rc = ASR_HIP_ELOGIC;
+    }
+    ASR_TRY(asr_shard_agree(ctx, comm, rc, "network preparation"));
+    arena_rewind(ctx->scratch, m_scratch);
+    arena_rewind(ctx->persist, m_persist);
+    net.num_amax = amax_mark;
+    return network_unet_decode(ctx, net, prm, values_out, feats_amax);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1614,17 +1660,31 @@ int asr_hip_implicit_forward_sharded(asr_hip_context* ctx, const asr_shard_comm*
     // option shard_geometry: 0 = the whole cloud's geometry on every rank (overlapped search, as on one GPU), 1 = lists,
     // plans and search for the owned voxels only, -1 (default) = 1 whenever there is more than one rank
     const bool own_geometry = comm->world > 1 && (ctx->opt.shard_geometry > 0 || (ctx->opt.shard_geometry < 0 && comm->world >= 2));
+    // No rank may fail alone between two collectives (its peers would wait in ncclSend / ncclRecv for ever): the build has no
+    // collective, the ranks agree on its outcome, and the network prepares everything that can fail before its first
+    // exchange and agrees again (implicit_network, asr_shard_agree).
     asr_shard_state* st = nullptr;
+    int rc;
     if (own_geometry) {
-        ASR_TRY(implicit_build(ctx, points, radii, n, prm, comm, &st));
+        rc = implicit_build(ctx, points, radii, n, prm, comm, &st);
     } else {
-        ASR_TRY(implicit_build(ctx, points, radii, n, prm));
-        ASR_TRY(asr_shard_build(ctx, comm, prm->precision != 0 && ctx->opt.sconv_plan, &st));
+        rc = implicit_build(ctx, points, radii, n, prm);
+        if (rc == ASR_HIP_OK) rc = asr_shard_build(ctx, comm, prm->precision != 0 && ctx->opt.sconv_plan, &st);
+    }
+    if (rc == ASR_HIP_OK && ctx->opt.inject_failure == 1) {
+        ctx->err = "injected failure (option inject_failure = 1)";
+        rc = ASR_HIP_ELOGIC;
+    }
+    rc = asr_shard_agree(ctx, comm, rc, "geometry build");
+    if (rc != ASR_HIP_OK) {
+        if (st) asr_shard_free(st);
+        return rc;
     }
     if (sizes) *sizes = ctx->sizes;
     ctx->shard = st;
-    const int rc = implicit_network(ctx, points, normals, n, weights, num_weights, prm, values_out);
+    rc = implicit_network(ctx, points, normals, n, weights, num_weights, prm, values_out, comm);
     ctx->shard = nullptr;
+    ctx->dry_launch = false;
     if (stats) *stats = *asr_shard_get_stats(st);
     asr_shard_free(st);
     return rc;

@@ -26,6 +26,7 @@ struct Arena {
     };
     std::vector<Slab> slabs;
     size_t min_slab = size_t(256) << 20;
+    size_t cap = 0;  // option "arena_cap_mb": the arena never reserves more than this many bytes (0: no limit)
 
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~size_t(255);
@@ -37,6 +38,7 @@ struct Arena {
                 return p;
             }
         size_t sz = bytes > min_slab ? bytes : min_slab;
+        if (cap && reserved() + sz > cap) return nullptr;
         void* p = nullptr;
         if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
         slabs.push_back({(char*)p, sz, bytes});
@@ -119,6 +121,10 @@ struct AsrOptions {
     // tiles, the longest of which runs its 30 slots x cin / 32 steps alone on its CU): the slots are cut into five fixed
     // ranges, every (tile, range) is a block of its own, a second kernel adds the partial sums in range order.  The
     // choice depends on the input grid's size only, so that one rank of a sharded cloud makes the same one.
+    i64 arena_cap_mb = 0;         // > 0: each device arena of the context (results, scratch, shard state) stops growing at this
+                                  // many MiB and the call fails with "arena allocation failed" instead (memory budget per rank)
+    i64 inject_failure = 0;       // fault injection for the tests of the sharded forward's error agreement: 1 = the build of this
+                                  // rank fails, 2 = its network preparation fails (the call RETURNS AN ERROR, nothing is skipped)
     i64 sconv_split_min_rows = 2048;
     i64 sconv_split_rows = 32768;  // 0: never
 };
@@ -221,6 +227,7 @@ struct asr_hip_context {
     float* d_zeros = nullptr;  // 4 KB of zeros: target of masked-out loads
     float* split_part = nullptr;   // partial sums of the slot-range split of the 16-bit sparse conv (grown on demand)
     size_t split_part_bytes = 0;
+    unsigned* d_status = nullptr;  // sharded forward: the status word of asr_shard_agree
     unsigned* d_absmax = nullptr;  // f16x2: running maxima of the network's activation buffers; [255]: one-off inputs
     void* radius_state = nullptr;  // RadiusState of asr_geom.hip (between _count and _fill)
     void* mesh_state = nullptr;    // MeshState of asr_mesh.hip (between _count and _fill)
@@ -242,6 +249,9 @@ struct asr_hip_context {
     unsigned* shard_stage_recv = nullptr;
     size_t shard_stage_cap = 0;  // dwords each
     struct asr_shard_state* shard = nullptr;  // set while asr_hip_implicit_forward_sharded runs its network half
+    // preparation pass of the sharded network (asr_api.hip implicit_network, phase 1): every argument check, weight packing
+    // and allocation of a convolution happens, the kernel launch and the halo exchange do not
+    bool dry_launch = false;
 };
 
 #define ASR_FAIL(ctx, code, ...)                         \
@@ -355,6 +365,9 @@ int asr_shard_rank(const asr_shard_state* st);
 void asr_shard_free(asr_shard_state* st);
 void asr_shard_release(asr_hip_context* ctx);  // the context's shard arena and staging buffers
 const asr_shard_stats* asr_shard_get_stats(const asr_shard_state* st);
+// all ranks learn whether ANY rank failed so far (one MAX all-reduce of a status word): rc_local when this rank failed,
+// ASR_HIP_EPEER when only others did, ASR_HIP_OK when nobody did
+int asr_shard_agree(asr_hip_context* ctx, const asr_shard_comm* comm, int rc_local, const char* phase);
 int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void* rs, void* feat, i64 ld_bytes, i64 row_bytes,
                           float* imp, unsigned* in_amax, const int32_t** perm, i64* num_out, const asr_conv_plan** plan);
 int asr_shard_stitch(asr_hip_context* ctx, asr_shard_state* st, float* values);

@@ -727,7 +727,11 @@ __global__ __launch_bounds__(1024) void k_cconv_heavy4_items(const i64* __restri
     const int n = cnt[0], t = threadIdx.x;
     // The list comes out of atomics in no particular order, so whether a row is cut must not depend on its position in it
     // (a cut row is summed segment by segment: other bits than the same row kept whole): ALL rows of more than one segment are
-    // cut when their slots fit together, none otherwise -- one decision per list, the same on every run and on every rank.
+    // cut when their slots fit together, none otherwise -- one decision per LAUNCH, the same on every run.  (A rank of a
+    // sharded cloud lists its own rows only: its decision equals the one-GPU run's as long as the long rows of the WHOLE
+    // cloud fit the CCH_CAP slots, i.e. below CCH_CAP x CCH_SEG = 6.7e7 pairs in rows of more than one segment -- 2.1e6 at
+    // 10 M points, 1.7e7 at 80 M.  Beyond that the one-GPU run keeps the rows whole while a rank may still cut them, and
+    // the two differ in summation order, within the tolerance, not in bits.)
     __shared__ long long s_total;
     if (t == 0) {
         s_carry[0] = s_carry[1] = 0;
@@ -1605,6 +1609,7 @@ int asr_conv_sparse(asr_hip_context* ctx, const asr_sparse_conv_args* pa) {
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "sparse_conv: MFMA path needs cout %% 4 == 0");
     const float* zeros = nullptr;
     ASR_TRY(asr_ctx_zeros(ctx, &zeros));
+    if (ctx->dry_launch) return ASR_HIP_OK;  // preparation pass of the sharded network: checked and allocated, not launched
     const bool imp = a.inp_importance || a.neighbors_importance;
     const bool dual = a.filters_b != nullptr;
     const int ctot = a.cout + (dual ? a.cout_b : 0);
@@ -1693,6 +1698,7 @@ int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const
     if (c > DEC_MAX || h1 > DEC_MAX || h2 > DEC_MAX || c < 1 || h1 < 1 || h2 < 1)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "decode_mlp: layer widths must be 1..64");
     size_t lds = sizeof(float) * (size_t)(h1 * c + h1 + h2 * h1 + h2 + 2 * h2);
+    if (ctx->dry_launch) return ASR_HIP_OK;
     if (c == 32 && h1 == 32 && h2 == 32 && ((uintptr_t)code % 16 == 0))
         k_decode_mfma<<<(unsigned)std::min<i64>((v + 63) / 64, 2048), 256, 0, ctx->stream>>>(code, v, w1, b1, w2, b2, w3, sizes, out);
     else

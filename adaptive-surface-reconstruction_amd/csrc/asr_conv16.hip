@@ -162,6 +162,9 @@ __device__ __forceinline__ void sconv16_split_f16x2(const u32x4& q0, const u32x4
 // MFMAs) and the small terms first.  IMP: everything goes to the per-slot accumulators tacc; DUAL: the last column
 // tile also feeds tacc[0] (bank b, scaled per row at the end of the slot).
 // ------------------------------------------------------------------------------------------
+#ifndef ASR_BF16X3_CHAIN
+#define ASR_BF16X3_CHAIN 0
+#endif
 template <int NT, int KC, int MODE, bool IMP, bool DUAL, int PLANES, int NJ>
 __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32x4* __restrict__ sb, f32x4 (&acc)[NT],
                                         f32x4 (&tacc)[IMP ? NT : 1], bool has_b, int ncol, int g) {
@@ -229,8 +232,22 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
                 if (IMP) {
                     ASR_SIX(tacc[nb])
                 } else {
+#if ASR_BF16X3_CHAIN
+                    // the six products of the step summed from ZERO, then ONE addition into the running sum: one fp32 rounding at
+                    // the accumulator's magnitude per step instead of six
+                    f32x4 t6 = {0.f, 0.f, 0.f, 0.f};
+                    ASR_SIX(t6)
+                    acc[nb] += t6;
+                    if (DUAL && has_b && nb == NT - 1) tacc[0] += t6;
+#if ASR_BF16X3_CHAIN == 2
+                    __builtin_amdgcn_sched_barrier(0);  // one temporary alive at a time (registers)
+#elif ASR_BF16X3_CHAIN == 3
+                    if (nb & 1) __builtin_amdgcn_sched_barrier(0);  // two temporaries alive at a time
+#endif
+#else
                     ASR_SIX(acc[nb])
                     if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
+#endif
                 }
 #undef ASR_SIX
             }
@@ -1216,6 +1233,7 @@ int asr_conv_sparse16(asr_hip_context* ctx, const asr_sparse_conv_args* pa, cons
         }
         spa.part = ctx->split_part;
     }
+    if (ctx->dry_launch) return ASR_HIP_OK;  // preparation pass of the sharded network: checked and allocated, not launched
 #define ASR_L16(NT_, KC_, W_, M_, I_, D_)                                                                        \
     {                                                                                                            \
         const i64 tiles_ = (a.num_out + W_ * 16 - 1) / (W_ * 16);                                                \

@@ -681,6 +681,7 @@ int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void*
     const i64 ns = c.send_first.back(), nr = c.recv_first.back();
     if (st->world == 1) return ASR_HIP_OK;
     if (ns == 0 && nr == 0) {  // no halo here, but the maximum is a collective: every rank takes part
+        if (ctx->dry_launch) return ASR_HIP_OK;
         if (in_amax && st->comm.allreduce_max_u32(st->comm.user, in_amax, 1, (void*)ctx->stream) != 0)
             ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the MAX all-reduce failed");
         return ASR_HIP_OK;
@@ -690,6 +691,7 @@ int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void*
     const int row_dwords = (int)(row_bytes / 4);
     const i64 per_row = row_dwords + (imp ? 1 : 0);
     ASR_TRY(shard_stage(ctx, st, (size_t)std::max(ns, nr) * per_row));
+    if (ctx->dry_launch) return ASR_HIP_OK;  // preparation pass: the staging buffers are sized, nothing travels
     PackDesc ds, dr;
     ds.npeer = (int)c.send_peer.size();
     dr.npeer = (int)c.recv_peer.size();
@@ -749,6 +751,35 @@ int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void*
     return ASR_HIP_OK;
 }
 
+// A failure on ONE rank between collectives would leave its peers inside ncclSend / ncclRecv for ever.  The sharded forward
+// therefore does everything that can fail for a reason of the rank's own -- the whole build (no collective in it), then the
+// preparation pass of the network (argument and weight checks, weight packing, every allocation incl. the staging buffers) --
+// BEFORE the first exchange, and the ranks agree on the outcome of each of the two parts with one MAX all-reduce of a
+// status word: if any rank failed, every rank returns (the failed ones their own error, the others ASR_HIP_EPEER).
+int asr_shard_agree(asr_hip_context* ctx, const asr_shard_comm* comm, int rc_local, const char* phase) {
+    if (!comm || comm->world <= 1) return rc_local;
+    const std::string own_err = ctx->err;  // (the calls below reuse the context's error text)
+    if (!ctx->d_status && hipMalloc((void**)&ctx->d_status, 256) != hipSuccess) {
+        ctx->d_status = nullptr;  // (this rank cannot take part: its peers wait -- nothing a rank without memory can do)
+        if (rc_local != ASR_HIP_OK) return rc_local;
+        ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: no memory for the status word");
+    }
+    unsigned* word = ctx->d_status;
+    unsigned status = rc_local != ASR_HIP_OK ? 1u : 0u;
+    bool ok = hipMemcpyAsync(word, &status, sizeof(status), hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    ok = ok && comm->allreduce_max_u32(comm->user, word, 1, (void*)ctx->stream) == 0;
+    unsigned any = 1;
+    ok = ok && hipMemcpyAsync(&any, word, sizeof(any), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (rc_local != ASR_HIP_OK) {
+        ctx->err = own_err;
+        return rc_local;
+    }
+    if (!ok) ASR_FAIL(ctx, ASR_HIP_EHIP, "sharded forward: the status all-reduce after the %s failed", phase);
+    if (any) ASR_FAIL(ctx, ASR_HIP_EPEER, "sharded forward: another rank failed in its %s; no rank goes on", phase);
+    return ASR_HIP_OK;
+}
+
 // values [V0, 2]: this rank's rows are valid; afterwards all rows are (all-gather of the owned rows)
 int asr_shard_stitch(asr_hip_context* ctx, asr_shard_state* st, float* values) {
     if (st->world == 1) return ASR_HIP_OK;
@@ -756,6 +787,7 @@ int asr_shard_stitch(asr_hip_context* ctx, asr_shard_state* st, float* values) {
     const i64 V0 = st->rows0_off[world];
     const i64 mine = st->rows0_off[me + 1] - st->rows0_off[me];
     ASR_TRY(shard_stage(ctx, st, (size_t)V0 * 2));
+    if (ctx->dry_launch) return ASR_HIP_OK;
     // my rows packed once, sent to every peer; the peers' rows land at their offsets of the grouped row list
     PackDesc dm;
     dm.npeer = 1;

@@ -47,23 +47,20 @@ Locked context_for(const at::Tensor& t) {
     }
     std::unique_lock<std::mutex> lock(dc->mu);
     auto stream = at::hip::getCurrentHIPStream(dev).stream();
-    if (!dc->ctx) {
-        c10::DeviceGuard guard(t.device());
+    c10::DeviceGuard guard(t.device());  // context, event and the record / wait below all belong to the tensor's device
+    const bool first_use = dc->ctx == nullptr;
+    if (first_use)
         TORCH_CHECK(asr_hip_context_create(&dc->ctx, stream) == ASR_HIP_OK, "asr_hip_context_create failed");
-    }
     // Threads on different streams share the context's scratch arena and flag pool: when the stream changes, the new stream
     // waits for everything the previous ops enqueued on the old one (ops are enqueued under the mutex, so an event recorded
-    // now is behind all of them).
-    if (dc->last_stream != stream) {
-        if (dc->switch_ev || hipEventCreateWithFlags(&dc->switch_ev, hipEventDisableTiming) == hipSuccess) {
-            c10::DeviceGuard guard(t.device());
-            {
-                TORCH_CHECK(hipEventRecord(dc->switch_ev, dc->last_stream) == hipSuccess, "hipEventRecord failed");
-                TORCH_CHECK(hipStreamWaitEvent(stream, dc->switch_ev, 0) == hipSuccess, "hipStreamWaitEvent failed");
-            }
-        }
-        dc->last_stream = stream;
+    // now is behind all of them).  Nothing to wait for on the first use.
+    if (!first_use && dc->last_stream != stream) {
+        if (!dc->switch_ev)
+            TORCH_CHECK(hipEventCreateWithFlags(&dc->switch_ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+        TORCH_CHECK(hipEventRecord(dc->switch_ev, dc->last_stream) == hipSuccess, "hipEventRecord failed");
+        TORCH_CHECK(hipStreamWaitEvent(stream, dc->switch_ev, 0) == hipSuccess, "hipStreamWaitEvent failed");
     }
+    dc->last_stream = stream;
     asr_hip_context_set_stream(dc->ctx, stream);
     return Locked{std::move(lock), dc->ctx};
 }

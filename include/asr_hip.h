@@ -31,6 +31,7 @@ extern "C" {
 #define ASR_HIP_ENODEV 3   /* no gfx950 device / extension not usable                   */
 #define ASR_HIP_ELOGIC 4   /* internal invariant violated (e.g. hash table overflow)    */
 #define ASR_HIP_EWEIGHT 5  /* weight table incomplete / wrong shape                     */
+#define ASR_HIP_EPEER 6    /* sharded forward: ANOTHER rank failed; every rank returns  */
 
 #define ASR_MAX_LEVEL 21      /* cpp/lib/octreebase.h:42                                  */
 #define ASR_NUM_GRIDS 5       /* cpp/lib/asr.cpp:156, models/v0/net_definitions_torch.py:403 */

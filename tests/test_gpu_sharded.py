@@ -267,3 +267,74 @@ def test_partial_build_of_a_sharded_forward_is_refused_by_the_standalone_entry_p
     v = pipe.network(pts, nrm, bb[0], bb[1])
     ref = ImplicitPipeline(synth.make_weights(4, seed=1), device=dev, precision="bf16x3").forward(pts, nrm, rad, bb[0], bb[1])
     assert torch.equal(v, ref)
+
+
+# ---- no rank fails alone (round 6): the ranks agree on the outcome of the build and of the network preparation ---------
+def _failing_worker(rank, world, port, how, bad_rank, out):
+    sys.path[:0] = [REPO, os.path.join(REPO, "adaptive-surface-reconstruction_amd"), os.path.join(REPO, "tests")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from asr_hip import shardcomm, synth
+    from asr_hip._lib import AsrHipError
+    from asr_hip.pipeline import ImplicitPipeline
+    pts, nrm = synth.scan_cloud(30000, seed=55, device=dev)
+    rad = synth.knn_radii_gpu(pts, 24)
+    bb = synth.bounding_box(pts, 0.1)
+    weights = synth.make_weights(2, seed=6)
+    pipe = ImplicitPipeline(weights, device=dev, precision="bf16x3")
+    comm = shardcomm.HostStagedComm()
+    good = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1]).clone()  # a healthy forward first
+    if rank == bad_rank:
+        if how == "arena":
+            pipe.ctx.set_option("arena_cap_mb", 1)  # no arena may grow any more: the first new slab fails
+        else:
+            pipe.ctx.set_option("inject_failure", 1 if how == "build" else 2)
+    if how == "arena":  # a cloud whose arrays do not fit the 256 MB slabs the first forward left behind
+        pts, nrm = synth.scan_cloud(1500000, seed=56, device=dev)
+        rad = synth.knn_radii_gpu(pts, 24)
+        bb = synth.bounding_box(pts, 0.1)
+    info = {"rank": rank, "error": None}
+    try:
+        pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1])
+    except AsrHipError as e:
+        info["error"] = str(e)
+    # the context and the communicator survive: the next forward (fault removed) is healthy and equals the first one
+    pipe.ctx.set_option("inject_failure", 0)
+    pipe.ctx.set_option("arena_cap_mb", 0)
+    if how != "arena":
+        again = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1])
+        info["recovered"] = bool(torch.equal(again, good))
+    else:
+        again = pipe.forward_sharded(comm, pts, nrm, rad, bb[0], bb[1])
+        info["recovered"] = bool(torch.isfinite(again).all())
+    out.put(info)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("how,bad_rank", [("build", 1), ("network", 0), ("arena", 1)])
+def test_library_sharded_forward_one_failing_rank_makes_every_rank_return(gpu, how, bad_rank):
+    """A rank that fails between two collectives would leave its peers inside ncclSend / ncclRecv.  The sharded forward does
+    everything that can fail locally BEFORE the first exchange -- the build, then the preparation pass of the network
+    (weights, packing, every allocation, staging buffers) -- and the ranks agree on each part's outcome with one MAX
+    all-reduce of a status word (asr_shard_agree).  Here one of two ranks fails in its build (injected), in its network
+    preparation (injected) or by exhausting its arena budget (option arena_cap_mb on a cloud that needs new slabs): BOTH
+    ranks return an error (the healthy one ASR_HIP_EPEER, code 6) instead of hanging, and the next forward works."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, how, bad_rank, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    infos = sorted([out.get(timeout=600) for _ in range(2)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    bad, other = infos[bad_rank], infos[1 - bad_rank]
+    assert bad["error"] is not None and other["error"] is not None, infos
+    assert "error 6" in other["error"] and "another rank failed" in other["error"], other
+    assert ("injected failure" in bad["error"]) if how != "arena" else ("allocation failed" in bad["error"]), bad
+    assert bad["recovered"] and other["recovered"], infos

@@ -1241,7 +1241,9 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
             // voxels in index order, which every rank therefore searches itself (no communication).
             ArenaMark before;
             arena_mark(sc->persist, before);
-            i64 prefix = std::min<i64>(g0.v, std::max<i64>(1024, g0.v / 8));
+            // (the first V0 pairs sit in the first few thousand rows -- the coarsest voxels have the longest rows; the number
+            // that sufficed last time is the next build's first guess)
+            i64 prefix = std::min<i64>(g0.v, ctx->shard_prefix_hint > 0 ? ctx->shard_prefix_hint : std::max<i64>(1024, g0.v / 256));
             for (;;) {
                 arena_rewind(sc->persist, before);
                 int32_t* qrows = nullptr;
@@ -1259,9 +1261,10 @@ int implicit_build(asr_hip_context* ctx, const float* points, const float* radii
                 ASR_HIP_CHECK(sc, hipMemcpyAsync(&prefix_pairs, ctx->agg_rs + prefix, sizeof(i64), hipMemcpyDeviceToHost, sc->stream));
                 ASR_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
                 if (prefix_pairs < g0.v && prefix < g0.v) {
-                    prefix = std::min<i64>(g0.v, 2 * prefix);
+                    prefix = std::min<i64>(g0.v, 4 * prefix);
                     continue;
                 }
+                ctx->shard_prefix_hint = prefix;
                 // (prefix == V0 and fewer pairs than voxels: implicit_network reports the reference's out-of-range indexing)
                 ctx->agg_rows = qrows;
                 ctx->agg_nq = nq;
@@ -1544,10 +1547,16 @@ int network_unet_decode(asr_hip_context* ctx, Net& net, const asr_implicit_param
         values = arena_alloc<float>(ctx->persist, 2 * (size_t)V0);
         if (!values) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     }
-    ASR_TRY(asr_conv_decode(ctx, code, V0, c_dec[0], w1->data, b1->data, (int)w1->shape[0], w2->data,
+    // sharded forward: the decoder runs over the rows this rank owns; the owners' rows are gathered
+    const int32_t* drows = nullptr;
+    i64 dn = V0;
+    if (ctx->shard && asr_shard_world(ctx->shard) > 1) {
+        drows = asr_shard_owned_rows0(ctx->shard, &dn);
+        if (!drows) dn = V0;
+    }
+    ASR_TRY(asr_conv_decode(ctx, code, dn, c_dec[0], w1->data, b1->data, (int)w1->shape[0], w2->data,
                             b2->data, (int)w2->shape[0], w3->data,
-                            prm->scale_sdf ? g[0].sizes : nullptr, values));
-    // sharded forward: the decoder ran over all rows, this rank's are the valid ones; the owners' rows are gathered
+                            prm->scale_sdf ? g[0].sizes : nullptr, values, drows));
     if (ctx->shard) ASR_TRY(asr_shard_stitch(ctx, ctx->shard, values));
     ctx->values = values;
     name_it(ctx, "values", values, 8 * (size_t)V0);

@@ -211,6 +211,7 @@ struct asr_hip_context {
     const float* agg_qcenters = nullptr;
     const float* agg_qsizes = nullptr;
     AsrPointIndex pindex;                // asr_geom_presort
+    i64 shard_prefix_hint = 0;           // rows of the importance prefix the last sharded build needed
     int search_extras = 0;               // pairs the last aligned search took from the rounding margin (diagnostic)
     int leaf_lmin = -1, leaf_lmax = -1;  // levels of the first / last leaf of the last octree
     float* values = nullptr;
@@ -371,6 +372,7 @@ int asr_shard_agree(asr_hip_context* ctx, const asr_shard_comm* comm, int rc_loc
 int asr_shard_before_conv(asr_hip_context* ctx, asr_shard_state* st, const void* rs, void* feat, i64 ld_bytes, i64 row_bytes,
                           float* imp, unsigned* in_amax, const int32_t** perm, i64* num_out, const asr_conv_plan** plan);
 int asr_shard_stitch(asr_hip_context* ctx, asr_shard_state* st, float* values);
+const int32_t* asr_shard_owned_rows0(const asr_shard_state* st, i64* n);  // grid-0 rows of this rank, ascending (world > 1)
 
 // internal entry points shared between translation units
 int asr_geom_point_keys(asr_hip_context* ctx, const asr_octree_frame* frame, const float* pts,
@@ -436,6 +438,7 @@ int asr_geom_radius_count(asr_hip_context* ctx, const asr_octree_frame* frame, c
                           i64* num_pairs, Arena* keep = nullptr, const float* radii = nullptr,
                           const u64* voxel_keys = nullptr, int lmin_hint = -1, int lmax_hint = -1,
                           const AsrPointIndex* pre = nullptr);
+
 int asr_geom_radius_fill(asr_hip_context* ctx, const float* pts, const float* radii, i64 n,
                          const float* centers, const float* sizes, i64 v, const i64* rs,
                          int32_t* idx, float* dist, float* compat, int32_t* spos = nullptr,
@@ -495,4 +498,4 @@ int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gi
                     i64 rows, float* out);
 int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const float* w1,
                     const float* b1, int h1, const float* w2, const float* b2, int h2,
-                    const float* w3, const float* sizes, float* out);
+                    const float* w3, const float* sizes, float* out, const int32_t* rows = nullptr);  // rows: v listed rows

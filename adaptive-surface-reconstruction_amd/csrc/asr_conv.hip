@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, 
                                                 const float* __restrict__ b2, int h2_,
                                                 const float* __restrict__ w3,
                                                 const float* __restrict__ sizes,
-                                                float* __restrict__ out) {
+                                                float* __restrict__ out, const int32_t* __restrict__ rows = nullptr) {
     const int c = CT ? CT : c_, h1 = H1T ? H1T : h1_, h2 = H2T ? H2T : h2_;
     extern __shared__ float s_w[];
     float* sw1 = s_w;                 // [h1][c]   (shift columns dropped: shifts are zero)
@@ -1322,6 +1322,7 @@ __global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, 
     __syncthreads();
     i64 q = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     if (q >= v) return;
+    if (rows) q = rows[q];  // a row list instead of rows 0 .. v
     float x[CT ? CT : DEC_MAX], f1[H1T ? H1T : DEC_MAX];
     if (CT) {
 #pragma unroll
@@ -1385,7 +1386,8 @@ __global__ __launch_bounds__(256) void k_decode(const float* __restrict__ code, 
 __global__ __launch_bounds__(256) void k_decode_mfma(const float* __restrict__ code, i64 v, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
                                                      const float* __restrict__ b2, const float* __restrict__ w3,
-                                                     const float* __restrict__ sizes, float* __restrict__ out) {
+                                                     const float* __restrict__ sizes, float* __restrict__ out,
+                                                     const int32_t* __restrict__ rows) {  // rows: a row list instead of 0 .. v
     constexpr int C = 32, LD = 36;
     __shared__ __attribute__((aligned(16))) float s_t[4][16][LD];
     const int lane = threadIdx.x & 63;
@@ -1410,10 +1412,11 @@ __global__ __launch_bounds__(256) void k_decode_mfma(const float* __restrict__ c
     const i64 wave0 = (i64)blockIdx.x * 4 + wave, nwaves = (i64)gridDim.x * 4;
     float (*st)[LD] = s_t[wave];
     auto load_rows = [&](i64 grp, float4& t0, float4& t1) __attribute__((always_inline)) {
-        const i64 q = grp * 16 + n;
+        i64 q = grp * 16 + n;
         t0 = make_float4(0.f, 0.f, 0.f, 0.f);
         t1 = t0;
         if (grp < groups && q < v) {
+            if (rows) q = rows[q];
             t0 = *reinterpret_cast<const float4*>(code + q * C + 8 * kk);
             t1 = *reinterpret_cast<const float4*>(code + q * C + 8 * kk + 4);
         }
@@ -1452,8 +1455,11 @@ __global__ __launch_bounds__(256) void k_decode_mfma(const float* __restrict__ c
         if (n < 2) {  // o[i] = out[voxel 4 kk + i][n]
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const i64 vox = grp * 16 + 4 * kk + i;
-                if (vox < v) out[2 * vox + n] = (n == 0 && sizes) ? o[i] * sizes[vox] : o[i];
+                i64 vox = grp * 16 + 4 * kk + i;
+                if (vox < v) {
+                    if (rows) vox = rows[vox];
+                    out[2 * vox + n] = (n == 0 && sizes) ? o[i] * sizes[vox] : o[i];
+                }
             }
         }
     }
@@ -1693,17 +1699,17 @@ int asr_conv_reduce(asr_hip_context* ctx, const float* values, const int32_t* gi
 
 int asr_conv_decode(asr_hip_context* ctx, const float* code, i64 v, int c, const float* w1,
                     const float* b1, int h1, const float* w2, const float* b2, int h2,
-                    const float* w3, const float* sizes, float* out) {
+                    const float* w3, const float* sizes, float* out, const int32_t* rows) {
     if (v <= 0) return ASR_HIP_OK;
     if (c > DEC_MAX || h1 > DEC_MAX || h2 > DEC_MAX || c < 1 || h1 < 1 || h2 < 1)
         ASR_FAIL(ctx, ASR_HIP_EINVAL, "decode_mlp: layer widths must be 1..64");
     size_t lds = sizeof(float) * (size_t)(h1 * c + h1 + h2 * h1 + h2 + 2 * h2);
     if (ctx->dry_launch) return ASR_HIP_OK;
     if (c == 32 && h1 == 32 && h2 == 32 && ((uintptr_t)code % 16 == 0))
-        k_decode_mfma<<<(unsigned)std::min<i64>((v + 63) / 64, 2048), 256, 0, ctx->stream>>>(code, v, w1, b1, w2, b2, w3, sizes, out);
+        k_decode_mfma<<<(unsigned)std::min<i64>((v + 63) / 64, 2048), 256, 0, ctx->stream>>>(code, v, w1, b1, w2, b2, w3, sizes, out, rows);
     else
         k_decode<0, 0, 0><<<grid_for(v, 256), 256, lds, ctx->stream>>>(code, v, c, w1, b1, h1, w2, b2, h2, w3,
-                                                                       sizes, out);
+                                                                       sizes, out, rows);
     ASR_CHECK_LAUNCH(ctx);
     return ASR_HIP_OK;
 }

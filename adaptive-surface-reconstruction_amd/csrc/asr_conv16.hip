@@ -162,12 +162,17 @@ __device__ __forceinline__ void sconv16_split_f16x2(const u32x4& q0, const u32x4
 // MFMAs) and the small terms first.  IMP: everything goes to the per-slot accumulators tacc; DUAL: the last column
 // tile also feeds tacc[0] (bank b, scaled per row at the end of the slot).
 // ------------------------------------------------------------------------------------------
+// -DASR_BF16X3_CHAIN=4 (build-time, off): bf16x3 with a SECOND accumulator for the five small products of a step, added once in
+// the epilogue.  The default chain rounds the large running sum six times per (slot, panel) step, which is where bf16x3's
+// error comes from (scripts/split_error_study.py: rms error of `values` 2.1e-7 of the range -> 6.3e-8, below the
+// exact-f32 kernel's 1.9e-7); it costs 32 registers on the 128-column instances = two blocks per CU instead of three,
+// U-Net 26.4 -> 27.5 ms at 10 M points, so the default stays the single chain.
 #ifndef ASR_BF16X3_CHAIN
 #define ASR_BF16X3_CHAIN 0
 #endif
 template <int NT, int KC, int MODE, bool IMP, bool DUAL, int PLANES, int NJ>
 __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32x4* __restrict__ sb, f32x4 (&acc)[NT],
-                                        f32x4 (&tacc)[IMP ? NT : 1], bool has_b, int ncol, int g) {
+                                        f32x4 (&tacc)[IMP ? NT : 1], bool has_b, int ncol, int g, f32x4 (&lo)[NT]) {
     constexpr int SLOTS = KC / 8;
     constexpr int PLANE_PIECES = NT * 16 * SLOTS;
 #pragma unroll
@@ -232,18 +237,21 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
                 if (IMP) {
                     ASR_SIX(tacc[nb])
                 } else {
-#if ASR_BF16X3_CHAIN
-                    // the six products of the step summed from ZERO, then ONE addition into the running sum: one fp32 rounding at
-                    // the accumulator's magnitude per step instead of six
-                    f32x4 t6 = {0.f, 0.f, 0.f, 0.f};
-                    ASR_SIX(t6)
-                    acc[nb] += t6;
-                    if (DUAL && has_b && nb == NT - 1) tacc[0] += t6;
-#if ASR_BF16X3_CHAIN == 2
-                    __builtin_amdgcn_sched_barrier(0);  // one temporary alive at a time (registers)
-#elif ASR_BF16X3_CHAIN == 3
-                    if (nb & 1) __builtin_amdgcn_sched_barrier(0);  // two temporaries alive at a time
-#endif
+#if ASR_BF16X3_CHAIN == 4
+                    // the five small products (2^-8 and 2^-16 of the leading one) go to a second accumulator that is added
+                    // ONCE, in the epilogue: one fp32 rounding at the running sum's magnitude per step instead of six
+                    {
+                        const bf16x8 b2 = __builtin_bit_cast(bf16x8, sb[2 * PLANE_PIECES + piece]);
+                        lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b2, lo[nb], 0, 0, 0);
+                        const bf16x8 b1 = __builtin_bit_cast(bf16x8, sb[PLANE_PIECES + piece]);
+                        lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, lo[nb], 0, 0, 0);
+                        lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, lo[nb], 0, 0, 0);
+                        const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[piece]);
+                        lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b0, lo[nb], 0, 0, 0);
+                        lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, lo[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[nb], 0, 0, 0);
+                    }
+                    if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
 #else
                     ASR_SIX(acc[nb])
                     if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
@@ -443,6 +451,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
     bmask &= (1ull << K) - 1;
 
     f32x4 acc[NT];
+    f32x4 lo[NT];  // (ASR_BF16X3_CHAIN == 4: the small products' accumulator; unused and removed otherwise)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) lo[t] = {0.f, 0.f, 0.f, 0.f};
     f32x4 tacc[IMP ? NT : 1];  // per-slot accumulators of the importance-weighted bank
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
@@ -613,7 +624,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
         if (active) {
             const u32x4* sb = s_B[buf];
             __builtin_amdgcn_s_setprio(1);
-            sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa, sb, acc, tacc, has_b, ncol, g);
+            sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa, sb, acc, tacc, has_b, ncol, g, lo);
             __builtin_amdgcn_s_setprio(0);
             // end of a slot: scale the slot's importance-weighted products per row and fold them in
             if ((IMP || DUAL) && p_cur == npanel - 1) {
@@ -654,6 +665,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
         rows4[i] = s_row[wave * 16 + 4 * g + i];
         norms4[i] = s_norm[wave * 16 + 4 * g + i];
     }
+#if ASR_BF16X3_CHAIN == 4
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) acc[nb] += lo[nb];
+#endif
     sconv16_epilogue<NT, MODE, DUAL>(a, acc, acc_b, rows4, norms4, n0, ncol, ca, cout, has_b, out_f16, zeros, unscale);
     if (a.out_importance && ychunk == 0 && tid < TM && s_row[tid] >= 0)
         a.out_importance[s_row[tid]] = s_norm[tid];
@@ -771,6 +786,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     }
 
     f32x4 acc[NT];
+    f32x4 lo[NT];  // (ASR_BF16X3_CHAIN == 4: the small products' accumulator; unused and removed otherwise)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) lo[t] = {0.f, 0.f, 0.f, 0.f};
     f32x4 tacc[IMP ? NT : 1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = {0.f, 0.f, 0.f, 0.f};
@@ -943,7 +961,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         if (active) {
             const u32x4* sb = BUF ? s_B1 : s_B0;
             __builtin_amdgcn_s_setprio(1);
-            sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa, sb, acc, tacc, has_b, ncol, g);
+            sconv16_products<NT, KC, MODE, IMP, DUAL, PLANES, NJ>(fa, sb, acc, tacc, has_b, ncol, g, lo);
             __builtin_amdgcn_s_setprio(0);
             if (ROWW && roww && slot_end) {
 #pragma unroll
@@ -981,6 +999,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     }
 #undef ASR_SEQ_ADVANCE
 
+#if ASR_BF16X3_CHAIN == 4
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) acc[nb] += lo[nb];
+#endif
     // output rows of this lane's four accumulator rows (-1: beyond the list)
     int q4[4];
 #pragma unroll

@@ -412,7 +412,9 @@ int asr_shard_ownership(asr_hip_context* ctx, const asr_shard_comm* comm, int by
         if (!codes || !codes_s || !ids || !order || !w || !cum) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
         k_shard_codes<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(g[0].keys, V0, codes, ids);
         ASR_CHECK_LAUNCH(ctx);
-        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes, codes_s, ids, order, V0, 63)));
+        // (no leaf is finer than leaf_lmax: the low 3 (21 - leaf_lmax) bits of every code are zero -- fewer radix passes)
+        const int low = ctx->leaf_lmax >= 0 ? 3 * (ASR_MAX_LEVEL - std::min(ctx->leaf_lmax, ASR_MAX_LEVEL)) : 0;
+        ASR_TRY((sort_pairs<u64, int32_t>(ctx, ctx->scratch, codes, codes_s, ids, order, V0, 63, low)));
         if (by_pairs) {
             k_shard_weights<<<grid_for(V0, BLK), BLK, 0, ctx->stream>>>(order, g[0].nrs, V0, w);
             ASR_CHECK_LAUNCH(ctx);
@@ -665,6 +667,10 @@ int asr_shard_query_rows(asr_hip_context* ctx, const asr_shard_state* st, i64 pr
     return ASR_HIP_OK;
 }
 int asr_shard_rank(const asr_shard_state* st) { return st->rank; }
+const int32_t* asr_shard_owned_rows0(const asr_shard_state* st, i64* n) {
+    *n = st->rows0_off[st->rank + 1] - st->rows0_off[st->rank];
+    return st->rows0 ? st->rows0 + st->rows0_off[st->rank] : nullptr;
+}
 int asr_shard_world(const asr_shard_state* st) { return st->world; }
 
 // before a convolution over the list `rs`: the rows it computes (perm, num_out, plan), the halo exchange of its input and

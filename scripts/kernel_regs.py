@@ -17,21 +17,33 @@ def kernels(path):
         subprocess.check_call([LLVM + "clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                                "--input=" + fat, "--output=" + dev, "--unbundle"])
         notes = subprocess.check_output([LLVM + "llvm-readelf", "--notes", dev]).decode()
-    out, cur = [], {}
+    # amdhsa.kernels is a YAML list: an entry starts with "  - .agpr_count:" (keys in alphabetical order), argument entries
+    # with a deeper "      - ." -- the kernel entries are the "- ." items at the shallowest indentation after "amdhsa.kernels:"
+    out, cur, depth, inside = [], None, None, False
     for line in notes.splitlines():
-        m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)", line)
-        if not m:
+        if line.strip().startswith("amdhsa.kernels:"):
+            inside = True
             continue
-        k, v = m.group(1), m.group(2).strip()
-        if k == "name" and v.startswith("_Z") and not v.endswith(".kd"):
-            if cur:
-                out.append(cur)
-            cur = {"name": v}
+        if not inside:
+            continue
+        m = re.match(r"(\s*)(-\s+)?\.(\w+):\s*(.*)", line)
+        if not m:
+            if line.strip().startswith("amdhsa."):
+                inside = False
+            continue
+        ind, item, k, v = len(m.group(1)), m.group(2), m.group(3), m.group(4).strip()
+        if item and (depth is None or ind <= depth):
+            depth = ind
+            cur = {}
+            out.append(cur)
+        if cur is None or ind > depth + 2:
+            continue
+        if k == "name":
+            cur["name"] = v
         elif k in ("vgpr_count", "agpr_count", "sgpr_count", "group_segment_fixed_size", "private_segment_fixed_size",
-                   "vgpr_spill_count") and cur:
+                   "vgpr_spill_count"):
             cur[k] = int(v)
-    if cur:
-        out.append(cur)
+    out = [k for k in out if "name" in k]
     names = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in out).encode(),
                            stdout=subprocess.PIPE).stdout.decode().splitlines()
     for k, n in zip(out, names):

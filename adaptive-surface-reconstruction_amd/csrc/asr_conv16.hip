@@ -809,13 +809,38 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         unscale[1] = f16x2_pow2(un - un / 2);
     }
 
-#define ASR_SEQ_ADVANCE(todo, k, p)                          \
-    if ((k) >= 0 && ++(p) == npanel) {                       \
-        (p) = 0;                                             \
-        (todo) &= (todo)-1;                                  \
-        (k) = (todo) ? __builtin_ctzll(todo) : -1;           \
-    }
+    // The block walks its slots in ascending order.  Position i of that sequence ("ordinal") is what the loop carries;
+    // two per-wave registers map it back: lane i of v_seq holds the byte offset of the weight block of the i-th slot, lane i
+    // of v_off the byte offset of this wave's pool block for that slot, or OOB_OFF when the wave has no row in the slot (read
+    // with v_readlane -- the 64-bit mask arithmetic this replaces was a third of the loop's scalar instructions, and the
+    // scalar unit is what the 64- and 32-column instances of level 0 are short of; U-Net 26.4 -> 25.9 ms.  A third
+    // register would cost the 128- and 64-column instances a block per CU: 80 and 64 registers are the limits).
     constexpr unsigned OOB_OFF = 0xFFFFE000u;
+    const int nslots = __popcll(bmask);
+    const int panel_bytes = ctot_pad * KC * 2, slot_bytes = npanel * panel_bytes;
+    int v_seq, v_off;
+    {
+        const bool mine = lane < K && ((bmask >> lane) & 1);               // lane = slot number
+        const int ord = __popcll(bmask & ((1ull << lane) - 1));            // its position in the sequence
+        const bool has = (wmask >> lane) & 1;
+        const unsigned off = has ? (woff + (unsigned)__popcll(wmask_all & ((1ull << lane) - 1))) * 64u : OOB_OFF;
+        const int dst = (mine ? ord : 63) * 4;                            // (nslots <= 56: lane 63 is never an ordinal)
+        v_seq = __builtin_amdgcn_ds_permute(dst, lane * slot_bytes);
+        v_off = __builtin_amdgcn_ds_permute(dst, (int)off);
+        if (lane >= nslots) {  // beyond the sequence: a dummy weight block (never read), no pool block
+            v_seq = 0;
+            v_off = (int)OOB_OFF;
+        }
+    }
+    // next (ordinal, panel); runs on beyond the end of the sequence (at most two steps: the prefetch distance), where the
+    // tables answer "no slot"
+#define ASR_SEQ_ADVANCE(i, p)                   \
+    {                                           \
+        const int nx_ = (p) + 1;                \
+        const int wrap_ = nx_ == npanel ? 1 : 0; \
+        (p) = wrap_ ? 0 : nx_;                  \
+        (i) += wrap_;                           \
+    }
     constexpr int RSRC_FLAGS = 0x00020000;
     const __amdgpu_buffer_rsrc_t rs_w =
             __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, (int)(PLANES * plane_stride * 2), RSRC_FLAGS);
@@ -833,8 +858,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         const int pl = c / CHUNKS_PER_PLANE, ci = c % CHUNKS_PER_PLANE;
         w_soff[s] = (unsigned)((pl * plane_stride + (i64)n0 * KC) * 2 + ci * 1024);
     }
-    auto dma_panel = [&](const int qk, const int qp, auto bufc) __attribute__((always_inline)) {
-        const int soff = (((qk < 0 ? 0 : qk) * npanel + qp) * ctot_pad * KC) * 2;
+    auto dma_panel = [&](const int qi, const int qp, auto bufc) __attribute__((always_inline)) {
+        const int soff = __builtin_amdgcn_readlane(v_seq, qi & 63) + qp * panel_bytes;
         u32x4* dst = decltype(bufc)::value ? s_B1 : s_B0;
 #pragma unroll
         for (int s = 0; s < SV; ++s) {
@@ -847,35 +872,34 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     // neighbour index of this lane's row for slot k (wave-uniform k): one 64-byte block of the pool.  The load
     // is issued whether or not the wave has the slot (offset beyond the pool -> 0), so that every step has the
     // same sequence of memory instructions; has_slot() tells the two apart.
-    auto has_slot = [&](const int k) __attribute__((always_inline)) -> bool { return k >= 0 && ((wmask >> k) & 1); };
-    auto pool_off = [&](const int k) __attribute__((always_inline)) -> unsigned {
-        const int kk = k < 0 ? 0 : k;
-        return (woff + (unsigned)__popcll(wmask_all & ((1ull << kk) - 1))) * 64u;
+    // ordinal i (any value: lanes beyond the sequence hold OOB_OFF) -> the wave's pool block; the range check of a raw
+    // buffer looks at the VECTOR offset only, so a wave without the slot puts OOB_OFF there and gets zeros
+    // (a wave without the slot: OOB_OFF in the vector offset -> zeros, whatever the scalar offset)
+    auto lacks = [&](const int i) __attribute__((always_inline)) -> int {
+        return (unsigned)__builtin_amdgcn_readlane(v_off, i & 63) == OOB_OFF ? (int)OOB_OFF : 0;
     };
-    auto load_idx = [&](const int k) __attribute__((always_inline)) -> int {
-        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, has_slot(k) ? r * 4 : (int)OOB_OFF, (int)pool_off(k), 0);
+    auto load_idx = [&](const int i) __attribute__((always_inline)) -> int {
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, r * 4 + lacks(i), __builtin_amdgcn_readlane(v_off, i & 63), 0);
     };
-    auto load_idx4 = [&](const int k) __attribute__((always_inline)) -> u32x4 {  // rows 4 g .. 4 g + 3
-        return __builtin_amdgcn_raw_buffer_load_b128(rs_p, has_slot(k) ? g * 16 : (int)OOB_OFF, (int)pool_off(k), 0);
+    auto load_idx4 = [&](const int i) __attribute__((always_inline)) -> u32x4 {  // rows 4 g .. 4 g + 3
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_p, g * 16 + lacks(i), __builtin_amdgcn_readlane(v_off, i & 63), 0);
     };
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.inp_features, 0, (int)(unsigned)(a.num_inp > 0 ? ((a.num_inp - 1) * a.inp_ld + cin) * ESZ : 0),
             RSRC_FLAGS);
-    int cache_k = -2;
+    int cache_i = -2;
     unsigned cache_off = OOB_OFF;
     int pref_idx = -1;  // index for the slot after the one being gathered, in flight
     // (the launcher sends matrices of 4 GB and more and cin that is not a multiple of KC to k_sconv_mfma16)
-    auto gather_a = [&](const int qk, const int qp, u32x4 (&aq)[NJ * AW], const bool first) __attribute__((always_inline)) {
-        const bool sw = qk != cache_k;
+    auto gather_a = [&](const int qi, const int qp, u32x4 (&aq)[NJ * AW], const bool first) __attribute__((always_inline)) {
+        const bool sw = qi != cache_i;
         int idx = pref_idx;
-        if (first) idx = load_idx(qk);
-        const unsigned long long rest = qk < 0 ? 0ull : (bmask >> qk) >> 1;
-        const int kn = rest ? qk + 1 + __builtin_ctzll(rest) : -1;
+        if (first) idx = load_idx(qi);
         if (sw) {  // once per slot: take the prefetched index, prefetch the one of the slot after it
-            cache_k = qk;
-            const bool valid = has_slot(qk) && idx >= 0;
+            cache_i = qi;
+            const bool valid = lacks(qi) == 0 && idx >= 0;
             cache_off = valid ? (unsigned)idx * (unsigned)(a.inp_ld * ESZ) + (unsigned)(8 * g * ESZ) : OOB_OFF;
-            pref_idx = load_idx(kn);
+            pref_idx = load_idx(qi + 1);
         }
         const int soff = qp * KC * ESZ;
 #pragma unroll
@@ -890,14 +914,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     // block per CU (plain 8-wave instances: 80 registers -> three blocks of NT = 8; measured per layer)
     constexpr int DEPTH = (WAVES == 8 && !IMP && !DUAL) ? 1 : 2;
     u32x4 a_q0[NJ * AW], a_q1[DEPTH == 2 ? NJ * AW : 1];
-    unsigned long long todo1 = bmask;
-    int k_cur = bmask ? __builtin_ctzll(bmask) : -1, p_cur = 0;
-    int k1 = k_cur, p1 = 0;
-    ASR_SEQ_ADVANCE(todo1, k1, p1)
+    // (k_cur, k1, k2: ORDINALS of the slot of this step, the next one and the one after it; p_*: their panels)
+    int k_cur = 0, p_cur = 0;
+    int k1 = 0, p1 = 0;
+    ASR_SEQ_ADVANCE(k1, p1)
     u32x4 idx4_cur = {~0u, ~0u, ~0u, ~0u}, idx4_next = {~0u, ~0u, ~0u, ~0u};
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
-    if (k_cur >= 0) {
+    if (k_cur < nslots) {
         dma_panel(k_cur, p_cur, B0());
         if (ROWW && roww) idx4_next = load_idx4(k_cur);
         gather_a(k_cur, p_cur, a_q0, true);
@@ -909,12 +933,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     auto step = [&](u32x4 (&aq)[NJ * AW], auto bufc) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value;
         int k2 = k1, p2 = p1;
-        ASR_SEQ_ADVANCE(todo1, k2, p2)
+        ASR_SEQ_ADVANCE(k2, p2)
         // panel of the next step straight into the other LDS buffer (every wave is past the barrier that ended
         // its reads).  Issued before every other load of this step: the wait at the end of the step counts on it.
         dma_panel(k1, p1, std::integral_constant<int, BUF ^ 1>());
         __builtin_amdgcn_sched_barrier(0);
-        const bool active = (wmask >> k_cur) & 1;
+        const bool active = lacks(k_cur) == 0;
         float w4[4] = {0.f, 0.f, 0.f, 0.f};
         const bool slot_end = p_cur == npanel - 1;
         if (ROWW && roww) {
@@ -989,9 +1013,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         k1 = k2;
         p1 = p2;
     };
-    while (k_cur >= 0) {
+    while (k_cur < nslots) {
         step(a_q0, B0());
-        if (k_cur < 0) break;
+        if (k_cur >= nslots) break;
         if constexpr (DEPTH == 2)
             step(a_q1, B1());
         else

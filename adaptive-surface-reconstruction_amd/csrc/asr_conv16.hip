@@ -715,6 +715,9 @@ struct asr_split_args {
 //   * LDS holds only the two panel buffers, so three 8-wave blocks fit a CU.
 // Row weights (conv1b: importance of the neighbour) are read per (row, slot) through the plan as well.
 // ------------------------------------------------------------------------------------------
+#ifndef ASR_PLAN_LINEGATHER
+#define ASR_PLAN_LINEGATHER 1
+#endif
 template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4) void k_sconv_plan16(
         asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
@@ -736,6 +739,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     __shared__ __attribute__((aligned(16))) u32x4 s_B0[PV];
     __shared__ __attribute__((aligned(16))) u32x4 s_B1[PV];
     __shared__ unsigned long long s_wm[WAVES];
+    // LINE (whole-line gathers, see gather_a): the rows arrive as (row L >> 3, piece L & 7) and leave as operand fragments
+    // (row r, pieces 2 g, 2 g + 1) through 2 KB of LDS per wave; piece p of row q sits at column p ^ (q & 7), which makes
+    // both the ds_write_b128 and the ds_read_b128 conflict free
+    __shared__ __attribute__((aligned(16))) u32x4 s_stage[(ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && KC == 32 && (NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL)))) ? WAVES * 128 : 1];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -890,9 +897,44 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     int cache_i = -2;
     unsigned cache_off = OOB_OFF;
     int pref_idx = -1;  // index for the slot after the one being gathered, in flight
+    // LINE: whole-line gathers (round 6).  Lane L loads piece (L & 7) of rows (L >> 3) and 8 + (L >> 3): eight adjacent lanes
+    // cover one 128-byte line, one tag look-up per line instead of two half-line ones (the operand layout has lane (r, g) on
+    // bytes [32 g, 32 g + 32) of row r: the four lanes of a row take 64 of its line's 128 bytes per instruction), and the rows
+    // go through 2 KB of LDS per wave into the operand layout (s_stage).  The gather-bound instances of level 0 are bound by
+    // the L1's request rate, not by bytes or latency: a 4-byte touch of the next slot's rows made them 11-18 % SLOWER, the
+    // whole-line addressing alone (wrong operands, no transpose) 16 % faster.  Kept where it wins in the same-box A/B: the
+    // 32-column instances (2 367 -> 2 150 us for the four decoder layers of level 0) and the two-bank 64-column one (912 ->
+    // 877 us); the plain 64-column instance needs 70 registers with it (three blocks per CU instead of four: +1 %), the 128-
+    // column ones are MFMA bound and lose a block as well (+6 %).
+    constexpr bool LINE = ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && NJ == 1 && AW == 2 && (NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL)));
+    unsigned cache_off1 = OOB_OFF;
+    int pref_idx1 = -1;
+    const int lrow = lane >> 3, lpiece = lane & 7;
+    auto load_idx_row = [&](const int i, const int row) __attribute__((always_inline)) -> int {
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(rs_p, row * 4 + lacks(i), __builtin_amdgcn_readlane(v_off, i & 63), 0);
+    };
     // (the launcher sends matrices of 4 GB and more and cin that is not a multiple of KC to k_sconv_mfma16)
     auto gather_a = [&](const int qi, const int qp, u32x4 (&aq)[NJ * AW], const bool first) __attribute__((always_inline)) {
         const bool sw = qi != cache_i;
+        if constexpr (LINE) {
+            int idx0 = pref_idx, idx1 = pref_idx1;
+            if (first) {
+                idx0 = load_idx_row(qi, lrow);
+                idx1 = load_idx_row(qi, 8 + lrow);
+            }
+            if (sw) {
+                cache_i = qi;
+                const bool has = lacks(qi) == 0;
+                cache_off = has && idx0 >= 0 ? (unsigned)idx0 * (unsigned)(a.inp_ld * ESZ) + (unsigned)(lpiece * 16) : OOB_OFF;
+                cache_off1 = has && idx1 >= 0 ? (unsigned)idx1 * (unsigned)(a.inp_ld * ESZ) + (unsigned)(lpiece * 16) : OOB_OFF;
+                pref_idx = load_idx_row(qi + 1, lrow);
+                pref_idx1 = load_idx_row(qi + 1, 8 + lrow);
+            }
+            const int soff = qp * KC * ESZ;
+            aq[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off, soff, 0);
+            aq[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off1, soff, 0);
+            return;
+        }
         int idx = pref_idx;
         if (first) idx = load_idx(qi);
         if (sw) {  // once per slot: take the prefetched index, prefetch the one of the slot after it
@@ -954,6 +996,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         }
         u32x4 fa[NJ][PLANES];
         if (active) {
+            if constexpr (LINE) {
+                u32x4* st = s_stage + wave * 128;
+                const int wcol = lpiece ^ (lrow & 7);
+                st[lrow * 8 + wcol] = aq[0];
+                st[(8 + lrow) * 8 + wcol] = aq[1];
+                __builtin_amdgcn_wave_barrier();  // (LDS operations of a wave complete in order)
+                aq[0] = st[r * 8 + ((2 * g) ^ (r & 7))];
+                aq[1] = st[r * 8 + ((2 * g + 1) ^ (r & 7))];
+                __builtin_amdgcn_wave_barrier();
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if constexpr (MODE == ASR_CONV16_F16) {

@@ -718,6 +718,9 @@ struct asr_split_args {
 #ifndef ASR_PLAN_LINEGATHER
 #define ASR_PLAN_LINEGATHER 1
 #endif
+#ifndef ASR_PLAN_LINEDMA
+#define ASR_PLAN_LINEDMA 1
+#endif
 template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4) void k_sconv_plan16(
         asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
@@ -738,11 +741,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     // two separate arrays: the compiler then knows that a panel DMA into one does not feed reads of the other
     __shared__ __attribute__((aligned(16))) u32x4 s_B0[PV];
     __shared__ __attribute__((aligned(16))) u32x4 s_B1[PV];
-    __shared__ unsigned long long s_wm[WAVES];
+    // (LDMA: the eight mask words live in the tail of the second panel buffer, which no DMA writes before the barrier that ends
+    // the prologue -- 4 blocks x 40 960 bytes are exactly the CU's 160 KB)
+    constexpr bool LDMA_ = ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && KC == 32 && (ASR_PLAN_LINEDMA && NT <= 4 && WAVES == 8 && !IMP && !DUAL);
+    __shared__ unsigned long long s_wm_own[LDMA_ ? 1 : WAVES];
+    unsigned long long* const s_wm = LDMA_ ? reinterpret_cast<unsigned long long*>(&s_B1[PV - 4]) : s_wm_own;
     // LINE (whole-line gathers, see gather_a): the rows arrive as (row L >> 3, piece L & 7) and leave as operand fragments
     // (row r, pieces 2 g, 2 g + 1) through 2 KB of LDS per wave; piece p of row q sits at column p ^ (q & 7), which makes
     // both the ds_write_b128 and the ds_read_b128 conflict free
-    __shared__ __attribute__((aligned(16))) u32x4 s_stage[(ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && KC == 32 && (NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL)))) ? WAVES * 128 : 1];
+    __shared__ __attribute__((aligned(16))) u32x4 s_stage[(ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && KC == 32 && ((NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL))) || (ASR_PLAN_LINEDMA && NT <= 4 && WAVES == 8 && !IMP && !DUAL))) ? WAVES * 128 : 1];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -906,7 +913,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     // 32-column instances (2 367 -> 2 150 us for the four decoder layers of level 0) and the two-bank 64-column one (912 ->
     // 877 us); the plain 64-column instance needs 70 registers with it (three blocks per CU instead of four: +1 %), the 128-
     // column ones are MFMA bound and lose a block as well (+6 %).
-    constexpr bool LINE = ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && NJ == 1 && AW == 2 && (NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL)));
+    constexpr bool LDMA = ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && NJ == 1 && AW == 2 && (ASR_PLAN_LINEDMA && NT <= 4 && WAVES == 8 && !IMP && !DUAL);
+    constexpr bool LINE = LDMA || (ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && NJ == 1 && AW == 2 && (NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL))));
+    // LDMA (plain 8-wave instances, gathers one step ahead): the two whole-line gathers are buffer_load ... lds, i.e. the rows
+    // go HBM -> LDS without passing through registers (lane L fetches piece (L & 7) ^ (row & 7) so that it lands in the
+    // swizzled column), eight registers fewer than the register form: the 64-column instance keeps four blocks per CU
     unsigned cache_off1 = OOB_OFF;
     int pref_idx1 = -1;
     const int lrow = lane >> 3, lpiece = lane & 7;
@@ -925,14 +936,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
             if (sw) {
                 cache_i = qi;
                 const bool has = lacks(qi) == 0;
-                cache_off = has && idx0 >= 0 ? (unsigned)idx0 * (unsigned)(a.inp_ld * ESZ) + (unsigned)(lpiece * 16) : OOB_OFF;
-                cache_off1 = has && idx1 >= 0 ? (unsigned)idx1 * (unsigned)(a.inp_ld * ESZ) + (unsigned)(lpiece * 16) : OOB_OFF;
+                const int pc = LDMA ? (lpiece ^ (lrow & 7)) : lpiece;  // (LDMA: the swizzle is applied on the source side)
+                cache_off = has && idx0 >= 0 ? (unsigned)idx0 * (unsigned)(a.inp_ld * ESZ) + (unsigned)(pc * 16) : OOB_OFF;
+                cache_off1 = has && idx1 >= 0 ? (unsigned)idx1 * (unsigned)(a.inp_ld * ESZ) + (unsigned)(pc * 16) : OOB_OFF;
                 pref_idx = load_idx_row(qi + 1, lrow);
                 pref_idx1 = load_idx_row(qi + 1, 8 + lrow);
             }
             const int soff = qp * KC * ESZ;
-            aq[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off, soff, 0);
-            aq[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off1, soff, 0);
+            if constexpr (LDMA) {  // lane L's 16 bytes land at stage + 16 L: rows 0 .. 7, then rows 8 .. 15
+                u32x4* st = s_stage + wave * 128;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)st, 16, (int)cache_off, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(st + 64), 16, (int)cache_off1, soff, 0, 0);
+            } else {
+                aq[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off, soff, 0);
+                aq[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)cache_off1, soff, 0);
+            }
             return;
         }
         int idx = pref_idx;
@@ -976,9 +994,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         constexpr int BUF = decltype(bufc)::value;
         int k2 = k1, p2 = p1;
         ASR_SEQ_ADVANCE(k2, p2)
+        if constexpr (LDMA) {
+            // the rows of THIS step were the last two loads of the previous one: they have landed when nothing is in flight;
+            // they leave the stage (into aq) before the next step's rows are sent into it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const u32x4* st = s_stage + wave * 128;
+            aq[0] = st[r * 8 + ((2 * g) ^ (r & 7))];
+            aq[1] = st[r * 8 + ((2 * g + 1) ^ (r & 7))];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         // panel of the next step straight into the other LDS buffer (every wave is past the barrier that ended
         // its reads).  Issued before every other load of this step: the wait at the end of the step counts on it.
         dma_panel(k1, p1, std::integral_constant<int, BUF ^ 1>());
+        if constexpr (LDMA) gather_a(k1, p1, aq, false);  // (into the stage: the registers of this step's rows are untouched)
         __builtin_amdgcn_sched_barrier(0);
         const bool active = lacks(k_cur) == 0;
         float w4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -996,7 +1024,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         }
         u32x4 fa[NJ][PLANES];
         if (active) {
-            if constexpr (LINE) {
+            if constexpr (LINE && !LDMA) {
                 u32x4* st = s_stage + wave * 128;
                 const int wcol = lpiece ^ (lrow & 7);
                 st[lrow * 8 + wcol] = aq[0];
@@ -1032,7 +1060,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         }
         if constexpr (DEPTH == 2)
             gather_a(k2, p2, aq, false);
-        else
+        else if constexpr (!LDMA)
             gather_a(k1, p1, aq, false);
         if (active) {
             const u32x4* sb = BUF ? s_B1 : s_B0;

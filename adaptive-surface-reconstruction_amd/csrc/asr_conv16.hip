@@ -721,6 +721,21 @@ struct asr_split_args {
 #ifndef ASR_PLAN_LINEDMA
 #define ASR_PLAN_LINEDMA 1
 #endif
+#ifndef ASR_PLAN_LDMA_DUAL
+#define ASR_PLAN_LDMA_DUAL 1
+#endif
+// which instances of k_sconv_plan16 gather whole lines (see gather_a): by LDS DMA (gathers one step ahead) or through registers
+// and an LDS transpose
+template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
+constexpr bool plan_ldma() {
+    return ASR_PLAN_LINEGATHER && ASR_PLAN_LINEDMA && MODE != ASR_CONV16_F16 && KC == 32 && WAVES == 8 &&
+           ((!IMP && !DUAL && NT <= 4) || (ASR_PLAN_LDMA_DUAL && (IMP || DUAL)));
+}
+template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
+constexpr bool plan_line() {
+    return plan_ldma<NT, KC, WAVES, MODE, IMP, DUAL>() ||
+           (ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && KC == 32 && (NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL))));
+}
 template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL, bool SPLIT = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) ? 2 : 3) : 4) void k_sconv_plan16(
         asr_sparse_conv_args a, asr_conv_plan_view plan, const u16* __restrict__ packed, int cin_pad, int ctot_pad, int out_f16,
@@ -743,13 +758,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     __shared__ __attribute__((aligned(16))) u32x4 s_B1[PV];
     // (LDMA: the eight mask words live in the tail of the second panel buffer, which no DMA writes before the barrier that ends
     // the prologue -- 4 blocks x 40 960 bytes are exactly the CU's 160 KB)
-    constexpr bool LDMA_ = ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && KC == 32 && (ASR_PLAN_LINEDMA && NT <= 4 && WAVES == 8 && !IMP && !DUAL);
+    constexpr bool LDMA_ = plan_ldma<NT, KC, WAVES, MODE, IMP, DUAL>();
     __shared__ unsigned long long s_wm_own[LDMA_ ? 1 : WAVES];
     unsigned long long* const s_wm = LDMA_ ? reinterpret_cast<unsigned long long*>(&s_B1[PV - 4]) : s_wm_own;
     // LINE (whole-line gathers, see gather_a): the rows arrive as (row L >> 3, piece L & 7) and leave as operand fragments
     // (row r, pieces 2 g, 2 g + 1) through 2 KB of LDS per wave; piece p of row q sits at column p ^ (q & 7), which makes
     // both the ds_write_b128 and the ds_read_b128 conflict free
-    __shared__ __attribute__((aligned(16))) u32x4 s_stage[(ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && KC == 32 && ((NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL))) || (ASR_PLAN_LINEDMA && NT <= 4 && WAVES == 8 && !IMP && !DUAL))) ? WAVES * 128 : 1];
+    __shared__ __attribute__((aligned(16))) u32x4 s_stage[plan_line<NT, KC, WAVES, MODE, IMP, DUAL>() ? WAVES * 128 : 1];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -908,13 +923,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
     // cover one 128-byte line, one tag look-up per line instead of two half-line ones (the operand layout has lane (r, g) on
     // bytes [32 g, 32 g + 32) of row r: the four lanes of a row take 64 of its line's 128 bytes per instruction), and the rows
     // go through 2 KB of LDS per wave into the operand layout (s_stage).  The gather-bound instances of level 0 are bound by
-    // the L1's request rate, not by bytes or latency: a 4-byte touch of the next slot's rows made them 11-18 % SLOWER, the
-    // whole-line addressing alone (wrong operands, no transpose) 16 % faster.  Kept where it wins in the same-box A/B: the
-    // 32-column instances (2 367 -> 2 150 us for the four decoder layers of level 0) and the two-bank 64-column one (912 ->
-    // 877 us); the plain 64-column instance needs 70 registers with it (three blocks per CU instead of four: +1 %), the 128-
-    // column ones are MFMA bound and lose a block as well (+6 %).
-    constexpr bool LDMA = ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && NJ == 1 && AW == 2 && (ASR_PLAN_LINEDMA && NT <= 4 && WAVES == 8 && !IMP && !DUAL);
-    constexpr bool LINE = LDMA || (ASR_PLAN_LINEGATHER && MODE != ASR_CONV16_F16 && NJ == 1 && AW == 2 && (NT <= 2 || (NT == 4 && WAVES == 8 && (IMP || DUAL))));
+    // the L1's REQUEST rate, not by bytes or latency: a 4-byte touch of the next slot's rows made them 11-18 % slower, the
+    // whole-line addressing alone (wrong operands, no transpose) 16 % faster.  Same-box A/B, level 0 at 10 M points: 64-column
+    // layers 3 885 -> 3 224 us (four launches), 32-column 2 367 -> 1 954 us, two-bank 64-column 912 -> 810 us; the two-bank
+    // 128-column instances of levels 1-2 -1 %.  Not for the plain 128-column instances: 64 KB of LDS = two blocks per CU instead
+    // of three on MFMA-bound layers (+8 %).
+    constexpr bool LDMA = plan_ldma<NT, KC, WAVES, MODE, IMP, DUAL>();
+    constexpr bool LINE = plan_line<NT, KC, WAVES, MODE, IMP, DUAL>();
     // LDMA (plain 8-wave instances, gathers one step ahead): the two whole-line gathers are buffer_load ... lds, i.e. the rows
     // go HBM -> LDS without passing through registers (lane L fetches piece (L & 7) ^ (row & 7) so that it lands in the
     // swizzled column), eight registers fewer than the register form: the 64-column instance keeps four blocks per CU
@@ -972,7 +987,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
 
     // Feature gathers run two steps ahead, or one step ahead where the eight registers that saves buy another
     // block per CU (plain 8-wave instances: 80 registers -> three blocks of NT = 8; measured per layer)
-    constexpr int DEPTH = (WAVES == 8 && !IMP && !DUAL) ? 1 : 2;
+    constexpr int DEPTH = ((WAVES == 8 && !IMP && !DUAL) || LDMA) ? 1 : 2;
     u32x4 a_q0[NJ * AW], a_q1[DEPTH == 2 ? NJ * AW : 1];
     // (k_cur, k1, k2: ORDINALS of the slot of this step, the next one and the one after it; p_*: their panels)
     int k_cur = 0, p_cur = 0;
@@ -1006,7 +1021,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         // panel of the next step straight into the other LDS buffer (every wave is past the barrier that ended
         // its reads).  Issued before every other load of this step: the wait at the end of the step counts on it.
         dma_panel(k1, p1, std::integral_constant<int, BUF ^ 1>());
-        if constexpr (LDMA) gather_a(k1, p1, aq, false);  // (into the stage: the registers of this step's rows are untouched)
+        // (into the stage: the registers of this step's rows are untouched.  The two-bank instances issue it after their
+        // importance loads, which this step still waits for: the gathers must be younger than those)
+        if constexpr (LDMA && !ROWW) gather_a(k1, p1, aq, false);
         __builtin_amdgcn_sched_barrier(0);
         const bool active = lacks(k_cur) == 0;
         float w4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1060,7 +1077,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
         }
         if constexpr (DEPTH == 2)
             gather_a(k2, p2, aq, false);
-        else if constexpr (!LDMA)
+        else if constexpr (!LDMA || ROWW)
             gather_a(k1, p1, aq, false);
         if (active) {
             const u32x4* sb = BUF ? s_B1 : s_B0;

@@ -166,6 +166,10 @@ def load():
             raise AsrHipError(
                 "libasr_hip.so not found at %s -- build it with __graft_entry__.build() or "
                 "`make -C adaptive-surface-reconstruction_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        # torch first: it ships its own HIP runtime, and a process that loads /opt/rocm's copy (through libasr_hip.so) BEFORE
+        # torch's ends up with two runtimes -- torch.cuda.is_available() turns False and hipGetDeviceCount fails in the library
+        # (ASR_HIP_ENODEV).  With torch loaded first the library binds to the runtime that is already there.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         lib.asr_hip_last_error.restype = ctypes.c_char_p
         lib.asr_hip_version.restype = ctypes.c_char_p

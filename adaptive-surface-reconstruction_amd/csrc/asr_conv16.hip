@@ -724,11 +724,18 @@ struct asr_split_args {
 #ifndef ASR_PLAN_LDMA_DUAL
 #define ASR_PLAN_LDMA_DUAL 1
 #endif
+#ifndef ASR_PLAN_LDMA_F16
+#define ASR_PLAN_LDMA_F16 8  // widest plain f16 instance (column tiles) with LDS-DMA gathers; 0: none
+#endif
 // which instances of k_sconv_plan16 gather whole lines (see gather_a): by LDS DMA (gathers one step ahead) or through registers
 // and an LDS transpose
 template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
 constexpr bool plan_ldma() {
-    return ASR_PLAN_LINEGATHER && ASR_PLAN_LINEDMA && MODE != ASR_CONV16_F16 && KC == 32 && WAVES == 8 &&
+    // (f16 activations, config C5: 64-deep panels of 2-byte elements are the same 128 bytes per row and step; the f16 panel
+    // buffers leave room for the stage at every width)
+    if (MODE == ASR_CONV16_F16)
+        return ASR_PLAN_LINEGATHER && ASR_PLAN_LINEDMA && ASR_PLAN_LDMA_F16 && KC == 64 && WAVES == 8 && (IMP || DUAL || NT <= ASR_PLAN_LDMA_F16);
+    return ASR_PLAN_LINEGATHER && ASR_PLAN_LINEDMA && KC == 32 && WAVES == 8 &&
            ((!IMP && !DUAL && NT <= 4) || (ASR_PLAN_LDMA_DUAL && (IMP || DUAL)));
 }
 template <int NT, int KC, int WAVES, int MODE, bool IMP, bool DUAL>
@@ -1014,8 +1021,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
             // they leave the stage (into aq) before the next step's rows are sent into it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const u32x4* st = s_stage + wave * 128;
-            aq[0] = st[r * 8 + ((2 * g) ^ (r & 7))];
-            aq[1] = st[r * 8 + ((2 * g + 1) ^ (r & 7))];
+            // f32 rows: the lane's eight values are pieces 2 g, 2 g + 1; f16 rows (two 32-deep halves): pieces g and 4 + g
+            aq[0] = st[r * 8 + ((MODE == ASR_CONV16_F16 ? g : 2 * g) ^ (r & 7))];
+            aq[1] = st[r * 8 + ((MODE == ASR_CONV16_F16 ? 4 + g : 2 * g + 1) ^ (r & 7))];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         // panel of the next step straight into the other LDS buffer (every wave is past the barrier that ended

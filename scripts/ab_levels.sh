@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   tag=$(basename $lib .so)
   out=/tmp/abl_$tag; rm -rf $out
-  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python $root/scripts/unet_time.py --lib $root/$lib --steps 3 > /tmp/abl_$tag.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python $root/scripts/unet_time.py --lib $root/$lib --steps 3 $ASR_AB_ARGS > /tmp/abl_$tag.log 2>&1
   t=$(find $out -name "*kernel_trace.csv" | head -1)
   python3 - "$t" "$tag" <<'PY'
 import csv, sys, collections

@@ -373,20 +373,25 @@ def test_plan_kernel_equals_table_kernel_on_random_lists(gpu, mode):
         n_rows = max(1, v // 2) if (use_rows and perm is not None) else None
         kw = dict(inp_importance=imp, normalize=imp is not None, relu=True, row_perm=perm, num_rows=n_rows)
         pk = ops.pack_filters(W, mode)
-        outs = []
-        for plan_on in (1, 0):
-            ctx.set_option("sconv_plan", plan_on)
-            ctx.sconv_variant_counts(reset=True)
-            out = torch.full((v, cout), -3.0, device=gpu)
-            ops.sparse_conv16(mode, pk, K, cin, cout, f, idx.to(torch.int32).to(gpu), slots.to(torch.uint8).to(gpu),
-                              rs.to(gpu), out=out, **kw)
-            assert list(ctx.sconv_variant_counts())[0][6] == plan_on
-            outs.append(out)
-        ctx.set_option("sconv_plan", 1)
-        if imp is None:
-            assert torch.equal(outs[0], outs[1]), case
-        else:
-            assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max())), case
+        # waves 0: the launcher's choice (4-wave blocks at these sizes: rows through registers); 8: the 8-wave instances, whose
+        # rows travel HBM -> LDS by DMA in whole lines (round 6) -- absent neighbours, padded strides and partial last tiles
+        # included
+        for waves in (0, 8):
+            outs = []
+            for plan_on in (1, 0):
+                ctx.set_option("sconv_plan", plan_on)
+                ctx.sconv_variant_counts(reset=True)
+                out = torch.full((v, cout), -3.0, device=gpu)
+                ops.sparse_conv16(mode, pk, K, cin, cout, f, idx.to(torch.int32).to(gpu), slots.to(torch.uint8).to(gpu),
+                                  rs.to(gpu), out=out, force_waves=waves, **kw)
+                key = list(ctx.sconv_variant_counts())[0]
+                assert key[6] == plan_on and (waves == 0 or key[3] == 8), key
+                outs.append(out)
+            ctx.set_option("sconv_plan", 1)
+            if imp is None:
+                assert torch.equal(outs[0], outs[1]), (case, waves)
+            else:
+                assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max())), (case, waves)
 
 
 def _rel(a, b, tol=2e-6):

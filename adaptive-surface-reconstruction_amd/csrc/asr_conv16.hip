@@ -159,8 +159,9 @@ __device__ __forceinline__ void sconv16_split_f16x2(const u32x4& q0, const u32x4
 // Products of one step, shared by the two kernels below: fa = the wave's A fragments of the step (f16: one per 32
 // k; bf16x3: the three exact bf16 terms of the gathered f32), sb = the step's weight panel in LDS.  bf16x3 evaluates
 // a*b as the six products a_i*b_j with i + j <= 2, one weight plane at a time (a B fragment lives for at most three
-// MFMAs) and the small terms first.  IMP: everything goes to the per-slot accumulators tacc; DUAL: the last column
-// tile also feeds tacc[0] (bank b, scaled per row at the end of the slot).
+// MFMAs) and the small terms first.  IMP: everything goes to the per-slot accumulators tacc; DUAL: the products of the last
+// column tile (bank a's last eight columns and bank b's eight) go to tacc[0] ONLY; at the end of the slot it is added to
+// acc[NT - 1] as it is (bank a) and, scaled per row by the importance, to acc_b (bank b) -- not a second chain of products.
 // ------------------------------------------------------------------------------------------
 // -DASR_BF16X3_CHAIN=4 (build-time, off): bf16x3 with a SECOND accumulator for the five small products of a step, added once in
 // the epilogue.  The default chain rounds the large running sum six times per (slot, panel) step, which is where bf16x3's
@@ -185,10 +186,10 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
                 const f16x8 bf = __builtin_bit_cast(f16x8, sb[col * SLOTS + swz<KC>(col, 4 * j + g)]);
                 if (IMP) {
                     tacc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[nb], 0, 0, 0);
+                } else if (DUAL && has_b && nb == NT - 1) {
+                    tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);  // (see the head comment)
                 } else {
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nb], 0, 0, 0);
-                    if (DUAL && has_b && nb == NT - 1)
-                        tacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, tacc[0], 0, 0, 0);
                 }
             }
         } else if constexpr (MODE == ASR_CONV16_F16X2) {
@@ -208,9 +209,10 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
     }
                 if (IMP) {
                     ASR_THREE(tacc[nb])
+                } else if (DUAL && has_b && nb == NT - 1) {
+                    ASR_THREE(tacc[0])
                 } else {
                     ASR_THREE(acc[nb])
-                    if (DUAL && has_b && nb == NT - 1) { ASR_THREE(tacc[0]) }
                 }
 #undef ASR_THREE
             }
@@ -238,6 +240,9 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
                     ASR_SIX(tacc[nb])
                 } else {
 #if ASR_BF16X3_CHAIN == 4
+                    if (DUAL && has_b && nb == NT - 1) {
+                        ASR_SIX(tacc[0])
+                    } else
                     // the five small products (2^-8 and 2^-16 of the leading one) go to a second accumulator that is added
                     // ONCE, in the epilogue: one fp32 rounding at the running sum's magnitude per step instead of six
                     {
@@ -251,10 +256,12 @@ __device__ inline void sconv16_products(const u32x4 (&fa)[NJ][PLANES], const u32
                         lo[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, lo[nb], 0, 0, 0);
                         acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[nb], 0, 0, 0);
                     }
-                    if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
 #else
-                    ASR_SIX(acc[nb])
-                    if (DUAL && has_b && nb == NT - 1) { ASR_SIX(tacc[0]) }
+                    if (DUAL && has_b && nb == NT - 1) {
+                        ASR_SIX(tacc[0])
+                    } else {
+                        ASR_SIX(acc[nb])
+                    }
 #endif
                 }
 #undef ASR_SIX
@@ -640,6 +647,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 3) void k_sconv_mfma16
                 } else if (has_b) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc_b[i] += w4[i] * tacc[0][i];
+                    acc[NT - 1] += tacc[0];  // bank a's columns of the shared tile: the slot's plain sums
                     tacc[0] = {0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -1105,6 +1113,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? (NT >= 8 && (IMP || DUAL) 
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc_b[i] += w4[i] * tacc[0][i];
+                    acc[NT - 1] += tacc[0];  // bank a's columns of the shared tile: the slot's plain sums
                     tacc[0] = {0.f, 0.f, 0.f, 0.f};
                 }
             }

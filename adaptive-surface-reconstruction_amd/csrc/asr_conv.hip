@@ -276,25 +276,37 @@ __global__ __launch_bounds__(1024, 8) void k_cconv(const float* __restrict__ fil
 //     3-4 voxels share one batch of 64 lanes: one index load, one record load, one coordinate transform and one LDS
 //     store per chunk instead of per voxel); a row of more than 64 pairs gets chunks of its own, cut at multiples of 64
 //     from the row start.  The index loads of chunk c+2 and the record loads of chunk c+1 are in flight while chunk c
-//     is accumulated (the row_splits -> index -> record chain is the latency that bounds a wave; with the group matrix
-//     below only two waves per SIMD fit, so the depth has to come from the pipeline).
+//     is accumulated (the row_splits -> index -> record chain is the latency that bounds a wave; the pipeline gives the
+//     depth that the two to four waves per SIMD alone do not).
 //   * Per voxel the 64 cells x 4 features are ONE 16 x 16 accumulator tile D[i = cy + 4 cz][j = c + 4 cx], four pairs
 //     per v_mfma_f32_16x16x4_f32, quads counted from the ROW start (a lane whose pair lies beyond the row end feeds a
 //     zero B operand): a row's result does not depend on which rows share its chunk.
-//   * Every 16 voxels the 16 x 256 matrix parked in LDS is contracted with the 256 x cout filter matrix in 128
-//     v_mfma_f32_16x16x4_f32 (exact f32; the filter fragments, 128 floats per lane, stay in registers for the whole
-//     persistent kernel).  k order: MFMA step (j, t) of k-lane g contracts k = 16 j + 4 g + t on both operands, so the
-//     A fragment of four steps is one ds_read_b128; the LDS rows are 264 floats apart (conflict-free for that read).
+//   * Every CCG voxels the CCG x 256 matrix parked in LDS is contracted with the 256 x cout filter matrix on the f32 matrix
+//     cores (exact f32 products, f32 accumulate); the two forms of the contraction are described at the template below.
+//     CCG == 16: MFMA step (j, t) of k-lane g contracts k = 16 j + 4 g + t on both operands, so the A fragment of four
+//     steps is one ds_read_b128; the LDS rows are 264 floats apart (conflict-free for that read, and for CCG == 4's).
 // ------------------------------------------------------------------------------------------
-constexpr int CCG = 16;        // voxels per contraction group
 constexpr int CCG_LD = 264;    // floats per LDS row of the group matrix
+#ifndef ASR_CCONV_GROUP
+#define ASR_CCONV_GROUP 4
+#endif
 constexpr int CCS = 64;        // voxels per super-group (one per lane)
 constexpr int CC_PAIR_LD = 160;  // float4 per wave: 64 pairs x 2 + 16 zero pairs (quads are read four at a time, up to 15 beyond a batch)
 // SORTED: neighbours are positions into the 32-byte records `rec`; else `rec` is unused and positions / features
 // come from the AoS arrays inp_pos [N,3] / inp_feat [N,4] at original indices (the generic operator boundary):
 // same arithmetic, so both layouts give identical bits.
-template <bool SORTED>
-__global__ __launch_bounds__(512, 2) void k_cconv_mfma(
+// CCG = voxels per contraction group.
+//   16 (rounds 2-5): the group matrix is the A operand of v_mfma_f32_16x16x4_f32, the filter fragments live in 128 registers:
+//      8 waves per CU (135 KB of group matrices, 200 registers).
+//   4 (round 6): the 16 blocks of v_mfma_f32_4x4x1_16B_f32 are (8 groups of four output channels) x (two halves of k): block
+//      (og, kh) accumulates out[voxel i][4 og + j] over k = 128 kh + s -- the same multiply-adds per cycle as the 16 x 16 x 4
+//      form with 4 voxels per group instead of 16.  The filter leaves the registers for 32 KB of LDS shared by the block (one
+//      ds_read_b128 per four steps and lane, as for the group matrix); the two halves of k are added with one lane exchange
+//      per output.  16 waves per CU (4 per SIMD) instead of 8: the kernel is bound by the latency of its dependent chains
+//      (one wave per SIMD: 2.48 ms, two: 1.56 ms).
+constexpr int cconv_waves(int ccg) { return ccg == 16 ? 8 : 16; }
+template <bool SORTED, int CCG>
+__global__ __launch_bounds__(cconv_waves(CCG) * 64) void k_cconv_mfma(
         const float* __restrict__ filters, const float* __restrict__ out_pos, const float* __restrict__ extents,
         const float4* __restrict__ rec, const float* __restrict__ inp_pos, const float* __restrict__ inp_feat,
         const int32_t* __restrict__ nidx, const float* __restrict__ nimp,
@@ -305,9 +317,12 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
     // are written; the contraction happens in the caller (dW = B^T g)
     // out_absmax != null: the running maximum of |out| for the f16x2 sparse conv that reads it (one atomic per wave)
     unsigned amax = 0;
-    __shared__ __attribute__((aligned(16))) float s_bt[8][CCG][CCG_LD];
-    __shared__ __attribute__((aligned(16))) float4 s_pair[8][CC_PAIR_LD];
-    __shared__ float s_norm[8][CCG];
+    constexpr int NW = cconv_waves(CCG);
+    __shared__ __attribute__((aligned(16))) float s_bt[NW][CCG][CCG_LD];
+    __shared__ __attribute__((aligned(16))) float4 s_pair[NW][CC_PAIR_LD];
+    __shared__ float s_norm[NW][CCG];
+    // CCG == 4: s_w[u][lane = 4 (og + 8 kh) + j] = W[k = 128 kh + 4 u + t][o = 4 og + j], t = 0..3
+    __shared__ __attribute__((aligned(16))) float4 s_w[CCG == 16 ? 1 : 32 * 64];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n = lane & 15, g = lane >> 4;
@@ -318,19 +333,32 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
     const float b_cx = (float)(n >> 2);                         // B operand: column j = n -> cx = j / 4, channel j % 4
     const int b_c = n & 3;
     // filter fragments: wreg[T][j][t] = W[k = 16 j + 4 g + t][o = 16 T + n], W = filters viewed as [256][cout]
-    float wreg[2][16][4];
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int o = 16 * T + n;
-                wreg[T][j][t] = o < cout ? filters[(i64)(16 * j + 4 * g + t) * cout + o] : 0.f;
-            }
+    float wreg[CCG == 16 ? 2 : 1][CCG == 16 ? 16 : 1][4];
     float bias_o[2];
+    if constexpr (CCG == 16) {
 #pragma unroll
-    for (int T = 0; T < 2; ++T) bias_o[T] = (bias && 16 * T + n < cout) ? bias[16 * T + n] : 0.f;
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int o = 16 * T + n;
+                    wreg[T][j][t] = o < cout ? filters[(i64)(16 * j + 4 * g + t) * cout + o] : 0.f;
+                }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) bias_o[T] = (bias && 16 * T + n < cout) ? bias[16 * T + n] : 0.f;
+    } else {
+        for (int e = threadIdx.x; e < 32 * 64; e += NW * 64) {
+            const int u = e >> 6, l = e & 63, o = l & 31, k0 = 128 * (l >> 5) + 4 * u;
+            float w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = (o < cout && !basis_out) ? filters[(i64)(k0 + t) * cout + o] : 0.f;
+            s_w[e] = make_float4(w[0], w[1], w[2], w[3]);
+        }
+        bias_o[0] = (bias && (lane & 31) < cout) ? bias[lane & 31] : 0.f;  // lane = output channel (both halves of k)
+        bias_o[1] = 0.f;
+        __syncthreads();
+    }
     if (lane < CC_PAIR_LD - 128) s_pair[wib][128 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // never written again
 
     float4* const sp4 = &s_pair[wib][0];
@@ -444,6 +472,39 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
         // contraction of the 16 voxels q0 + 16 k .. parked in s_bt
         auto contract = [&](int k) __attribute__((always_inline)) {
             __builtin_amdgcn_wave_barrier();
+            if constexpr (CCG == 4) {
+                // lane 4 b + i supplies A = group matrix[voxel i][128 kh + s], lane 4 b + j supplies B = W[128 kh + s][4 og + j]
+                // (b = og + 8 kh); four independent chains (s mod 4) so that consecutive instructions do not wait for each other
+                f32x4 acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const float* arow = &s_bt[wib][lane & 3][128 * (lane >> 5)];
+#pragma unroll  // (all 64 reads up front: -4 % against groups of eight)
+                for (int u = 0; u < 32; ++u) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * u);
+                    const float4 b4 = s_w[u * 64 + lane];
+                    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.x, b4.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.y, b4.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.z, b4.z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4.w, b4.w, acc[3], 0, 0, 0);
+                }
+                // acc[.][r] = partial out[voxel r][o = lane & 31] of this lane's half of k
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+                    v += __shfl_xor(v, 32, 64);
+                    const i64 q = q0 + 4 * k + r;
+                    const float norm = s_norm[wib][r];
+                    if (q >= num_out || norm < 0.f) continue;
+                    if (normalize && norm != 0.f) v = v / norm;
+                    v += bias_o[0];
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (lane < cout && lane < 32) {
+                        out[q * cout + lane] = v;
+                        amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+                    }
+                }
+            } else {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -474,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void k_cconv_mfma(
                         amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
                     }
                 }
+            }
             }
             __builtin_amdgcn_wave_barrier();  // the group matrix is re-used by the next group
         };
@@ -1516,13 +1578,13 @@ int asr_conv_cconv(asr_hip_context* ctx, const float* filters, const float* out_
     else                                  \
         ASR_LAUNCH_CCONV_HEAVY_S(C_, false)
     if (mfma_path) {
-        // contraction on the matrix cores: one persistent 8-wave block per CU (152 KB of LDS)
+        // contraction on the matrix cores: one persistent 16-wave block per CU (138 KB of LDS)
         if (sorted4)
-            k_cconv_mfma<true><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, (const float4*)inp_pos, nullptr,
+            k_cconv_mfma<true, ASR_CCONV_GROUP><<<256, cconv_waves(ASR_CCONV_GROUP) * 64, 0, ctx->stream>>>(filters, out_pos, extents, (const float4*)inp_pos, nullptr,
                                                              nullptr, nidx, nimp, rs, num_out, cout, normalize, bias,
                                                              relu, out, CCONV_HEAVY, nullptr, nullptr, out_absmax, d_count + 2);
         else
-            k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(filters, out_pos, extents, nullptr, inp_pos, inp_feat,
+            k_cconv_mfma<false, ASR_CCONV_GROUP><<<256, cconv_waves(ASR_CCONV_GROUP) * 64, 0, ctx->stream>>>(filters, out_pos, extents, nullptr, inp_pos, inp_feat,
                                                               nidx, nimp, rs, num_out, cout, normalize, bias, relu,
                                                               out, CCONV_HEAVY, nullptr, nullptr, out_absmax, d_count + 2);
     } else if (cout <= 8)
@@ -1580,7 +1642,7 @@ int asr_conv_cconv_basis(asr_hip_context* ctx, const float* out_pos, const float
     int* tickets = arena_alloc<int>(ctx->scratch, 4);
     if (!tickets) ASR_FAIL(ctx, ASR_HIP_EHIP, "arena allocation failed");
     ASR_HIP_CHECK(ctx, hipMemsetAsync(tickets, 0, 4 * sizeof(int), ctx->stream));
-    k_cconv_mfma<false><<<256, 512, 0, ctx->stream>>>(zeros, out_pos, extents, nullptr, inp_pos, inp_feat, nidx, nimp,
+    k_cconv_mfma<false, ASR_CCONV_GROUP><<<256, cconv_waves(ASR_CCONV_GROUP) * 64, 0, ctx->stream>>>(zeros, out_pos, extents, nullptr, inp_pos, inp_feat, nidx, nimp,
                                                       rs, num_out, 0, 0, nullptr, 0, nullptr,
                                                       (i64)0x7fffffff, basis_out, norm_out, nullptr, tickets);
     ASR_CHECK_LAUNCH(ctx);

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(cconv_waves(CCG) * 64) void k_cconv_mfma(
         };
         f32x4 D = {0.f, 0.f, 0.f, 0.f};  // the voxel being accumulated (carried over chunks for rows of more than 64 pairs)
         float nl = 0.f;                  // its importance, summed per lane over the row's batches
-        // contraction of the 16 voxels q0 + 16 k .. parked in s_bt
+        // contraction of the CCG voxels q0 + CCG k .. parked in s_bt
         auto contract = [&](int k) __attribute__((always_inline)) {
             __builtin_amdgcn_wave_barrier();
             if constexpr (CCG == 4) {

@@ -44,7 +44,7 @@ def test_aggregation_importance_and_continuous_conv(geo, gpu):
     imp_ref = (item["aggregation_scale_compat"] * O.window_poly6(item["aggregation_neighbors_dist"]))
     _close(imp.cpu().numpy(), imp_ref, 1e-7)
     feats = np.concatenate([nrm, np.ones((len(pts), 1), np.float32)], 1)
-    for cout in (8, 32):
+    for cout in (8, 32, 5, 20):  # (widths that leave lanes of the contraction's output blocks idle too)
         W = (rng.standard_normal((4, 4, 4, 4, cout)) * 0.7).astype(np.float32)
         b = rng.standard_normal(cout).astype(np.float32) * 0.1
         for nimp, normalize in ((imp_ref.astype(np.float32), True), (None, True), (None, False)):
